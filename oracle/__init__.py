@@ -1,0 +1,20 @@
+"""CPU oracle for the LFM sampling hot path -- TEST INFRASTRUCTURE ONLY.
+
+Nothing under ``oracle/`` is product code.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+it, and only as the checker.  The shipped path lives in ``lfm_amd/`` and
+fails loudly when the HIP library is missing; it never routes through here.
+
+Pinning status (see DESIGN.md "Oracle"):
+
+* ``dit_ref`` / ``unet_ref`` / ``karras_ref`` / ``randgen_ref`` are PINNED: they
+  are checked in ``tests/test_oracle_golden.py`` against golden vectors that
+  ``oracle/make_golden.py`` produced by importing the unmodified reference
+  classes from ``/root/reference`` (behind the three-class ``timm`` shim in
+  ``oracle/timm_shim.py``).
+* ``ode_ref`` (torchdiffeq) and ``vae_ref`` (diffusers ``AutoencoderKL``
+  decoder) restate third-party packages that are neither vendored in the
+  reference nor installed here (requirements.txt:2-3, no versions):
+  **parity unpinned** for those two -- they are anchored on analytic
+  known-answer tests and on the reference's call sites only.
+"""

@@ -1,0 +1,172 @@
+"""Generate ``tests/golden/*.pt`` by running the UNMODIFIED reference (oracle tooling).
+
+Run in the build container only (``/root/reference`` does not exist on the GPU box):
+
+    python -m oracle.make_golden            # rewrites tests/golden/
+
+What is imported from the reference, as-is:
+  * models/DiT.py           (behind oracle/timm_shim.py -- timm is not installed)
+  * models/guided_diffusion/unet.py  (UNetModel)
+  * sampler/karras_sample.py, sampler/random_util.py
+Every fixture stores the reference state_dict (tiny configs, so the files stay small), the
+seeded inputs and the reference outputs.  torchdiffeq / diffusers have no fixture: they are not
+installable here (parity unpinned, see oracle/__init__.py).
+"""
+import os
+import sys
+
+import torch
+
+REF = os.environ.get("LFM_REFERENCE", "/root/reference")
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def _import_reference():
+    from oracle import timm_shim
+
+    timm_shim.install()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import models.DiT as ref_dit  # noqa
+    import sampler.karras_sample as ref_karras  # noqa
+    import sampler.random_util as ref_rand  # noqa
+
+    return ref_dit, ref_karras, ref_rand
+
+
+def _dezero_module(m, seed):
+    from oracle.dit_ref import dezero_
+
+    sd = m.state_dict()
+    n = dezero_(sd, seed=seed)
+    m.load_state_dict(sd)
+    return n
+
+
+def golden_dit(ref_dit):
+    out = {}
+    g = torch.Generator().manual_seed(42)
+    for name, kw in {
+        "cond": dict(num_classes=10, label_dropout=0.1),
+        "uncond": dict(num_classes=1, label_dropout=0.0),
+    }.items():
+        torch.manual_seed(0)
+        m = ref_dit.DiT(img_resolution=32, patch_size=2, in_channels=4, hidden_size=128, depth=2, num_heads=2, **kw).eval()
+        nz = _dezero_module(m, 1234)
+        # give biases some signal too (reference init zeroes every Linear bias, DiT.py:196-200)
+        sd = m.state_dict()
+        for k in sd:
+            if k.endswith(".bias"):
+                sd[k].copy_(torch.randn(sd[k].shape, generator=g) * 0.02)
+        m.load_state_dict(sd)
+        x = torch.randn(3, 4, 32, 32, generator=g)
+        rec = {"cfg": dict(depth=2, hidden=128, patch=2, heads=2, img_resolution=32, in_channels=4, **kw),
+               "state_dict": {k: v.clone() for k, v in m.state_dict().items()}, "x": x, "dezeroed": nz}
+        with torch.no_grad():
+            t0 = torch.tensor(0.37)
+            tN = torch.tensor([0.9, 0.5, 0.02])
+            if name == "cond":
+                y = torch.tensor([3, 0, 9])
+                rec["y"] = y
+                rec["v_t0d"] = m(t0, x, y)
+                rec["v_tN"] = m(tN, x, y)
+                rec["v_ynone"] = m(t0, x)  # y=None => null class row
+                x2 = torch.cat([x[:2], x[:2]], 0)
+                y2 = torch.tensor([3, 7, 10, 10])
+                rec["x_cfg"], rec["y_cfg"], rec["cfg_scale"] = x2, y2, 1.5
+                rec["v_cfg"] = m.forward_with_cfg(t0, x2, y2, cfg_scale=1.5)
+            else:
+                rec["v_t0d"] = m(t0, x)
+                rec["v_tN"] = m(tN, x)
+        out[name] = rec
+    return out
+
+
+def golden_karras(ref_karras, ref_rand):
+    """sample_euler / sample_heun on a cheap nonlinear field; includes the steps=40 quirk."""
+    g = torch.Generator().manual_seed(7)
+    A = torch.randn(16, 16, generator=g) * 0.3
+
+    class Field:
+        def __call__(self, t, x, **kw):
+            flat = x.flatten(1)
+            return (torch.tanh(flat @ A) * (1.0 + t[:, None]) - 0.5 * flat).reshape(x.shape)
+
+        forward_with_cfg = None
+
+    x = torch.randn(5, 1, 4, 4, generator=g)
+    out = {"A": A, "x": x}
+    gen = ref_rand.get_generator("dummy")
+    for sampler, steps in (("euler", 11), ("euler", 51), ("heun", 11), ("heun", 50), ("heun", 40)):
+        r = ref_karras.karras_sample(Field(), x.clone(), steps=steps, model_kwargs={}, device="cpu",
+                                     clip_denoised=False, sigma_min=1e-5, sigma_max=1.0, s_tmin=0.0,
+                                     s_tmax=1.0, s_churn=0.0, sampler=sampler, generator=gen)
+        out[f"{sampler}_{steps}"] = r
+    return out
+
+
+def golden_randgen(ref_rand):
+    out = {}
+    for n, seed, bs in ((64, 42, 8), (10, 7, 4)):
+        gen = ref_rand.get_generator("determ", n, seed)
+        out[f"determ_n{n}_s{seed}_randn"] = gen.randn(bs, 4, 8, 8)
+        out[f"determ_n{n}_s{seed}_randn2"] = gen.randn(bs, 4, 8, 8)  # second draw advances the stream
+        out[f"determ_n{n}_s{seed}_randint"] = gen.randint(0, 1000, (bs,))
+    gen = ref_rand.get_generator("determ-indiv", 6, 3)
+    out["indiv_n6_s3_randn"] = gen.randn(4, 2, 3, 3)
+    # rank/world slicing (random_util.py:58-67) emulated by poking the attributes dist would set
+    gen = ref_rand.get_generator("determ", 64, 42)
+    gen.rank, gen.world_size = 1, 4
+    out["determ_n64_s42_rank1of4_randn"] = gen.randn(8, 4, 8, 8)
+    return out
+
+
+def golden_unet():
+    sys.path.insert(0, REF)
+    from models.guided_diffusion.unet import UNetModel
+
+    out = {}
+    g = torch.Generator().manual_seed(11)
+    cfgs = {
+        "ssn": dict(image_size=16, in_channels=4, model_channels=32, out_channels=4, num_res_blocks=1,
+                    attention_resolutions=(2,), dropout=0.0, channel_mult=(1, 2), conv_resample=True, dims=2,
+                    num_classes=None, use_checkpoint=False, use_fp16=False, num_heads=2, num_head_channels=-1,
+                    num_heads_upsample=-1, use_scale_shift_norm=True, resblock_updown=False,
+                    use_new_attention_order=False),
+        "cls": dict(image_size=16, in_channels=4, model_channels=32, out_channels=4, num_res_blocks=1,
+                    attention_resolutions=(1, 2), dropout=0.0, channel_mult=(1, 1), conv_resample=True, dims=2,
+                    num_classes=5, use_checkpoint=False, use_fp16=False, num_heads=4, num_head_channels=-1,
+                    num_heads_upsample=-1, use_scale_shift_norm=True, resblock_updown=False,
+                    use_new_attention_order=False),
+    }
+    for name, kw in cfgs.items():
+        torch.manual_seed(0)
+        m = UNetModel(**kw).eval()
+        _dezero_module(m, 4321)
+        x = torch.randn(2, 4, 16, 16, generator=g)
+        t = torch.tensor([0.8, 0.1])
+        rec = {"cfg": kw, "state_dict": {k: v.clone() for k, v in m.state_dict().items()}, "x": x, "t": t}
+        with torch.no_grad():
+            if kw["num_classes"]:
+                y = torch.tensor([1, 4])
+                rec["y"] = y
+                rec["v"] = m(t, x, y)
+            else:
+                rec["v"] = m(t, x)
+        out[name] = rec
+    return out
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref_dit, ref_karras, ref_rand = _import_reference()
+    torch.save(golden_dit(ref_dit), os.path.join(OUT, "dit_tiny.pt"))
+    torch.save(golden_karras(ref_karras, ref_rand), os.path.join(OUT, "karras.pt"))
+    torch.save(golden_randgen(ref_rand), os.path.join(OUT, "randgen.pt"))
+    torch.save(golden_unet(), os.path.join(OUT, "unet_tiny.pt"))
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()

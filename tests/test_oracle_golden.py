@@ -1,0 +1,53 @@
+"""Pin the oracle restatements against fixtures produced by the unmodified reference
+(oracle/make_golden.py).  CPU only."""
+import os
+
+import pytest
+import torch
+
+from oracle import dit_ref
+
+
+def _load(golden_dir, name):
+    return torch.load(os.path.join(golden_dir, name), map_location="cpu", weights_only=False)
+
+
+@pytest.mark.parametrize("which", ["cond", "uncond"])
+def test_dit_ref_matches_reference(golden_dir, which):
+    rec = _load(golden_dir, "dit_tiny.pt")[which]
+    cfg = dit_ref.DiTCfg(**rec["cfg"])
+    sd, x = rec["state_dict"], rec["x"]
+    assert rec["dezeroed"] >= 6  # adaLN w/b per block + final: the zero-init trap is defused
+    y = rec.get("y")
+    v = dit_ref.dit_forward(sd, cfg, torch.tensor(0.37), x, y)
+    assert float(rec["v_t0d"].abs().mean()) > 1e-3  # not comparing 0 with 0
+    torch.testing.assert_close(v, rec["v_t0d"], rtol=1e-5, atol=1e-6)
+    v = dit_ref.dit_forward(sd, cfg, torch.tensor([0.9, 0.5, 0.02]), x, y)
+    torch.testing.assert_close(v, rec["v_tN"], rtol=1e-5, atol=1e-6)
+    if which == "cond":
+        v = dit_ref.dit_forward(sd, cfg, torch.tensor(0.37), x, None)
+        torch.testing.assert_close(v, rec["v_ynone"], rtol=1e-5, atol=1e-6)
+        v = dit_ref.dit_forward_with_cfg(sd, cfg, torch.tensor(0.37), rec["x_cfg"], rec["y_cfg"], rec["cfg_scale"])
+        torch.testing.assert_close(v, rec["v_cfg"], rtol=1e-5, atol=1e-6)
+
+
+def test_pos_embed_closed_form(golden_dir):
+    rec = _load(golden_dir, "dit_tiny.pt")["cond"]
+    pe = dit_ref.sincos_pos_embed_2d(128, 16)
+    torch.testing.assert_close(pe, rec["state_dict"]["pos_embed"], rtol=0, atol=1e-6)
+
+
+def test_make_dit_state_names_match_reference(golden_dir):
+    rec = _load(golden_dir, "dit_tiny.pt")["cond"]
+    cfg = dit_ref.DiTCfg(**rec["cfg"])
+    mine = dit_ref.make_dit_state(cfg, seed=3)
+    assert set(mine) == set(rec["state_dict"])
+    for k, v in rec["state_dict"].items():
+        assert tuple(mine[k].shape) == tuple(v.shape), k
+    v = dit_ref.dit_forward(mine, cfg, torch.tensor(0.5), rec["x"], rec["y"])
+    assert torch.isfinite(v).all() and float(v.abs().mean()) > 1e-3
+
+
+def test_flops_closed_form():
+    assert abs(dit_ref.dit_flops_per_image(dit_ref.DiTCfg.named("DiT-L/2")) / 1e9 - 161.4) < 0.5
+    assert abs(dit_ref.dit_flops_per_image(dit_ref.DiTCfg.named("DiT-B/2")) / 1e9 - 46.0) < 0.3
