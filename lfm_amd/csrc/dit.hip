@@ -1,0 +1,581 @@
+// DiT velocity field on gfx950: the kernels around the MFMA GEMMs and the per-call driver.
+// Reference behaviour: /root/reference/models/DiT.py (cited per kernel).
+#include "../../include/lfm_hip.h"
+#include "gemm_kernel.h"
+
+// ------------------------------------------------------------------ timestep embedder (DiT.py:29-69)
+// temb[r] = W2 * silu(W0 * [cos(t f) | sin(t f)] + b0) + b2, one block per row, fp32 throughout.
+__global__ __launch_bounds__(256) void temb_kernel(const float* __restrict__ t, const float* __restrict__ w0, const float* __restrict__ b0,
+                                                   const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ temb,
+                                                   int D) {
+  __shared__ float emb[256];
+  extern __shared__ float h1[];  // [D]
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float tv = t[r];
+  {
+    const int i = tid & 127;
+    const float f = __expf(-9.210340371976184f * (float)i / 128.0f);  // exp(-ln(1e4) i/half)
+    const float a = tv * f;
+    emb[tid] = (tid < 128) ? cosf(a) : sinf(a);
+  }
+  __syncthreads();
+  for (int j = wave; j < D; j += 4) {
+    const float* w = w0 + (long)j * 256;
+    float s = 0.f;
+#pragma unroll
+    for (int k = lane; k < 256; k += 64) s += w[k] * emb[k];
+    s = wave_sum(s);
+    if (lane == 0) h1[j] = silu_f(s + b0[j]);
+  }
+  __syncthreads();
+  for (int j = wave; j < D; j += 4) {
+    const float* w = w2 + (long)j * D;
+    float s = 0.f;
+    for (int k = lane; k < D; k += 64) s += w[k] * h1[k];
+    s = wave_sum(s);
+    if (lane == 0) temb[(long)r * D + j] = s + b2[j];
+  }
+}
+
+// c_half[r] = fp16(silu(temb[t_len==1 ? 0 : r] + y_table[y ? y[r] : null_row]))   (DiT.py:259-264 + the SiLU of :125)
+__global__ void cond_kernel(const float* __restrict__ temb, int t_len, const float* __restrict__ y_table, const int64_t* __restrict__ y,
+                            int null_row, half_t* __restrict__ c_half, int D, int rows) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows * D) return;
+  const int r = (int)(i / D), j = (int)(i - (long)r * D);
+  const long yr = y ? (long)y[r] : (long)null_row;
+  const float v = temb[(t_len == 1 ? 0 : (long)r * D) + j] + y_table[yr * D + j];
+  c_half[i] = (half_t)silu_f(v);
+}
+
+// ------------------------------------------------------------------ patch embed (timm PatchEmbed + pos_embed, DiT.py:179,261)
+// X[n*T + tok][j] = b[j] + pos[tok][j] + sum_{c,p,q} W[j][c][p][q] * x[n % xmod][c][hp+p][wp+q]; 4 outputs per thread.
+__global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                          const float* __restrict__ pos, float* __restrict__ X, int batch, int xmod, int C,
+                                                          int R, int p, int D) {
+  const int grid = R / p, T = grid * grid, KK = C * p * p;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int d4 = D / 4;
+  if (idx >= (long)batch * T * d4) return;
+  const int j = (int)(idx % d4) * 4;
+  const long m = idx / d4;
+  const int tok = (int)(m % T), n = (int)(m / T) % xmod;
+  const int hp = (tok / grid) * p, wp = (tok % grid) * p;
+  f32x4 acc = *(const f32x4*)(b + j) + *(const f32x4*)(pos + (long)tok * D + j);
+  for (int c = 0; c < C; ++c)
+    for (int pp = 0; pp < p; ++pp)
+      for (int q = 0; q < p; ++q) {
+        const float xv = x[(((long)n * C + c) * R + hp + pp) * R + wp + q];
+        const int k = (c * p + pp) * p + q;
+        acc.x += w[(long)(j + 0) * KK + k] * xv;
+        acc.y += w[(long)(j + 1) * KK + k] * xv;
+        acc.z += w[(long)(j + 2) * KK + k] * xv;
+        acc.w += w[(long)(j + 3) * KK + k] * xv;
+      }
+  *(f32x4*)(X + m * D + j) = acc;
+}
+
+// ------------------------------------------------------------------ LayerNorm + modulate -> fp16 (DiT.py:20-21,119,129-130)
+// one wave per token row; the row stays in registers (<= 5 float4 per lane => D <= 1280).
+#define LN_MAXV 5
+__global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restrict__ X, half_t* __restrict__ A, int M, int D, int tokens,
+                                                          const float* __restrict__ shift, const float* __restrict__ scale, long mod_stride) {
+  const int lane = threadIdx.x & 63;
+  const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const int nv = D >> 2;
+  const f32x4* xr = (const f32x4*)(X + m * D);
+  f32x4 v[LN_MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nv) {
+      v[i] = xr[c];
+      s += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nv) {
+      v[i] -= mean;
+      q += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)D + 1e-6f);
+  const long mo = (m / tokens) * mod_stride;
+  const f32x4* sh = (const f32x4*)(shift + mo);
+  const f32x4* sc = (const f32x4*)(scale + mo);
+  half4_t* ar = (half4_t*)(A + m * D);
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nv) {
+      const f32x4 o = v[i] * rstd * (1.0f + sc[c]) + sh[c];
+      half4_t h = {(half_t)o.x, (half_t)o.y, (half_t)o.z, (half_t)o.w};
+      ar[c] = h;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ attention (timm Attention core, DiT.py:120)
+// One workgroup per (head, image); T/64 waves, each owning 64 queries (two 32-query blocks, processed
+// together so every K / V^T fragment read from LDS feeds two MFMAs).
+// K [T][64] and V^T [64][T] of the head are staged once into LDS by LDS-DMA (XOR-swizzled source).
+// S^T = K Q^T on v_mfma_f32_32x32x16_f16: a lane then holds, for ONE query (lane&31), the scores of
+// keys kb*32 + 8g + 4*(lane>>5) + r -- row max / row sum are in-lane plus one lane^32 exchange, and the
+// fp32->fp16 packed P registers are directly the B-operand of O^T = V^T P^T (the key order inside an
+// MFMA k-slot is the same permutation on both operands, so no shuffle is needed).
+// Keys are consumed in 32-key blocks with an online softmax (running max m, running sum l), which keeps
+// the live state at S 32 + P 16 + O 64 + Q 32 registers (2 waves / SIMD).
+template <int T>
+__global__ __launch_bounds__(T, 2) void dit_attention_kernel(const half_t* __restrict__ Q, const half_t* __restrict__ K,
+                                                            const half_t* __restrict__ Vt, half_t* __restrict__ O, int D, int heads,
+                                                            float scale_log2e) {
+  constexpr int NKB = T / 32;  // 32-key blocks
+  constexpr int NW = T / 64;   // waves
+  constexpr int VKEY = (T / 8 - 1) < 15 ? (T / 8 - 1) : 15;  // V^T swizzle key mask (stays inside the row)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;             // [T][64] halves, 128-B rows, chunk' = chunk ^ ((row>>1)&7)
+  char* Vs = smem + T * 128;   // [64][T] halves, 2T-B rows, chunk' = chunk ^ (row&VKEY)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int head = blockIdx.x, img = blockIdx.y;
+  const half_t* Kg = K + (long)img * T * D + head * 64;
+  const half_t* Vg = Vt + ((long)img * heads + head) * 64 * T;
+
+  // ---- stage K and V^T (T*128 bytes each)
+#pragma unroll
+  for (int p = 0; p < (T * 8) / (NW * 64); ++p) {
+    const int s = p * (NW * 64) + tid;
+    {
+      const int row = s >> 3, c = (s & 7) ^ ((row >> 1) & 7);
+      glds16(Kg + (long)row * D + c * 8, Ks + (p * NW * 64 + wave * 64) * 16);
+    }
+    {
+      constexpr int CPR = T / 8;  // 16-B chunks per V^T row
+      const int row = s / CPR, c = (s % CPR) ^ (row & VKEY);
+      glds16(Vg + (long)row * T + c * 8, Vs + (p * NW * 64 + wave * 64) * 16);
+    }
+  }
+
+  // ---- Q fragments straight from global (each used by this wave only)
+  const int q0 = wave * 64;
+  const int hsel = lane >> 5, l31 = lane & 31;
+  half8_t qf[2][4];
+#pragma unroll
+  for (int jq = 0; jq < 2; ++jq)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      qf[jq][ks] = *(const half8_t*)(Q + ((long)img * T + q0 + jq * 32 + l31) * D + head * 64 + ks * 16 + hsel * 8);
+
+  f32x16 Oa[2][2];  // [jq][db]
+#pragma unroll
+  for (int jq = 0; jq < 2; ++jq)
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) Oa[jq][db][e] = 0.f;
+  float mrun[2] = {-3.0e38f, -3.0e38f}, lrun[2] = {0.f, 0.f};
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int vkey = l31 & VKEY;  // rows d and d+32 share the key (VKEY <= 15)
+#pragma unroll 1
+  for (int kb = 0; kb < NKB; ++kb) {
+    // ---- S^T block: 32 keys x 64 queries
+    f32x16 S[2];
+#pragma unroll
+    for (int jq = 0; jq < 2; ++jq)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) S[jq][e] = 0.f;
+    {
+      const int row = kb * 32 + l31;
+      const int key = (row >> 1) & 7;
+      const char* kp = Ks + row * 128;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const half8_t kf = *(const half8_t*)(kp + (((ks * 2 + hsel) ^ key) << 4));
+        S[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[0][ks], S[0], 0, 0, 0);
+        S[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[1][ks], S[1], 0, 0, 0);
+      }
+    }
+    // ---- online softmax update for the two queries this lane owns
+    half8_t P[2][2];
+#pragma unroll
+    for (int jq = 0; jq < 2; ++jq) {
+      float mx = S[jq][0];
+#pragma unroll
+      for (int e = 1; e < 16; ++e) mx = fmaxf(mx, S[jq][e]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mnew = fmaxf(mrun[jq], mx);
+      const float alpha = __builtin_amdgcn_exp2f((mrun[jq] - mnew) * scale_log2e);
+      mrun[jq] = mnew;
+      const float mb = mnew * scale_log2e;
+      float sum = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float pe = __builtin_amdgcn_exp2f(S[jq][e] * scale_log2e - mb);
+        sum += pe;
+        P[jq][e >> 3][e & 7] = (half_t)pe;
+      }
+      lrun[jq] = lrun[jq] * alpha + sum;
+#pragma unroll
+      for (int db = 0; db < 2; ++db) Oa[jq][db] *= alpha;
+    }
+    // ---- O^T[d][q] += sum_key V^T[d][key] P[q][key]
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const int d = db * 32 + l31;
+        const int c0 = kb * 4 + 2 * s;
+        const char* rowp = Vs + d * (2 * T) + hsel * 8;
+        const half4_t lo = *(const half4_t*)(rowp + ((c0 ^ vkey) << 4));
+        const half4_t hi = *(const half4_t*)(rowp + (((c0 + 1) ^ vkey) << 4));
+        const half8_t vf = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        Oa[0][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, P[0][s], Oa[0][db], 0, 0, 0);
+        Oa[1][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, P[1][s], Oa[1][db], 0, 0, 0);
+      }
+    }
+  }
+  // ---- normalise and store: lane owns query q, d = db*32 + 8g + 4*hsel + r
+#pragma unroll
+  for (int jq = 0; jq < 2; ++jq) {
+    const float inv = 1.0f / (lrun[jq] + __shfl_xor(lrun[jq], 32, 64));
+    half_t* orow = O + ((long)img * T + q0 + jq * 32 + l31) * D + head * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        half4_t h = {(half_t)(Oa[jq][db][4 * g] * inv), (half_t)(Oa[jq][db][4 * g + 1] * inv), (half_t)(Oa[jq][db][4 * g + 2] * inv),
+                     (half_t)(Oa[jq][db][4 * g + 3] * inv)};
+        *(half4_t*)(orow + db * 32 + 8 * g + 4 * hsel) = h;
+      }
+  }
+}
+
+// ------------------------------------------------------------------ final layer + unpatchify + solver update
+// (DiT.py:134-149,230-243,270-271; CFG combine :285-287; Euler update test_flow_latent.py:61-73 via torchdiffeq)
+// one wave per token (pair of tokens under CFG).  out[n][c][hp+p][wp+q] = base + dt * v, v = linear(modulate(LN(x)))[(p*P+q)*C + c]
+#define FIN_MAXO 64
+template <bool CFG>
+__global__ __launch_bounds__(256) void final_layer_kernel(const float* __restrict__ X, int M, int D, int tokens, const float* __restrict__ shift,
+                                                          const float* __restrict__ scale, long mod_stride, const float* __restrict__ Wf,
+                                                          const float* __restrict__ bf, int C, int R, int p, float cfg_scale,
+                                                          float* out, const float* base, const float* __restrict__ dt_ptr) {
+  const int lane = threadIdx.x & 63;
+  const long mrow = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int Mh = CFG ? M / 2 : M;
+  if (mrow >= Mh) return;
+  const int nv = D >> 2, NO = p * p * C;
+  float res[2] = {0.f, 0.f};  // lane o < NO holds output o of (cond, uncond)
+#pragma unroll
+  for (int half = 0; half < (CFG ? 2 : 1); ++half) {
+    const long m = mrow + (long)half * Mh;
+    const f32x4* xr = (const f32x4*)(X + m * D);
+    f32x4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nv) {
+        v[i] = xr[c];
+        s += v[i].x + v[i].y + v[i].z + v[i].w;
+      }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nv) {
+        v[i] -= mean;
+        q += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + 1e-6f);
+    const long mo = (m / tokens) * mod_stride;
+    const f32x4* sh = (const f32x4*)(shift + mo);
+    const f32x4* sc = (const f32x4*)(scale + mo);
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nv) v[i] = v[i] * rstd * (1.0f + sc[c]) + sh[c];
+    }
+    for (int o = 0; o < NO; ++o) {
+      const f32x4* wr = (const f32x4*)(Wf + (long)o * D);
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+          const f32x4 w4 = wr[c];
+          a += v[i].x * w4.x + v[i].y * w4.y + v[i].z * w4.z + v[i].w * w4.w;
+        }
+      }
+      a = wave_sum(a) + bf[o];
+      if (lane == o) res[half] = a;
+    }
+  }
+  if (lane < NO) {
+    float v = CFG ? res[1] + cfg_scale * (res[0] - res[1]) : res[0];
+    const int grid = R / p;
+    const int n = (int)(mrow / tokens), tok = (int)(mrow % tokens);
+    const int pp = lane / (p * C), qq = (lane / C) % p, c = lane % C;
+    const long off = (((long)n * C + c) * R + (tok / grid) * p + pp) * R + (tok % grid) * p + qq;
+    const long hoff = (long)(Mh / tokens) * C * R * R;  // second (uncond) half of the batch
+    if (base) {
+      const float dt = *dt_ptr;
+      out[off] = base[off] + dt * v;
+      if (CFG) out[off + hoff] = base[off + hoff] + dt * v;
+    } else {
+      out[off] = v;
+      if (CFG) out[off + hoff] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ solver helpers
+__global__ void grid_advance_kernel(const float* ts, const float* dts, int* step, float* t_cur, float* dt_cur) {
+  const int s = *step;
+  *t_cur = ts[s];
+  *dt_cur = dts[s];
+  *step = s + 1;
+}
+
+struct LinPtrs {
+  const float* k[8];
+};
+__global__ void lincomb_kernel(float* __restrict__ out, const float* __restrict__ base, LinPtrs ks, const float* __restrict__ coef, int nk,
+                               long n4) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 acc = base ? ((const f32x4*)base)[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < nk; ++j) {
+    const float c = coef[j];
+    if (c != 0.f) acc += c * ((const f32x4*)ks.k[j])[i];
+  }
+  ((f32x4*)out)[i] = acc;
+}
+
+// ------------------------------------------------------------------ host side
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct DitWs {
+  float* X;       // [M, D] fp32 residual stream
+  half_t* A;      // [M, D] LN output / attention output
+  half_t* QKVH;   // max(3*M*D, M*H): Q | K | Vt, later the fc1 activation
+  float* temb;    // [B, D]
+  half_t* c_half; // [B, D]
+  float* mod;     // [B, J]
+  size_t total;
+};
+
+static DitWs carve(const lfm_dit_shape* s, int B, void* ws) {
+  const size_t T = (size_t)(s->res / s->patch) * (s->res / s->patch), M = (size_t)B * T, D = s->hidden, H = s->mlp_hidden;
+  const size_t J = (size_t)s->depth * 6 * D + 2 * D;
+  size_t off = 0;
+  char* base = (char*)ws;
+  DitWs w;
+  auto take = [&](size_t bytes) {
+    char* p = base ? base + off : nullptr;
+    off += align_up(bytes, 256);
+    return p;
+  };
+  w.X = (float*)take(M * D * 4);
+  w.A = (half_t*)take(M * D * 2);
+  const size_t qkvh = (3 * M * D > M * H ? 3 * M * D : M * H) * 2;
+  w.QKVH = (half_t*)take(qkvh);
+  w.temb = (float*)take((size_t)B * D * 4);
+  w.c_half = (half_t*)take((size_t)B * D * 2);
+  w.mod = (float*)take((size_t)B * J * 4);
+  w.total = off;
+  return w;
+}
+
+static int check_shape(const lfm_dit_shape* s) {
+  if (!s) return LFM_ERR_ARG;
+  if (s->depth <= 0 || s->hidden <= 0 || s->heads <= 0 || s->patch <= 0 || s->in_ch <= 0 || s->res <= 0) return LFM_ERR_SHAPE;
+  if (s->hidden % s->heads || s->hidden / s->heads != 64) return LFM_ERR_SHAPE;  // hd must be 64 (S/B/L; XL has 72)
+  if (s->res % s->patch) return LFM_ERR_SHAPE;
+  const int T = (s->res / s->patch) * (s->res / s->patch);
+  if (T != 64 && T != 128 && T != 256) return LFM_ERR_SHAPE;
+  if (s->hidden % 64 || s->hidden > 256 * LN_MAXV || s->mlp_hidden % 64) return LFM_ERR_SHAPE;
+  if (s->patch * s->patch * s->in_ch > FIN_MAXO) return LFM_ERR_SHAPE;
+  if (s->label_rows <= 0) return LFM_ERR_SHAPE;
+  return LFM_OK;
+}
+
+extern "C" const char* lfm_strerror(int code) {
+  switch (code) {
+    case LFM_OK: return "ok";
+    case LFM_ERR_SHAPE: return "unsupported or inconsistent shape";
+    case LFM_ERR_ALIGN: return "pointer / leading dimension alignment";
+    case LFM_ERR_WORKSPACE: return "workspace too small";
+    case LFM_ERR_LAUNCH: return "kernel launch failed";
+    case LFM_ERR_ARG: return "bad argument";
+  }
+  return "unknown";
+}
+extern "C" int lfm_abi_version(void) { return 1; }
+
+extern "C" size_t lfm_dit_workspace_bytes(const lfm_dit_shape* shape, int max_batch) {
+  if (check_shape(shape) != LFM_OK || max_batch <= 0) return 0;
+  return carve(shape, max_batch, nullptr).total;
+}
+
+static int attention_launch(const half_t* Q, const half_t* K, const half_t* Vt, half_t* O, int batch, int heads, int T, hipStream_t st) {
+  const int D = heads * 64;
+  const float sl2 = 0.125f * 1.4426950408889634f;  // hd^-0.5 * log2(e)
+  const size_t lds = (size_t)T * 256;
+  dim3 grid(heads, batch);
+#define ATT_CASE(TT)                                                                                                     \
+  case TT: {                                                                                                             \
+    static bool set = false;                                                                                             \
+    if (!set) {                                                                                                          \
+      (void)hipFuncSetAttribute((const void*)dit_attention_kernel<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, TT * 256);   \
+      set = true;                                                                                                        \
+    }                                                                                                                    \
+    hipLaunchKernelGGL((dit_attention_kernel<TT>), grid, dim3(TT), lds, st, Q, K, Vt, O, D, heads, sl2);                  \
+    break;                                                                                                               \
+  }
+  switch (T) {
+    ATT_CASE(64)
+    ATT_CASE(128)
+    ATT_CASE(256)
+    default: return LFM_ERR_SHAPE;
+  }
+#undef ATT_CASE
+  LFM_CHECK_LAUNCH();
+  return LFM_OK;
+}
+
+extern "C" int lfm_dit_attention(const void* Q, const void* K, const void* Vt, void* O, int batch, int heads, int T, lfm_stream_t stream) {
+  if (!Q || !K || !Vt || !O) return LFM_ERR_ARG;
+  if (batch <= 0 || heads <= 0) return LFM_ERR_SHAPE;
+  return attention_launch((const half_t*)Q, (const half_t*)K, (const half_t*)Vt, (half_t*)O, batch, heads, T, (hipStream_t)stream);
+}
+
+static int ln_modulate_launch(const float* X, half_t* A, int M, int D, int tokens, const float* shift, const float* scale, long stride,
+                              hipStream_t st) {
+  if (D % 4 || D > 256 * LN_MAXV) return LFM_ERR_SHAPE;
+  hipLaunchKernelGGL(ln_modulate_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, X, A, M, D, tokens, shift, scale, stride);
+  LFM_CHECK_LAUNCH();
+  return LFM_OK;
+}
+
+extern "C" int lfm_ln_modulate(const float* X, void* A, int M, int D, int tokens, const float* shift, const float* scale, long mod_stride,
+                               lfm_stream_t stream) {
+  if (!X || !A || !shift || !scale) return LFM_ERR_ARG;
+  if (M <= 0 || tokens <= 0) return LFM_ERR_SHAPE;
+  return ln_modulate_launch(X, (half_t*)A, M, D, tokens, shift, scale, mod_stride, (hipStream_t)stream);
+}
+
+extern "C" int lfm_gemm_f16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N, int K, const float* bias,
+                            int epilogue, const float* gate, long gate_stride, int tokens, lfm_stream_t stream) {
+  if (!A || !W || !C) return LFM_ERR_ARG;
+  if ((lda % 8) || ((uintptr_t)A & 15)) return LFM_ERR_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  ASrcRowMajor a{(const half_t*)A, lda, M};
+  switch (epilogue) {
+    case 0: return launch_gemm_tn(a, (const half_t*)W, ldw, M, N, K, EpiBiasF16{(half_t*)C, ldc, bias}, st);
+    case 1:
+      if (!bias) return LFM_ERR_ARG;
+      return launch_gemm_tn(a, (const half_t*)W, ldw, M, N, K, EpiBiasGeluF16{(half_t*)C, ldc, bias}, st);
+    case 2: return launch_gemm_tn(a, (const half_t*)W, ldw, M, N, K, EpiBiasF32{(float*)C, ldc, bias}, st);
+    case 3:
+      if (!bias || !gate || tokens <= 0) return LFM_ERR_ARG;
+      return launch_gemm_tn(a, (const half_t*)W, ldw, M, N, K, EpiGateResidF32{(float*)C, ldc, bias, gate, gate_stride, tokens}, st);
+  }
+  return LFM_ERR_ARG;
+}
+
+extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w, void* workspace, size_t workspace_bytes,
+                               const lfm_dit_call* c, lfm_stream_t stream) {
+  int rc = check_shape(s);
+  if (rc) return rc;
+  if (!w || !workspace || !c || !c->x || !c->t || !c->out) return LFM_ERR_ARG;
+  const int B = c->batch;
+  if (B <= 0 || (c->t_len != 1 && c->t_len != B)) return LFM_ERR_SHAPE;
+  const bool cfg = c->cfg != 0;
+  if (cfg && (B & 1)) return LFM_ERR_SHAPE;
+  if (c->axpy_base && !c->axpy_dt) return LFM_ERR_ARG;
+  const DitWs ws = carve(s, B, workspace);
+  if (ws.total > workspace_bytes) return LFM_ERR_WORKSPACE;
+  if ((uintptr_t)workspace & 255) return LFM_ERR_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  const int D = s->hidden, H = s->mlp_hidden, grid = s->res / s->patch, T = grid * grid, M = B * T;
+  const long J = (long)s->depth * 6 * D + 2 * D;
+
+  // conditioning rows: one shared row when time is scalar and there are no labels
+  const int rows = (c->t_len == 1 && !c->y) ? 1 : B;
+  const long mstride = rows == 1 ? 0 : J;
+  hipLaunchKernelGGL(temb_kernel, dim3(c->t_len), dim3(256), D * sizeof(float), st, c->t, w->t_w0, w->t_b0, w->t_w2, w->t_b2, ws.temb, D);
+  LFM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(cond_kernel, dim3(cdiv((long)rows * D, 256)), dim3(256), 0, st, ws.temb, c->t_len, w->y_table, c->y, s->label_rows - 1,
+                     ws.c_half, D, rows);
+  LFM_CHECK_LAUNCH();
+  rc = launch_gemm_tn(ASrcRowMajor{ws.c_half, D, rows}, (const half_t*)w->ada_w, D, rows, (int)J, D, EpiBiasF32{ws.mod, J, w->ada_b}, st);
+  if (rc) return rc;
+
+  hipLaunchKernelGGL(patch_embed_kernel, dim3(cdiv((long)M * (D / 4), 256)), dim3(256), 0, st, c->x, w->patch_w, w->patch_b, w->pos_embed, ws.X,
+                     B, cfg ? B / 2 : B, s->in_ch, s->res, s->patch, D);
+  LFM_CHECK_LAUNCH();
+
+  half_t* Qb = ws.QKVH;
+  half_t* Kb = Qb + (size_t)M * D;
+  half_t* Vb = Kb + (size_t)M * D;
+  for (int i = 0; i < s->depth; ++i) {
+    const float* mod = ws.mod + (long)i * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+    rc = ln_modulate_launch(ws.X, ws.A, M, D, T, mod, mod + D, mstride, st);
+    if (rc) return rc;
+    rc = launch_gemm_tn(ASrcRowMajor{ws.A, D, M}, (const half_t*)w->qkv_w + (size_t)i * 3 * D * D, D, M, 3 * D, D,
+                        EpiQKV{Qb, Kb, Vb, w->qkv_b + (size_t)i * 3 * D, D, 64, T}, st);
+    if (rc) return rc;
+    rc = attention_launch(Qb, Kb, Vb, ws.A, B, s->heads, T, st);
+    if (rc) return rc;
+    rc = launch_gemm_tn(ASrcRowMajor{ws.A, D, M}, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D,
+                        EpiGateResidF32{ws.X, D, w->proj_b + (size_t)i * D, mod + 2 * D, mstride, T}, st);
+    if (rc) return rc;
+    rc = ln_modulate_launch(ws.X, ws.A, M, D, T, mod + 3 * D, mod + 4 * D, mstride, st);
+    if (rc) return rc;
+    rc = launch_gemm_tn(ASrcRowMajor{ws.A, D, M}, (const half_t*)w->fc1_w + (size_t)i * H * D, D, M, H, D,
+                        EpiBiasGeluF16{ws.QKVH, H, w->fc1_b + (size_t)i * H}, st);
+    if (rc) return rc;
+    rc = launch_gemm_tn(ASrcRowMajor{ws.QKVH, H, M}, (const half_t*)w->fc2_w + (size_t)i * D * H, H, M, D, H,
+                        EpiGateResidF32{ws.X, D, w->fc2_b + (size_t)i * D, mod + 5 * D, mstride, T}, st);
+    if (rc) return rc;
+  }
+  const float* fmod = ws.mod + (long)s->depth * 6 * D;
+  const int Mh = cfg ? M / 2 : M;
+  if (cfg)
+    hipLaunchKernelGGL(final_layer_kernel<true>, dim3(cdiv(Mh, 4)), dim3(256), 0, st, ws.X, M, D, T, fmod, fmod + D, mstride, w->final_w,
+                       w->final_b, s->in_ch, s->res, s->patch, c->cfg_scale, c->out, c->axpy_base, c->axpy_dt);
+  else
+    hipLaunchKernelGGL(final_layer_kernel<false>, dim3(cdiv(Mh, 4)), dim3(256), 0, st, ws.X, M, D, T, fmod, fmod + D, mstride, w->final_w,
+                       w->final_b, s->in_ch, s->res, s->patch, 1.0f, c->out, c->axpy_base, c->axpy_dt);
+  LFM_CHECK_LAUNCH();
+  return LFM_OK;
+}
+
+extern "C" int lfm_grid_advance(const float* ts, const float* dts, int* step, float* t_cur, float* dt_cur, lfm_stream_t stream) {
+  if (!ts || !dts || !step || !t_cur || !dt_cur) return LFM_ERR_ARG;
+  hipLaunchKernelGGL(grid_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, ts, dts, step, t_cur, dt_cur);
+  LFM_CHECK_LAUNCH();
+  return LFM_OK;
+}
+
+extern "C" int lfm_lincomb(float* out, const float* base, const float* const* k_host_ptrs, const float* coef, int nk, long n,
+                           lfm_stream_t stream) {
+  if (!out || !coef || nk < 0 || nk > 8 || (nk && !k_host_ptrs)) return LFM_ERR_ARG;
+  if (n % 4 || ((uintptr_t)out & 15)) return LFM_ERR_ALIGN;
+  LinPtrs p;
+  for (int i = 0; i < 8; ++i) p.k[i] = i < nk ? k_host_ptrs[i] : nullptr;
+  hipLaunchKernelGGL(lincomb_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, out, base, p, coef, nk, n / 4);
+  LFM_CHECK_LAUNCH();
+  return LFM_OK;
+}

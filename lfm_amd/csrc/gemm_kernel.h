@@ -1,0 +1,301 @@
+// fp16 x fp16 -> fp32 MFMA GEMM for gfx950:  C[m][n] = sum_k A[m][k] * W[n][k]  (+ fused epilogue).
+//
+// Both operands are K-contiguous ("TN"): activations A[M,K] row-major and weights W[N,K] exactly as
+// torch.nn.Linear stores them, so an MFMA fragment is one 16-byte load per lane.
+//
+// Structure (v1, "2-barrier"): 128x128x64 tile, 256 threads = 4 waves in 2(M) x 2(N), each wave a
+// 64x64 sub-tile = 2x2 v_mfma_f32_32x32x16_f16 fragments.  Operands are staged by 16-byte LDS-DMA
+// (global_load_lds_dwordx4) into a double-buffered, XOR-swizzled LDS image:
+//   LDS row = 64 halves = 128 B = 8 chunks of 16 B;  chunk c of row r lives at chunk c ^ ((r>>1)&7).
+// ds_read_b128 is serviced in 16-lane groups over a 256-B bank row (= two tile rows), so the key is
+// (r>>1)&7: the 16 rows a group touches land on 16 distinct 16-B slots (conflict-free).  The DMA
+// destination is lane-linear, so the swizzle is applied to the per-lane SOURCE address and to the
+// read address (both-sides rule).  The next tile's DMA stays in flight across the barrier
+// (counted s_waitcnt vmcnt + raw s_barrier).
+//
+// The MFMA is issued with W as the A-operand and the activations as the B-operand, i.e. it computes
+// the C^T fragment: lane l then owns column m = l&31 and FOUR CONSECUTIVE n per register group, so
+// the epilogue sees (m, n..n+3, float4) and can do 8/16-byte stores and per-n vector loads.
+#pragma once
+#include "common.h"
+
+#define GEMM_BM 128
+#define GEMM_BN 128
+#define GEMM_BK 64
+#define GEMM_STAGE_BYTES (2 * GEMM_BM * GEMM_BK * 2)  // A + W tile, 32 KiB
+#define GEMM_LDS_BYTES (2 * GEMM_STAGE_BYTES)         // double buffered, 64 KiB
+
+// ------------------------------------------------------------------ A-operand sources
+// Plain row-major activations; rows >= M are clamped (their results are never stored).
+struct ASrcRowMajor {
+  const half_t* A;
+  long lda;
+  int M;
+  __device__ __forceinline__ void init(int bz, long bs) { A += (long)bz * bs; }
+  struct Row {
+    const half_t* p;
+  };
+  __device__ __forceinline__ Row row(int m) const {
+    Row r;
+    r.p = A + (long)(m < M ? m : M - 1) * lda;
+    return r;
+  }
+  __device__ __forceinline__ const half_t* ptr(const Row& r, int k) const { return r.p + k; }
+};
+
+// ------------------------------------------------------------------ epilogues
+// Two-phase so the interior-tile path can issue ALL its loads before the first store (the compiler
+// will not move a load above a possibly-aliasing store):  aux = epi.load(m, n);  epi.store(m, n, v, aux)
+// with v = C[m][n..n+3] (fp32 accumulators).  m < M and n+3 < N are guaranteed by the caller.
+struct EpiBiasF16 {  // C = acc + bias  -> fp16
+  half_t* C;
+  long ldc;
+  const float* bias;  // may be null
+  typedef f32x4 Aux;
+  __device__ __forceinline__ Aux load(int, int n) const { return bias ? *(const f32x4*)(bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  __device__ __forceinline__ void store(int m, int n, f32x4 v, const Aux& b) const {
+    v += b;
+    half4_t h = {(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
+    *(half4_t*)(C + (long)m * ldc + n) = h;
+  }
+};
+
+struct EpiBiasGeluF16 {  // C = gelu_tanh(acc + bias) -> fp16   (timm Mlp fc1, DiT.py:123-124)
+  half_t* C;
+  long ldc;
+  const float* bias;
+  typedef f32x4 Aux;
+  __device__ __forceinline__ Aux load(int, int n) const { return *(const f32x4*)(bias + n); }
+  __device__ __forceinline__ void store(int m, int n, f32x4 v, const Aux& b) const {
+    v += b;
+    half4_t h = {(half_t)gelu_tanh_f(v.x), (half_t)gelu_tanh_f(v.y), (half_t)gelu_tanh_f(v.z), (half_t)gelu_tanh_f(v.w)};
+    *(half4_t*)(C + (long)m * ldc + n) = h;
+  }
+};
+
+struct EpiBiasF32 {  // C = acc + bias -> fp32   (adaLN modulation table)
+  float* C;
+  long ldc;
+  const float* bias;
+  typedef f32x4 Aux;
+  __device__ __forceinline__ Aux load(int, int n) const { return bias ? *(const f32x4*)(bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  __device__ __forceinline__ void store(int m, int n, f32x4 v, const Aux& b) const { *(f32x4*)(C + (long)m * ldc + n) = v + b; }
+};
+
+// X[m][n] += gate[img(m)][n] * (acc + bias[n]);  fp32 residual stream (DiT.py:129-130)
+struct EpiGateResidF32 {
+  float* X;
+  long ldx;
+  const float* bias;
+  const float* gate;  // gate + img*gate_stride + n
+  long gate_stride;   // floats between images' modulation rows (0 => one shared row)
+  int tokens;         // rows per image
+  struct Aux {
+    f32x4 b, g, x;
+  };
+  __device__ __forceinline__ Aux load(int m, int n) const {
+    Aux a;
+    a.b = *(const f32x4*)(bias + n);
+    a.g = *(const f32x4*)(gate + (long)(m / tokens) * gate_stride + n);
+    a.x = *(const f32x4*)(X + (long)m * ldx + n);
+    return a;
+  }
+  __device__ __forceinline__ void store(int m, int n, f32x4 v, const Aux& a) const {
+    *(f32x4*)(X + (long)m * ldx + n) = a.x + a.g * (v + a.b);
+  }
+};
+
+// QKV projection of timm Attention (DiT.py:120): columns [q | k | v], each [head][hd].
+// Q,K are stored token-major [M, D]; V is stored TRANSPOSED per (image, head): Vt[img][head][d][token],
+// which is the key-contiguous layout the attention kernel's P*V MFMA operand wants.
+struct EpiQKV {
+  half_t* Q;
+  half_t* K;
+  half_t* Vt;
+  const float* bias;
+  int D, hd, tokens;
+  typedef f32x4 Aux;
+  __device__ __forceinline__ Aux load(int, int n) const { return *(const f32x4*)(bias + n); }
+  __device__ __forceinline__ void store(int m, int n, f32x4 v, const Aux& b) const {
+    v += b;
+    if (n < 2 * D) {
+      half_t* dst = (n < D) ? (Q + (long)m * D + n) : (K + (long)m * D + (n - D));
+      half4_t h = {(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
+      *(half4_t*)dst = h;
+    } else {
+      const int c = n - 2 * D, head = c / hd, d = c - head * hd;
+      const int img = m / tokens, tok = m - img * tokens;
+      half_t* dst = Vt + (((long)img * (D / hd) + head) * hd + d) * tokens + tok;
+      dst[0] = (half_t)v.x;
+      dst[tokens] = (half_t)v.y;
+      dst[2 * tokens] = (half_t)v.z;
+      dst[3 * tokens] = (half_t)v.w;
+    }
+  }
+};
+
+// ------------------------------------------------------------------ kernel
+// default: epilogues ignore the batch index; batched epilogues provide a member batch(bz, stride).
+template <class Epi>
+__device__ __forceinline__ auto epi_batch(Epi& e, int bz, long bs, int) -> decltype(e.batch(bz, bs), void()) {
+  e.batch(bz, bs);
+}
+template <class Epi>
+__device__ __forceinline__ void epi_batch(Epi&, int, long, long) {}
+
+template <class ASrc, class Epi>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(ASrc asrc, const half_t* __restrict__ W, long ldw, int M, int N, int K,
+                                                          int tiles_n, Epi epi, long bsA, long bsW, long bsC) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  // XCD-aware tile order: block b runs on XCD b%8; give every XCD a contiguous range of M-panels so an
+  // activation panel is fetched into ONE L2 and reused by all N-tiles there.
+  int bid = blockIdx.x;
+  const int nb = gridDim.x;
+  if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
+  const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+  const int m0 = tile_m * GEMM_BM, n0 = tile_n * GEMM_BN;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // batched GEMM (blockIdx.y): operand/result bases advance by the batch strides
+  const int bz = blockIdx.y;
+  asrc.init(bz, bsA);
+  W += (long)bz * bsW;
+
+  // ---- per-thread DMA source rows: 4 passes over the 128-row tile, 32 rows per pass
+  typename ASrc::Row arow[4];
+  const half_t* wrow[4];
+  int cswz[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int r = p * 32 + (tid >> 3);
+    arow[p] = asrc.row(m0 + r);
+    const int n = n0 + r;
+    wrow[p] = W + (long)(n < N ? n : N - 1) * ldw;
+    cswz[p] = ((tid & 7) ^ ((r >> 1) & 7)) * 8;  // source k-offset (halves) of the chunk this lane fetches
+  }
+  const int nk = K / GEMM_BK;
+
+  auto issue = [&](int kt, int stage) {
+    char* sA = smem + stage * GEMM_STAGE_BYTES;
+    char* sW = sA + GEMM_BM * GEMM_BK * 2;
+    const int k0 = kt * GEMM_BK;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      glds16(asrc.ptr(arow[p], k0 + cswz[p]), sA + (p * 256 + wave * 64) * 16);
+      glds16(wrow[p] + k0 + cswz[p], sW + (p * 256 + wave * 64) * 16);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // fragment read offsets (bytes within a tile image), constant over K
+  int a_off[2], w_off[2], a_key[2], w_key[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int ra = wm * 64 + j * 32 + (lane & 31);
+    a_off[j] = ra * 128;
+    a_key[j] = (ra >> 1) & 7;
+    const int rw = wn * 64 + j * 32 + (lane & 31);
+    w_off[j] = rw * 128;
+    w_key[j] = (rw >> 1) & 7;
+  }
+  const int chalf = lane >> 5;
+
+  issue(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int stage = kt & 1;
+    if (kt + 1 < nk) {
+      issue(kt + 1, stage ^ 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // this wave's 8 DMAs of tile kt have landed
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();  // ... and everyone else's
+    asm volatile("" ::: "memory");
+    const char* sA = smem + stage * GEMM_STAGE_BYTES;
+    const char* sW = sA + GEMM_BM * GEMM_BK * 2;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int c = ks * 2 + chalf;
+      half8_t af[2], wf[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        af[j] = *(const half8_t*)(sA + a_off[j] + ((c ^ a_key[j]) << 4));
+        wf[j] = *(const half8_t*)(sW + w_off[j] + ((c ^ w_key[j]) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], af[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // all reads of this stage done before it is refilled
+    asm volatile("" ::: "memory");
+  }
+
+  // ---- epilogue: acc[i][j][4g+r] = C[m][n+r], m = ..+(lane&31), n = ..+8g+4*(lane>>5)
+  epi_batch(epi, bz, bsC, 0);
+  if (m0 + GEMM_BM <= M && n0 + GEMM_BN <= N) {  // interior tile: all loads first, then all stores
+    typename Epi::Aux aux[2][2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          aux[j][i][g] = epi.load(m0 + wm * 64 + j * 32 + (lane & 31), n0 + wn * 64 + i * 32 + 8 * g + 4 * chalf);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = m0 + wm * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = n0 + wn * 64 + i * 32 + 8 * g + 4 * chalf;
+          f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+          epi.store(m, n, v, aux[j][i][g]);
+        }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = m0 + wm * 64 + j * 32 + (lane & 31);
+      if (m >= M) continue;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = n0 + wn * 64 + i * 32 + 8 * g + 4 * chalf;
+          if (n + 3 < N) {
+            f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+            epi.store(m, n, v, epi.load(m, n));
+          }
+        }
+    }
+  }
+}
+
+template <class ASrc, class Epi>
+static inline int launch_gemm_tn(const ASrc& asrc, const half_t* W, long ldw, int M, int N, int K, const Epi& epi,
+                                 hipStream_t stream, int batch = 1, long bsA = 0, long bsW = 0, long bsC = 0) {
+  if (M <= 0 || N <= 0 || K <= 0 || (K % GEMM_BK) != 0 || (N % 4) != 0) return LFM_ERR_SHAPE;
+  if ((ldw % 8) != 0 || ((uintptr_t)W & 15)) return LFM_ERR_ALIGN;
+  const int tm = cdiv(M, GEMM_BM), tn = cdiv(N, GEMM_BN);
+  static bool attr_set = false;  // one attribute call per instantiation
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<ASrc, Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_tn_kernel<ASrc, Epi>), dim3(tm * tn, batch), dim3(256), GEMM_LDS_BYTES, stream, asrc, W, ldw, M, N, K, tn,
+                     epi, bsA, bsW, bsC);
+  LFM_CHECK_LAUNCH();
+  return LFM_OK;
+}

@@ -1,0 +1,114 @@
+"""ctypes binding of liblfm_hip.so (C ABI: include/lfm_hip.h).  Fails loudly -- no fallback."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "liblfm_hip.so")
+_lib = None
+
+
+class LfmHipError(RuntimeError):
+    pass
+
+
+class DitShape(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("depth", "hidden", "heads", "patch", "in_ch", "res", "mlp_hidden", "label_rows")]
+
+
+_DIT_WEIGHT_FIELDS = ("pos_embed", "patch_w", "patch_b", "t_w0", "t_b0", "t_w2", "t_b2", "y_table", "ada_w", "ada_b",
+                      "qkv_w", "qkv_b", "proj_w", "proj_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "final_w", "final_b")
+
+
+class DitWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _DIT_WEIGHT_FIELDS]
+
+
+class DitCall(C.Structure):
+    _fields_ = [("batch", C.c_int), ("x", C.c_void_p), ("t", C.c_void_p), ("t_len", C.c_int), ("y", C.c_void_p),
+                ("cfg", C.c_int), ("cfg_scale", C.c_float), ("out", C.c_void_p), ("axpy_base", C.c_void_p), ("axpy_dt", C.c_void_p)]
+
+
+def lib():
+    """Load the shared library (building it in-tree if hipcc is present and it is stale/missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        try:
+            from . import _build
+
+            _build.build()
+        except Exception as e:  # noqa
+            raise LfmHipError(f"liblfm_hip.so is missing and could not be built: {e}") from e
+    try:
+        L = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise LfmHipError(f"cannot load {LIB_PATH}: {e}") from e
+    L.lfm_strerror.restype = C.c_char_p
+    L.lfm_strerror.argtypes = [C.c_int]
+    L.lfm_abi_version.restype = C.c_int
+    L.lfm_dit_workspace_bytes.restype = C.c_size_t
+    L.lfm_dit_workspace_bytes.argtypes = [C.POINTER(DitShape), C.c_int]
+    L.lfm_dit_forward.restype = C.c_int
+    L.lfm_dit_forward.argtypes = [C.POINTER(DitShape), C.POINTER(DitWeights), C.c_void_p, C.c_size_t, C.POINTER(DitCall), C.c_void_p]
+    L.lfm_gemm_f16.restype = C.c_int
+    L.lfm_gemm_f16.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int,
+                               C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.c_int, C.c_void_p]
+    L.lfm_ln_modulate.restype = C.c_int
+    L.lfm_ln_modulate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
+    L.lfm_dit_attention.restype = C.c_int
+    L.lfm_dit_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.lfm_grid_advance.restype = C.c_int
+    L.lfm_grid_advance.argtypes = [C.c_void_p] * 5 + [C.c_void_p]
+    L.lfm_lincomb.restype = C.c_int
+    L.lfm_lincomb.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_long, C.c_void_p]
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        raise LfmHipError(f"{what} failed: {lib().lfm_strerror(rc).decode()} (code {rc})")
+
+
+def stream_ptr(device=None):
+    """Raw hipStream_t of torch's current stream (so launches are ordered with torch ops and graph-capturable)."""
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def require_gpu(t, what):
+    if not t.is_cuda:
+        raise LfmHipError(f"{what}: tensor is on {t.device}; the LFM hot path only runs on an MI355X (no CPU fallback)")
+
+
+# ----------------------------------------------------------------------------- thin op wrappers (used by tests)
+def gemm_f16(A, W, bias=None, epilogue=0, out=None, gate=None, gate_stride=0, tokens=1):
+    require_gpu(A, "gemm_f16")
+    M, K = A.shape
+    N = W.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=torch.float32 if epilogue in (2, 3) else torch.float16)
+    check(lib().lfm_gemm_f16(ptr(A), A.stride(0), ptr(W), W.stride(0), ptr(out), out.stride(0), M, N, K, ptr(bias), epilogue,
+                             ptr(gate), gate_stride, tokens, stream_ptr()), "lfm_gemm_f16")
+    return out
+
+
+def ln_modulate(X, shift, scale, tokens, mod_stride):
+    require_gpu(X, "ln_modulate")
+    M, D = X.shape
+    A = torch.empty(M, D, device=X.device, dtype=torch.float16)
+    check(lib().lfm_ln_modulate(ptr(X), ptr(A), M, D, tokens, ptr(shift), ptr(scale), mod_stride, stream_ptr()), "lfm_ln_modulate")
+    return A
+
+
+def dit_attention(Q, K, Vt, batch, heads, T):
+    require_gpu(Q, "dit_attention")
+    O = torch.empty_like(Q)
+    check(lib().lfm_dit_attention(ptr(Q), ptr(K), ptr(Vt), ptr(O), batch, heads, T, stream_ptr()), "lfm_dit_attention")
+    return O

@@ -1,0 +1,189 @@
+"""GPU parity: HIP DiT path (through the C ABI) vs the CPU oracle / reference golden vectors.
+
+Tolerances (SURVEY.md §8c rule 4; fp16 operands, fp32 accumulate, fp32 residual stream):
+  per-forward velocity rel-L2 <= 2e-3 against the fp32 oracle.
+"""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import dit_ref  # checker only
+
+
+def rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _load(golden_dir, name):
+    return torch.load(os.path.join(golden_dir, name), map_location="cpu", weights_only=False)
+
+
+# ----------------------------------------------------------------------------- building blocks
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 384, 1024), (200, 132, 64), (1, 1536, 768), (4096, 1024, 4096)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+def test_gemm_epilogues(dev, M, N, K, epi):
+    from lfm_amd import hip
+
+    g = torch.Generator().manual_seed(M * 7 + N + K + epi)
+    A = (torch.randn(M, K, generator=g) * 0.5).half()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).half()
+    bias = torch.randn(N, generator=g) * 0.1
+    ref = A.float() @ W.float().t() + bias
+    tokens = 8 if M % 8 == 0 else 1
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref, approximate="tanh")
+    out = None
+    gate = None
+    if epi == 3:
+        X = torch.randn(M, N, generator=g)
+        gate = torch.randn(M // tokens, N, generator=g)
+        ref = X + gate.repeat_interleave(tokens, 0) * ref
+        out = X.clone().to(dev)
+        gate = gate.to(dev)
+    got = hip.gemm_f16(A.to(dev), W.to(dev), bias.to(dev), epilogue=epi, out=out, gate=gate, gate_stride=N, tokens=tokens)
+    torch.cuda.synchronize()
+    assert rel_l2(got, ref) < (2e-3 if epi in (0, 1) else 2e-4)
+
+
+def test_gemm_detects_transpose(dev):
+    """A = I with an asymmetric W: a swapped C write cannot pass (cdna guide: always A=I-check)."""
+    from lfm_amd import hip
+
+    A = torch.eye(128, 128).half()
+    W = (torch.arange(256 * 128).reshape(256, 128) % 97).half()
+    got = hip.gemm_f16(A.to(dev), W.to(dev), None, epilogue=2)
+    assert torch.equal(got.cpu(), W.float().t())
+
+
+def test_gemm_rejects_bad_shapes(dev):
+    from lfm_amd import hip
+
+    A = torch.zeros(64, 72, device=dev, dtype=torch.float16)  # K not a multiple of 64
+    W = torch.zeros(64, 72, device=dev, dtype=torch.float16)
+    with pytest.raises(hip.LfmHipError):
+        hip.gemm_f16(A, W)
+
+
+@pytest.mark.parametrize("D,tokens,shared", [(1024, 256, False), (768, 256, True), (384, 64, False), (128, 256, False)])
+def test_ln_modulate(dev, D, tokens, shared):
+    from lfm_amd import hip
+
+    g = torch.Generator().manual_seed(D)
+    n_img = 3
+    X = torch.randn(n_img * tokens, D, generator=g) * 2 + 0.3
+    rows = 1 if shared else n_img
+    shift, scale = torch.randn(rows, D, generator=g) * 0.2, torch.randn(rows, D, generator=g) * 0.2
+    ln = torch.nn.functional.layer_norm(X, (D,), eps=1e-6).reshape(n_img, tokens, D)
+    ref = (ln * (1 + scale[:, None]) + shift[:, None]).reshape(-1, D)
+    mod = torch.stack([shift, scale], 1).contiguous().to(dev)  # [rows, 2, D]
+    got = hip.ln_modulate(X.to(dev), mod[:, 0], mod[:, 1], tokens, 0 if shared else 2 * D)
+    assert rel_l2(got, ref) < 1e-3
+
+
+@pytest.mark.parametrize("T,heads,batch", [(256, 16, 3), (256, 2, 1), (64, 6, 2), (128, 4, 2)])
+def test_attention(dev, T, heads, batch):
+    from lfm_amd import hip
+
+    g = torch.Generator().manual_seed(T + heads)
+    D = heads * 64
+    q = (torch.randn(batch, heads, T, 64, generator=g) * 1.5).half()
+    k = (torch.randn(batch, heads, T, 64, generator=g) * 1.5).half()
+    v = torch.randn(batch, heads, T, 64, generator=g).half()
+    k[0, 0, 5] *= 6  # a spiky key row exercises the running-max rescale of the online softmax
+    ref = torch.softmax((q.float() @ k.float().transpose(-1, -2)) * 0.125, -1) @ v.float()
+    ref = ref.transpose(1, 2).reshape(batch * T, D)
+    Q = q.transpose(1, 2).reshape(batch * T, D).contiguous().to(dev)
+    K = k.transpose(1, 2).reshape(batch * T, D).contiguous().to(dev)
+    Vt = v.transpose(-1, -2).contiguous().to(dev)  # [b, h, 64, T]
+    got = hip.dit_attention(Q, K, Vt, batch, heads, T)
+    assert rel_l2(got, ref) < 2e-3
+
+
+# ----------------------------------------------------------------------------- whole model
+def _model_from_state(cfgkw, sd, dev):
+    from lfm_amd.models import DiT
+
+    m = DiT(img_resolution=cfgkw["img_resolution"], patch_size=cfgkw["patch"], in_channels=cfgkw["in_channels"],
+            hidden_size=cfgkw["hidden"], depth=cfgkw["depth"], num_heads=cfgkw["heads"],
+            label_dropout=cfgkw["label_dropout"], num_classes=cfgkw["num_classes"])
+    m.load_state_dict(sd, strict=True)
+    return m.to(dev).eval()
+
+
+@pytest.mark.parametrize("which", ["cond", "uncond"])
+def test_dit_matches_reference_golden(dev, golden_dir, which):
+    """Same weights, same latents as the unmodified reference (tests/golden/dit_tiny.pt)."""
+    rec = _load(golden_dir, "dit_tiny.pt")[which]
+    m = _model_from_state(rec["cfg"], rec["state_dict"], dev)
+    x = rec["x"].to(dev)
+    y = rec["y"].to(dev) if "y" in rec else None
+    assert rel_l2(m(torch.tensor(0.37, device=dev), x, y), rec["v_t0d"]) < 2e-3
+    assert rel_l2(m(torch.tensor([0.9, 0.5, 0.02], device=dev), x, y), rec["v_tN"]) < 2e-3
+    if which == "cond":
+        assert rel_l2(m(torch.tensor(0.37), x), rec["v_ynone"]) < 2e-3
+        got = m.forward_with_cfg(torch.tensor(0.37, device=dev), rec["x_cfg"].to(dev), rec["y_cfg"].to(dev), cfg_scale=rec["cfg_scale"])
+        assert rel_l2(got, rec["v_cfg"]) < 2e-3
+
+
+@pytest.mark.parametrize("name,batch,kw", [
+    ("DiT-B/2", 4, dict(num_classes=1, label_dropout=0.0)),      # BASELINE config 1 shape
+    ("DiT-B/2", 6, dict(num_classes=1000, label_dropout=0.1)),   # config 4 shape (class-conditional)
+    ("DiT-L/2", 3, dict(num_classes=1, label_dropout=0.0)),      # config 2 shape
+])
+def test_dit_matches_oracle_fullsize(dev, name, batch, kw):
+    from lfm_amd.models import DiT_models
+
+    cfg = dit_ref.DiTCfg.named(name, **kw)
+    sd = dit_ref.make_dit_state(cfg, seed=1)
+    m = DiT_models[name](img_resolution=32, in_channels=4, **kw)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).eval()
+    g = torch.Generator().manual_seed(42)
+    x = torch.randn(batch, 4, 32, 32, generator=g)
+    y = torch.randint(0, kw["num_classes"], (batch,), generator=g) if kw["num_classes"] > 1 else None
+    for t in (torch.tensor(1.0), torch.tensor(0.5), torch.linspace(0.1, 0.9, batch)):
+        ref = dit_ref.dit_forward(sd, cfg, t, x, y)
+        got = m(t.to(dev), x.to(dev), y.to(dev) if y is not None else None)
+        assert float(ref.abs().mean()) > 1e-3
+        assert rel_l2(got, ref) < 2e-3, (name, t)
+
+
+def test_dit_fused_euler_update(dev):
+    """out = base + dt*v fused into the final-layer kernel equals the unfused v."""
+    import ctypes as C
+
+    from lfm_amd import hip
+    from lfm_amd.models import DiT_models
+
+    cfg = dit_ref.DiTCfg.named("DiT-S/2", num_classes=1, label_dropout=0.0)
+    sd = dit_ref.make_dit_state(cfg, seed=5)
+    m = DiT_models["DiT-S/2"](img_resolution=32, in_channels=4, num_classes=1, label_dropout=0.0)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    x = torch.randn(2, 4, 32, 32, generator=torch.Generator().manual_seed(0)).to(dev)
+    t = torch.tensor(0.7, device=dev)
+    v = m(t, x)
+    dt = torch.tensor([-0.02], device=dev)
+    xn = x.clone()
+    m._run(t, xn, None, False, 1.0, out=xn, axpy_base=xn, axpy_dt=dt)  # in place
+    torch.testing.assert_close(xn, x + dt * v, rtol=1e-6, atol=1e-6)
+    _ = (C, hip)
+
+
+def test_forward_refuses_cpu():
+    from lfm_amd import hip
+    from lfm_amd.models import DiT_models
+
+    m = DiT_models["DiT-S/2"](img_resolution=32, in_channels=4, num_classes=1, label_dropout=0.0).eval()
+    with pytest.raises(hip.LfmHipError):
+        m(torch.tensor(0.5), torch.zeros(1, 4, 32, 32))
