@@ -1,0 +1,180 @@
+"""Headline benchmark: images/sec of the LFM sampling hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): DiT-L/2 on 4x32x32 f8 latents (256x256 images), batch 64 per GPU, 50 Euler NFE on
+the torchdiffeq grid (step_size 0.02, the path the reference actually runs) + f8 VAE decode + uint8 NHWC conversion.
+Synthetic data: seeded random-init weights of the real architectures (de-zeroed), seeded Gaussian latents resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one full batch through the hot path.  Ranks shard batches (weak scaling, no data-path collective during the
+solve); with N > 1 every batch ends with one RCCL all_gather_into_tensor of the uint8 images.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense fp16/bf16 (MI355X_MICROARCH.md)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=3)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--batch", type=int, default=64, help="images per GPU per step")
+    p.add_argument("--model", type=str, default="DiT-L/2")
+    p.add_argument("--nfe", type=int, default=50)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-roofline", action="store_true")
+    return p.parse_args()
+
+
+def cpu_baseline(model_name, nfe):
+    """The oracle (CPU restatement of the reference path, fp32 torch) timed on the host cores: a bounded sample --
+    2 velocity evaluations of DiT at N=2 plus one VAE decode of one 256x256 image -- scaled to `nfe` evaluations + decode."""
+    from oracle import dit_ref, vae_ref
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = dit_ref.DiTCfg.named(model_name, num_classes=1, label_dropout=0.0)
+    sd = dit_ref.make_dit_state(cfg, seed=0)
+    x = torch.randn(2, 4, 32, 32, generator=torch.Generator().manual_seed(42))
+    dit_ref.dit_forward(sd, cfg, torch.tensor(0.9), x)  # warm-up
+    t0 = time.perf_counter()
+    reps = 2
+    for i in range(reps):
+        dit_ref.dit_forward(sd, cfg, torch.tensor(0.5 + 0.1 * i), x)
+    t_eval = (time.perf_counter() - t0) / reps / x.shape[0]
+    vsd = vae_ref.make_vae_state(seed=0)
+    z = torch.randn(1, 4, 32, 32, generator=torch.Generator().manual_seed(1))
+    t0 = time.perf_counter()
+    vae_ref.vae_decode(vsd, z)
+    t_dec = time.perf_counter() - t0
+    ips = 1.0 / (nfe * t_eval + t_dec)
+    return {"value": ips, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32 torch-CPU: {reps} {model_name} velocity evals at N=2 ({t_eval:.3f} s/img/eval) + 1 VAE decode of one "
+                      f"256x256 image ({t_dec:.2f} s), scaled to {nfe} NFE + decode per image"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+    torch.set_grad_enabled(False)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from lfm_amd import hip
+    from lfm_amd.autoencoder import AutoencoderKL, images_to_uint8
+    from lfm_amd.models import DiT_models
+    from lfm_amd.solvers import GraphedFixedGrid, torchdiffeq_euler_grid
+    from lfm_amd.test_flow_latent import dezero_
+
+    # ---- models (celeb256_dit.txt: --num_classes 1 --label_dropout 0.)
+    torch.manual_seed(0)
+    model = dezero_(DiT_models[a.model](img_resolution=32, in_channels=4, label_dropout=0.0, num_classes=1)).to(dev).eval()
+    vae = AutoencoderKL.from_random(seed=0).to(dev)
+    B = a.batch
+    h = 1.0 / a.nfe
+    ts, dts = torchdiffeq_euler_grid(h)
+    assert dts.numel() == a.nfe
+    solver = GraphedFixedGrid(model, B)
+    solver.set_grid(ts, dts)
+    x0 = torch.randn(B, 4, 32, 32, generator=torch.Generator().manual_seed(42 + rank)).to(dev)  # resident in HBM
+    gathered = torch.empty(world * B, 256, 256, 3, dtype=torch.uint8, device=dev) if world > 1 else None
+    scale = 1.0 / 0.18215
+
+    def step():
+        lat = solver.run(x0)
+        img = vae.decode(lat / 0.18215).sample
+        u8 = images_to_uint8(img)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, u8)
+        return u8
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(a.warmup, 0)):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    fence()
+    el = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt)
+    assert out.shape == (B, 256, 256, 3) and int(out.to(torch.int32).std() > 0)
+    ips = world * B * a.steps / el
+
+    from oracle import dit_ref, vae_ref  # FLOP closed forms only
+
+    f_img = a.nfe * dit_ref.dit_flops_per_image(dit_ref.DiTCfg.named(a.model, num_classes=1, label_dropout=0.0)) + vae_ref.vae_decode_flops(32)
+
+    res = {
+        "metric": "images/sec", "value": ips, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": 1e3 * el / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+        "data": "synthetic",
+        "config": {"workload": f"{a.model} celeb256 f8 (4x32x32 latents), batch {B}/GPU, {a.nfe}-step Euler (torchdiffeq grid) + f8 VAE decode "
+                               f"to 256x256 + uint8 NHWC" + (" + RCCL all-gather of images" if world > 1 else ""),
+                   "per_gpu_batch": B, "global_batch": B * world, "nfe": a.nfe, "sharding": f"dp{world}"},
+        "algorithmic_gflop_per_image": f_img / 1e9,
+        "mfma_frac_whole_path": ips * f_img / (MFMA_PEAK_TFLOPS * 1e12 * world),
+    }
+
+    if rank == 0 and not a.no_roofline:
+        # dominant kernel: the fc1 MFMA GEMM + GELU epilogue (gemm_tn_kernel<ASrcRowMajor, EpiBiasGeluF16>), timed live with
+        # HIP events on the stream it is launched on, at exactly the shape/operands the model uses.
+        D, H, M = model.hidden_size, model.mlp_hidden, B * 256
+        A = (torch.randn(M, D, device=dev) * 0.5).half()
+        W = (torch.randn(H, D, device=dev) * 0.03).half()
+        bias = torch.randn(H, device=dev) * 0.02
+        C = torch.empty(M, H, device=dev, dtype=torch.float16)
+        for _ in range(3):
+            hip.gemm_f16(A, W, bias, epilogue=1, out=C)
+        n = 20
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            hip.gemm_f16(A, W, bias, epilogue=1, out=C)
+        e1.record()
+        torch.cuda.synchronize()
+        dur = e0.elapsed_time(e1) / n * 1e-3
+        ach = 2.0 * M * H * D / dur / 1e12
+        res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
+                           "traffic": None, "kernel": "gemm_tn_kernel<ASrcRowMajor,EpiBiasGeluF16> (DiT fc1 + GELU)",
+                           "shape": {"M": M, "N": H, "K": D}, "avg_launch_us": dur * 1e6}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(a.model, a.nfe)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

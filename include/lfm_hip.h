@@ -113,14 +113,53 @@ int lfm_ln_modulate(const float* X, void* A, int M, int D, int tokens, const flo
  * Q,K: fp16 [batch*T, D] token-major; Vt: fp16 [batch, heads, hd, T]; O: fp16 [batch*T, D]. */
 int lfm_dit_attention(const void* Q, const void* K, const void* Vt, void* O, int batch, int heads, int T, lfm_stream_t stream);
 
-/* ------------------------------------------------------------------ solver helpers (device-resident time grid)
- * Advance the captured step: t_cur[0] = ts[*step]; dt_cur[0] = dts[*step]; ++*step.  Lets ONE captured
- * graph be replayed for every step of the fixed grids of test_flow_latent.py:42-76 (torchdiffeq euler)
- * and sampler/karras_sample.py:85-161. */
-int lfm_grid_advance(const float* ts, const float* dts, int* step, float* t_cur, float* dt_cur, lfm_stream_t stream);
+/* ------------------------------------------------------------------ first-stage VAE decoder
+ * Decode half of diffusers AutoencoderKL, config stabilityai/sd-vae-ft-mse (latent 4, block_out_channels
+ * [128,256,512,512], 2 layers/block, 32 GN groups, eps 1e-6), as the reference calls it:
+ *   test_flow_latent.py:131,193   first_stage_model.decode(fake_sample / args.scale_factor).sample
+ * conv3x3 weights are fp16 [Cout][tap = ky*3+kx][Cin]; 1x1 / linear weights fp16 [Cout][Cin]; GN affine and
+ * biases fp32.  NULL sc_w = identity shortcut. */
+typedef struct lfm_vae_resnet {
+  const float* n1_g; const float* n1_b; const void* c1_w; const float* c1_b;
+  const float* n2_g; const float* n2_b; const void* c2_w; const float* c2_b;
+  const void* sc_w; const float* sc_b;
+  int cin, cout;
+} lfm_vae_resnet;
 
-/* out = base + sum_i coef[i] * k[i]  (i < nk <= 8), n elements; coef is a DEVICE array (RK stage combos). */
-int lfm_lincomb(float* out, const float* base, const float* const* k_host_ptrs, const float* coef, int nk, long n,
+typedef struct lfm_vae_weights {
+  const float* pq_w; const float* pq_b;   /* post_quant_conv [4,4], [4]           fp32 */
+  const float* cin_w; const float* cin_b; /* decoder.conv_in [512,4,3,3], [512]   fp32 */
+  lfm_vae_resnet mid[2];                  /* decoder.mid_block.resnets.{0,1}           */
+  const float* at_g; const float* at_b;   /* decoder.mid_block.attentions.0.group_norm */
+  const void* q_w; const float* q_b; const void* k_w; const float* k_b;
+  const void* v_w; const float* v_b; const void* o_w; const float* o_b;   /* to_q/to_k/to_v/to_out.0 */
+  lfm_vae_resnet up[4][3];                /* decoder.up_blocks.i.resnets.j             */
+  const void* ups_w[3]; const float* ups_b[3]; /* decoder.up_blocks.i.upsamplers.0.conv */
+  const float* no_g; const float* no_b;   /* decoder.conv_norm_out                     */
+  const void* cout_w; const float* cout_b; /* decoder.conv_out padded to 4 outputs: fp16 [4][9][128], fp32 [4] */
+} lfm_vae_weights;
+
+size_t lfm_vae_workspace_bytes(int R, int chunk);
+
+/* out[N,3,8R,8R] fp32 NCHW = decode(z[N,4,R,R] fp32 NCHW); images are processed `chunk` at a time so the
+ * activation working set (4 x chunk x (8R)^2 x 256 fp16) stays bounded. */
+int lfm_vae_decode(const lfm_vae_weights* w, void* workspace, size_t workspace_bytes, const float* z, float* out, int N, int R,
+                   int chunk, lfm_stream_t stream);
+
+/* u8 NHWC = trunc(clamp((x+1)/2, 0, 1) * 255) of fp32 NCHW images (test_flow_latent_ddp.py:131-135). */
+int lfm_images_to_uint8(const float* x, uint8_t* out, int N, int H, int W, lfm_stream_t stream);
+
+/* ------------------------------------------------------------------ solver helpers (device-resident time grid)
+ * Advance the captured step:  s = *step;  t_cur[0] = ts[s];  t_next[0] = ts[s+1];  dt_cur[0] = dts[s];  *step = s+1.
+ * ts has n+1 entries, dts n.  Lets ONE captured graph be replayed for every interval of the fixed grids of
+ * test_flow_latent.py:42-76 (torchdiffeq euler) and sampler/karras_sample.py:85-161 (Euler / Heun). */
+int lfm_grid_advance(const float* ts, const float* dts, int* step, float* t_cur, float* t_next, float* dt_cur, lfm_stream_t stream);
+
+/* out = base + (scale ? *scale : 1) * sum_i coef[i] * k[i]   (i < nk <= 8), n fp32 elements (n % 4 == 0).
+ * coef and scale are DEVICE memory (read at run time); k_host_ptrs is a HOST array of nk device pointers.
+ * Covers the Heun update x + dt*(0.5 d + 0.5 d') (karras_sample.py:157-159) and the Runge-Kutta stage sums of
+ * torchdiffeq's rk4 / dopri5. */
+int lfm_lincomb(float* out, const float* base, const float* const* k_host_ptrs, const float* coef, const float* scale, int nk, long n,
                 lfm_stream_t stream);
 
 #ifdef __cplusplus

@@ -340,9 +340,10 @@ __global__ __launch_bounds__(256) void final_layer_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------ solver helpers
-__global__ void grid_advance_kernel(const float* ts, const float* dts, int* step, float* t_cur, float* dt_cur) {
+__global__ void grid_advance_kernel(const float* ts, const float* dts, int* step, float* t_cur, float* t_next, float* dt_cur) {
   const int s = *step;
   *t_cur = ts[s];
+  *t_next = ts[s + 1];
   *dt_cur = dts[s];
   *step = s + 1;
 }
@@ -350,15 +351,17 @@ __global__ void grid_advance_kernel(const float* ts, const float* dts, int* step
 struct LinPtrs {
   const float* k[8];
 };
-__global__ void lincomb_kernel(float* __restrict__ out, const float* __restrict__ base, LinPtrs ks, const float* __restrict__ coef, int nk,
-                               long n4) {
+__global__ void lincomb_kernel(float* out, const float* base, LinPtrs ks, const float* __restrict__ coef, const float* __restrict__ scale,
+                               int nk, long n4) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
-  f32x4 acc = base ? ((const f32x4*)base)[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int j = 0; j < nk; ++j) {
     const float c = coef[j];
     if (c != 0.f) acc += c * ((const f32x4*)ks.k[j])[i];
   }
+  if (scale) acc *= *scale;
+  if (base) acc += ((const f32x4*)base)[i];
   ((f32x4*)out)[i] = acc;
 }
 
@@ -480,7 +483,7 @@ extern "C" int lfm_gemm_f16(const void* A, long lda, const void* W, long ldw, vo
   if (!A || !W || !C) return LFM_ERR_ARG;
   if ((lda % 8) || ((uintptr_t)A & 15)) return LFM_ERR_ALIGN;
   hipStream_t st = (hipStream_t)stream;
-  ASrcRowMajor a{(const half_t*)A, lda, M};
+  ASrcRowMajor a{(const half_t*)A, lda, M, 0};
   switch (epilogue) {
     case 0: return launch_gemm_tn(a, (const half_t*)W, ldw, M, N, K, EpiBiasF16{(half_t*)C, ldc, bias}, st);
     case 1:
@@ -519,7 +522,7 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
   hipLaunchKernelGGL(cond_kernel, dim3(cdiv((long)rows * D, 256)), dim3(256), 0, st, ws.temb, c->t_len, w->y_table, c->y, s->label_rows - 1,
                      ws.c_half, D, rows);
   LFM_CHECK_LAUNCH();
-  rc = launch_gemm_tn(ASrcRowMajor{ws.c_half, D, rows}, (const half_t*)w->ada_w, D, rows, (int)J, D, EpiBiasF32{ws.mod, J, w->ada_b}, st);
+  rc = launch_gemm_tn(ASrcRowMajor{ws.c_half, D, rows, 0}, (const half_t*)w->ada_w, D, rows, (int)J, D, EpiBiasF32{ws.mod, J, w->ada_b}, st);
   if (rc) return rc;
 
   hipLaunchKernelGGL(patch_embed_kernel, dim3(cdiv((long)M * (D / 4), 256)), dim3(256), 0, st, c->x, w->patch_w, w->patch_b, w->pos_embed, ws.X,
@@ -533,20 +536,20 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
     const float* mod = ws.mod + (long)i * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
     rc = ln_modulate_launch(ws.X, ws.A, M, D, T, mod, mod + D, mstride, st);
     if (rc) return rc;
-    rc = launch_gemm_tn(ASrcRowMajor{ws.A, D, M}, (const half_t*)w->qkv_w + (size_t)i * 3 * D * D, D, M, 3 * D, D,
+    rc = launch_gemm_tn(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->qkv_w + (size_t)i * 3 * D * D, D, M, 3 * D, D,
                         EpiQKV{Qb, Kb, Vb, w->qkv_b + (size_t)i * 3 * D, D, 64, T}, st);
     if (rc) return rc;
     rc = attention_launch(Qb, Kb, Vb, ws.A, B, s->heads, T, st);
     if (rc) return rc;
-    rc = launch_gemm_tn(ASrcRowMajor{ws.A, D, M}, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D,
+    rc = launch_gemm_tn(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D,
                         EpiGateResidF32{ws.X, D, w->proj_b + (size_t)i * D, mod + 2 * D, mstride, T}, st);
     if (rc) return rc;
     rc = ln_modulate_launch(ws.X, ws.A, M, D, T, mod + 3 * D, mod + 4 * D, mstride, st);
     if (rc) return rc;
-    rc = launch_gemm_tn(ASrcRowMajor{ws.A, D, M}, (const half_t*)w->fc1_w + (size_t)i * H * D, D, M, H, D,
+    rc = launch_gemm_tn(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->fc1_w + (size_t)i * H * D, D, M, H, D,
                         EpiBiasGeluF16{ws.QKVH, H, w->fc1_b + (size_t)i * H}, st);
     if (rc) return rc;
-    rc = launch_gemm_tn(ASrcRowMajor{ws.QKVH, H, M}, (const half_t*)w->fc2_w + (size_t)i * D * H, H, M, D, H,
+    rc = launch_gemm_tn(ASrcRowMajor{ws.QKVH, H, M, 0}, (const half_t*)w->fc2_w + (size_t)i * D * H, H, M, D, H,
                         EpiGateResidF32{ws.X, D, w->fc2_b + (size_t)i * D, mod + 5 * D, mstride, T}, st);
     if (rc) return rc;
   }
@@ -562,20 +565,20 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
   return LFM_OK;
 }
 
-extern "C" int lfm_grid_advance(const float* ts, const float* dts, int* step, float* t_cur, float* dt_cur, lfm_stream_t stream) {
-  if (!ts || !dts || !step || !t_cur || !dt_cur) return LFM_ERR_ARG;
-  hipLaunchKernelGGL(grid_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, ts, dts, step, t_cur, dt_cur);
+extern "C" int lfm_grid_advance(const float* ts, const float* dts, int* step, float* t_cur, float* t_next, float* dt_cur, lfm_stream_t stream) {
+  if (!ts || !dts || !step || !t_cur || !t_next || !dt_cur) return LFM_ERR_ARG;
+  hipLaunchKernelGGL(grid_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, ts, dts, step, t_cur, t_next, dt_cur);
   LFM_CHECK_LAUNCH();
   return LFM_OK;
 }
 
-extern "C" int lfm_lincomb(float* out, const float* base, const float* const* k_host_ptrs, const float* coef, int nk, long n,
-                           lfm_stream_t stream) {
+extern "C" int lfm_lincomb(float* out, const float* base, const float* const* k_host_ptrs, const float* coef, const float* scale, int nk,
+                           long n, lfm_stream_t stream) {
   if (!out || !coef || nk < 0 || nk > 8 || (nk && !k_host_ptrs)) return LFM_ERR_ARG;
   if (n % 4 || ((uintptr_t)out & 15)) return LFM_ERR_ALIGN;
   LinPtrs p;
   for (int i = 0; i < 8; ++i) p.k[i] = i < nk ? k_host_ptrs[i] : nullptr;
-  hipLaunchKernelGGL(lincomb_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, out, base, p, coef, nk, n / 4);
+  hipLaunchKernelGGL(lincomb_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, out, base, p, coef, scale, nk, n / 4);
   LFM_CHECK_LAUNCH();
   return LFM_OK;
 }

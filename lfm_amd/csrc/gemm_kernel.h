@@ -40,7 +40,9 @@ struct ASrcRowMajor {
     r.p = A + (long)(m < M ? m : M - 1) * lda;
     return r;
   }
-  __device__ __forceinline__ const half_t* ptr(const Row& r, int k) const { return r.p + k; }
+  int k0;
+  __device__ __forceinline__ void begin_tile(int kt) { k0 = kt * 64; }
+  __device__ __forceinline__ const half_t* ptr(const Row& r, int koff) const { return r.p + k0 + koff; }
 };
 
 // ------------------------------------------------------------------ epilogues
@@ -181,9 +183,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(ASrc asrc, const half_t
     char* sA = smem + stage * GEMM_STAGE_BYTES;
     char* sW = sA + GEMM_BM * GEMM_BK * 2;
     const int k0 = kt * GEMM_BK;
+    asrc.begin_tile(kt);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      glds16(asrc.ptr(arow[p], k0 + cswz[p]), sA + (p * 256 + wave * 64) * 16);
+      glds16(asrc.ptr(arow[p], cswz[p]), sA + (p * 256 + wave * 64) * 16);
       glds16(wrow[p] + k0 + cswz[p], sW + (p * 256 + wave * 64) * 16);
     }
   };

@@ -1,0 +1,418 @@
+// SD f8 KL-VAE decoder on gfx950 (decode half of diffusers AutoencoderKL, sd-vae-ft-mse config).
+// Reference call site: /root/reference/test_flow_latent.py:193  first_stage_model.decode(z / scale_factor).sample
+// Activations are NHWC fp16 ([pixels, C] row-major == the GEMM "A" operand), so every 3x3 convolution is an
+// implicit GEMM on the same MFMA kernel as the DiT linears: M = N*H*W pixels, N = Cout, K = 9*Cin with
+// k = tap*Cin + ci; the A-tile gather (shifted pixel rows, zero padding, optional nearest-2x upsample) is done
+// by the per-lane LDS-DMA source address.  GroupNorm statistics / apply+SiLU are bandwidth-bound side kernels.
+#include "../../include/lfm_hip.h"
+#include "gemm_kernel.h"
+
+// ------------------------------------------------------------------ implicit-GEMM A source: 3x3 conv, pad 1, NHWC
+// UPS=1: the convolution runs on the nearest-2x upsampled image (diffusers Upsample2D) without materialising it.
+template <int UPS>
+struct ASrcConv3x3 {
+  const half_t* in;    // [N, Hs, Ws, Cin] with Hs = H >> UPS
+  const half_t* zeros; // >= 64 halves of zeros (padding rows)
+  int H, W, Cin, M;    // output (= conv input after upsample) spatial size; M = N*H*W
+  int tap, ci0;        // k-tile state: k0 = tap*Cin + ci0 (a 64-wide k tile never straddles a tap: Cin % 64 == 0)
+  __device__ __forceinline__ void init(int, long) {}
+  struct Row {
+    int n, y, x;
+  };
+  __device__ __forceinline__ Row row(int m) const {
+    if (m >= M) m = M - 1;
+    Row r;
+    r.x = m % W;
+    const int t = m / W;
+    r.y = t % H;
+    r.n = t / H;
+    return r;
+  }
+  __device__ __forceinline__ void begin_tile(int kt) {  // called with kt = 0, 1, 2, ... in order
+    if (kt == 0) {
+      tap = 0;
+      ci0 = 0;
+    } else {
+      ci0 += GEMM_BK;
+      if (ci0 >= Cin) {
+        ci0 = 0;
+        ++tap;
+      }
+    }
+  }
+  __device__ __forceinline__ const half_t* ptr(const Row& r, int koff) const {
+    const int iy = r.y + tap / 3 - 1, ix = r.x + tap % 3 - 1;
+    if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) return zeros + koff;
+    const int Hs = H >> UPS, Ws = W >> UPS;
+    return in + (((long)r.n * Hs + (iy >> UPS)) * Ws + (ix >> UPS)) * Cin + ci0 + koff;
+  }
+};
+
+// ------------------------------------------------------------------ epilogues
+struct EpiConvF16 {  // out = acc + bias (+ residual)  -> fp16 NHWC
+  half_t* C;
+  long ldc;
+  const float* bias;
+  const half_t* resid;  // may be null; same layout as C
+  struct Aux {
+    f32x4 b;
+    half4_t r;
+  };
+  __device__ __forceinline__ Aux load(int m, int n) const {
+    Aux a;
+    a.b = *(const f32x4*)(bias + n);
+    if (resid) a.r = *(const half4_t*)(resid + (long)m * ldc + n);
+    else a.r = (half4_t){0, 0, 0, 0};
+    return a;
+  }
+  __device__ __forceinline__ void store(int m, int n, f32x4 v, const Aux& a) const {
+    v += a.b;
+    half4_t h = {(half_t)(v.x + (float)a.r.x), (half_t)(v.y + (float)a.r.y), (half_t)(v.z + (float)a.r.z), (half_t)(v.w + (float)a.r.w)};
+    *(half4_t*)(C + (long)m * ldc + n) = h;
+  }
+};
+
+struct EpiTransposeF16 {  // per image: Ct[img][n][m % T] = acc + bias[n]   (V^T for the mid attention)
+  half_t* Ct;
+  const float* bias;
+  int T, N;
+  typedef f32x4 Aux;
+  __device__ __forceinline__ Aux load(int, int n) const { return *(const f32x4*)(bias + n); }
+  __device__ __forceinline__ void store(int m, int n, f32x4 v, const Aux& b) const {
+    v += b;
+    const int img = m / T, tok = m - img * T;
+    half_t* d = Ct + ((long)img * N + n) * T + tok;
+    d[0] = (half_t)v.x;
+    d[T] = (half_t)v.y;
+    d[2 * T] = (half_t)v.z;
+    d[3 * T] = (half_t)v.w;
+  }
+};
+
+struct EpiBatchF32 {  // batched scores: S[bz][m][n] = acc
+  float* C;
+  long ldc;
+  typedef int Aux;
+  __device__ __forceinline__ void batch(int bz, long bs) { C += (long)bz * bs; }
+  __device__ __forceinline__ Aux load(int, int) const { return 0; }
+  __device__ __forceinline__ void store(int m, int n, f32x4 v, const Aux&) const { *(f32x4*)(C + (long)m * ldc + n) = v; }
+};
+
+struct EpiBatchF16 {  // batched: O[bz][m][n] = acc -> fp16
+  half_t* C;
+  long ldc;
+  typedef int Aux;
+  __device__ __forceinline__ void batch(int bz, long bs) { C += (long)bz * bs; }
+  __device__ __forceinline__ Aux load(int, int) const { return 0; }
+  __device__ __forceinline__ void store(int m, int n, f32x4 v, const Aux&) const {
+    half4_t h = {(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
+    *(half4_t*)(C + (long)m * ldc + n) = h;
+  }
+};
+
+struct EpiConvOutNCHW {  // final conv (Cout=3, padded to 4): fp32 NCHW image, the `.sample` tensor
+  float* out;
+  const float* bias;  // [4]
+  int HW;             // H*W
+  typedef f32x4 Aux;
+  __device__ __forceinline__ Aux load(int, int n) const { return *(const f32x4*)(bias + n); }
+  __device__ __forceinline__ void store(int m, int n, f32x4 v, const Aux& b) const {
+    if (n != 0) return;
+    v += b;
+    const int img = m / HW, pix = m - img * HW;
+    float* o = out + (long)img * 3 * HW + pix;
+    o[0] = v.x;
+    o[HW] = v.y;
+    o[2 * HW] = v.z;
+  }
+};
+
+// ------------------------------------------------------------------ post_quant_conv (1x1, 4->4) + conv_in (3x3, 4->Cout)
+// z fp32 NCHW [N,4,R,R] -> fp16 NHWC [N,R,R,Cout].  conv_in sees post_quant(z) zero-padded, so the 1x1 is
+// evaluated per tap and skipped (=0) outside the image.  One thread = one pixel x 8 output channels.
+__global__ __launch_bounds__(256) void vae_conv_in_kernel(const float* __restrict__ z, const float* __restrict__ pq_w,
+                                                          const float* __restrict__ pq_b, const float* __restrict__ w,
+                                                          const float* __restrict__ b, half_t* __restrict__ out, int N, int R, int Cout) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c8 = Cout / 8;
+  if (idx >= (long)N * R * R * c8) return;
+  const int co = (int)(idx % c8) * 8;
+  const long pix = idx / c8;
+  const int x = (int)(pix % R), y = (int)((pix / R) % R), n = (int)(pix / ((long)R * R));
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = b[co + j];
+  for (int ky = 0; ky < 3; ++ky)
+    for (int kx = 0; kx < 3; ++kx) {
+      const int iy = y + ky - 1, ix = x + kx - 1;
+      if ((unsigned)iy >= (unsigned)R || (unsigned)ix >= (unsigned)R) continue;
+      float zi[4], pq[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) zi[c] = z[(((long)n * 4 + c) * R + iy) * R + ix];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) pq[c] = pq_b[c] + pq_w[c * 4 + 0] * zi[0] + pq_w[c * 4 + 1] * zi[1] + pq_w[c * 4 + 2] * zi[2] + pq_w[c * 4 + 3] * zi[3];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[j] += w[(((long)(co + j) * 4 + c) * 3 + ky) * 3 + kx] * pq[c];
+    }
+  half8_t h;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) h[j] = (half_t)acc[j];
+  *(half8_t*)(out + pix * Cout + co) = h;
+}
+
+// ------------------------------------------------------------------ GroupNorm(32 groups, eps 1e-6) on NHWC fp16
+// stats[n][g] = {sum, sumsq} accumulated with one atomicAdd pair per (block, group-slice); apply fuses SiLU.
+// Block = 256 threads over a slab of pixels; thread t owns channel-octet (t % (C/8)) and strides over pixels.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict__ stats, int HW, int C,
+                                                       int pix_per_block) {
+  __shared__ float red[4][256];
+  const int n = blockIdx.y, c8n = C / 8, tid = threadIdx.x;
+  const int oct = tid % c8n, prow = tid / c8n, pstride = 256 / c8n;
+  const int p0 = blockIdx.x * pix_per_block;
+  const int p1 = min(p0 + pix_per_block, HW);
+  float s[2] = {0.f, 0.f}, q[2] = {0.f, 0.f};  // per half-octet (4 channels): a group is >= 4 channels wide
+  const half_t* base = x + (long)n * HW * C + oct * 8;
+  for (int p = p0 + prow; p < p1; p += pstride) {
+    const half8_t v = *(const half8_t*)(base + (long)p * C);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float f = (float)v[j];
+      s[j >> 2] += f;
+      q[j >> 2] += f * f;
+    }
+  }
+  red[0][tid] = s[0];
+  red[1][tid] = s[1];
+  red[2][tid] = q[0];
+  red[3][tid] = q[1];
+  __syncthreads();
+  if (tid < c8n) {  // fold the pixel-rows of this channel octet, then one atomic pair per half-octet
+    for (int r = 1; r < pstride; ++r) {
+      s[0] += red[0][tid + r * c8n];
+      s[1] += red[1][tid + r * c8n];
+      q[0] += red[2][tid + r * c8n];
+      q[1] += red[3][tid + r * c8n];
+    }
+    const int cpg = C / 32;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int g = (tid * 8 + hh * 4) / cpg;
+      atomicAdd(&stats[((long)n * 32 + g) * 2 + 0], s[hh]);
+      atomicAdd(&stats[((long)n * 32 + g) * 2 + 1], q[hh]);
+    }
+  }
+}
+
+template <bool SILU>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, const float* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, int HW, int C,
+                                                       long total8) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total8) return;
+  const int c8n = C / 8, cpg = C / 32;
+  const int oct = (int)(i % c8n);
+  const int n = (int)(i / ((long)c8n * HW));
+  const float cnt = (float)HW * (float)cpg;
+  const half8_t v = ((const half8_t*)x)[i];
+  half8_t o;
+  float mean[2], rstd[2];
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {
+    const int g = (oct * 8 + hh * 4) / cpg;
+    mean[hh] = stats[((long)n * 32 + g) * 2] / cnt;
+    const float var = fmaxf(stats[((long)n * 32 + g) * 2 + 1] / cnt - mean[hh] * mean[hh], 0.f);
+    rstd[hh] = rsqrtf(var + 1e-6f);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = oct * 8 + j;
+    float f = ((float)v[j] - mean[j >> 2]) * rstd[j >> 2] * gamma[c] + beta[c];
+    if (SILU) f = silu_f(f);
+    o[j] = (half_t)f;
+  }
+  ((half8_t*)y)[i] = o;
+}
+
+// rows of S [rows, T] fp32 -> P fp16 = softmax(S * scale); one wave per row.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, half_t* __restrict__ P, long rows, int T, float scale_log2e) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* s = S + r * T;
+  float mx = -3.0e38f;
+  for (int i = lane; i < T; i += 64) mx = fmaxf(mx, s[i]);
+  mx = wave_max(mx) * scale_log2e;
+  float sum = 0.f;
+  for (int i = lane; i < T; i += 64) sum += __builtin_amdgcn_exp2f(s[i] * scale_log2e - mx);
+  const float inv = 1.0f / wave_sum(sum);
+  half_t* p = P + r * T;
+  for (int i = lane; i < T; i += 64) p[i] = (half_t)(__builtin_amdgcn_exp2f(s[i] * scale_log2e - mx) * inv);
+}
+
+// ------------------------------------------------------------------ host side
+static inline size_t a256(size_t v) { return (v + 255) / 256 * 256; }
+
+struct VaeWs {
+  half_t *b0, *b1, *b2, *b3;  // four ping-pong activation buffers of the largest size
+  float* stats;               // [chunk, 32, 2]
+  half_t* zeros;              // 256 B
+  float* S;                   // [chunk, T, T] scores
+  size_t total;
+};
+
+static VaeWs vae_carve(int R, int chunk, void* ws) {
+  // largest activation: 128 ch at 8R x 8R  ==  256 ch at 4R x 4R x 2 ... = chunk * (8R)^2 * 128 halves;
+  // the upsample conv of block 2 writes 256 ch at 8R x 8R: chunk * (8R)^2 * 256 halves -> size for that.
+  const size_t act = (size_t)chunk * (8 * R) * (8 * R) * 256 * 2;
+  const size_t T = (size_t)R * R;
+  size_t off = 0;
+  char* base = (char*)ws;
+  auto take = [&](size_t bytes) {
+    char* p = base ? base + off : nullptr;
+    off += a256(bytes);
+    return p;
+  };
+  VaeWs w;
+  w.b0 = (half_t*)take(act);
+  w.b1 = (half_t*)take(act);
+  w.b2 = (half_t*)take(act);
+  w.b3 = (half_t*)take(act);
+  w.stats = (float*)take((size_t)chunk * 64 * 4);
+  w.zeros = (half_t*)take(256);
+  w.S = (float*)take((size_t)chunk * T * T * 4);
+  w.total = off;
+  return w;
+}
+
+extern "C" size_t lfm_vae_workspace_bytes(int R, int chunk) {
+  if (R <= 0 || chunk <= 0 || (R % 8)) return 0;
+  return vae_carve(R, chunk, nullptr).total;
+}
+
+#define RC(x)            \
+  do {                   \
+    int _rc = (x);       \
+    if (_rc) return _rc; \
+  } while (0)
+
+static int gn(const half_t* x, half_t* y, float* stats, const float* g, const float* b, int n, int HW, int C, bool silu, hipStream_t st) {
+  if (C % 128 || 256 % (C / 8)) return LFM_ERR_SHAPE;  // groups of >= 4 channels, octet-per-thread mapping
+  if (hipMemsetAsync(stats, 0, (size_t)n * 64 * 4, st) != hipSuccess) return LFM_ERR_LAUNCH;
+  const int ppb = 1024;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(cdiv(HW, ppb), n), dim3(256), 0, st, x, stats, HW, C, ppb);
+  LFM_CHECK_LAUNCH();
+  const long total8 = (long)n * HW * C / 8;
+  if (silu) hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(cdiv(total8, 256)), dim3(256), 0, st, x, y, stats, g, b, HW, C, total8);
+  else hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(cdiv(total8, 256)), dim3(256), 0, st, x, y, stats, g, b, HW, C, total8);
+  LFM_CHECK_LAUNCH();
+  return LFM_OK;
+}
+
+// out[n,H,W,Cout] = conv3x3(in (optionally nearest-2x upsampled)) + bias (+ resid)
+static int conv3(const half_t* in, const half_t* w, const float* b, const half_t* resid, half_t* out, const half_t* zeros, int n, int H, int W,
+                 int Cin, int Cout, bool ups, hipStream_t st) {
+  if (Cin % 64 || Cout % 4) return LFM_ERR_SHAPE;
+  const int M = n * H * W;
+  EpiConvF16 epi{out, Cout, b, resid};
+  if (ups) return launch_gemm_tn(ASrcConv3x3<1>{in, zeros, H, W, Cin, M, 0, 0}, w, 9L * Cin, M, Cout, 9 * Cin, epi, st);
+  return launch_gemm_tn(ASrcConv3x3<0>{in, zeros, H, W, Cin, M, 0, 0}, w, 9L * Cin, M, Cout, 9 * Cin, epi, st);
+}
+
+static int resnet(const lfm_vae_resnet* r, half_t*& x, half_t*& t1, half_t*& t2, half_t*& t3, const VaeWs& ws, int n, int H, int W, hipStream_t st) {
+  const int HW = H * W, M = n * HW;
+  RC(gn(x, t1, ws.stats, r->n1_g, r->n1_b, n, HW, r->cin, true, st));
+  RC(conv3(t1, (const half_t*)r->c1_w, r->c1_b, nullptr, t2, ws.zeros, n, H, W, r->cin, r->cout, false, st));
+  RC(gn(t2, t1, ws.stats, r->n2_g, r->n2_b, n, HW, r->cout, true, st));
+  const half_t* skip = x;
+  if (r->sc_w) {  // 1x1 conv shortcut
+    RC(launch_gemm_tn(ASrcRowMajor{x, r->cin, M, 0}, (const half_t*)r->sc_w, r->cin, M, r->cout, r->cin, EpiConvF16{t3, r->cout, r->sc_b, nullptr}, st));
+    skip = t3;
+  }
+  RC(conv3(t1, (const half_t*)r->c2_w, r->c2_b, skip, t2, ws.zeros, n, H, W, r->cout, r->cout, false, st));
+  half_t* o = t2;  // result in t2; rotate buffers so x is the result
+  t2 = x;
+  x = o;
+  return LFM_OK;
+}
+
+extern "C" int lfm_vae_decode(const lfm_vae_weights* w, void* workspace, size_t workspace_bytes, const float* z, float* out, int N, int R,
+                              int chunk, lfm_stream_t stream) {
+  if (!w || !workspace || !z || !out) return LFM_ERR_ARG;
+  if (N <= 0 || R <= 0 || (R % 8) || chunk <= 0) return LFM_ERR_SHAPE;
+  const VaeWs ws = vae_carve(R, chunk, workspace);
+  if (ws.total > workspace_bytes) return LFM_ERR_WORKSPACE;
+  if ((uintptr_t)workspace & 255) return LFM_ERR_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(ws.zeros, 0, 256, st) != hipSuccess) return LFM_ERR_LAUNCH;
+  const int T = R * R;
+  for (int n0 = 0; n0 < N; n0 += chunk) {
+    const int n = (N - n0 < chunk) ? N - n0 : chunk;
+    half_t *x = ws.b0, *t1 = ws.b1, *t2 = ws.b2, *t3 = ws.b3;
+    hipLaunchKernelGGL(vae_conv_in_kernel, dim3(cdiv((long)n * T * 64, 256)), dim3(256), 0, st, z + (long)n0 * 4 * T, w->pq_w, w->pq_b, w->cin_w,
+                       w->cin_b, x, n, R, 512);
+    LFM_CHECK_LAUNCH();
+    int H = R;
+    RC(resnet(&w->mid[0], x, t1, t2, t3, ws, n, H, H, st));
+    {  // mid attention: 1 head of 512 channels over T = R*R tokens, all on the GEMM kernel
+      const int M = n * T, C = 512;
+      RC(gn(x, t1, ws.stats, w->at_g, w->at_b, n, T, C, false, st));
+      half_t* Qb = t2;                 // [M, C]
+      half_t* Kb = t2 + (size_t)M * C;  // [M, C]
+      half_t* Vt = t3;                 // [n, C, T]
+      half_t* Pb = t3 + (size_t)M * C;  // [n, T, T]
+      RC(launch_gemm_tn(ASrcRowMajor{t1, C, M, 0}, (const half_t*)w->q_w, C, M, C, C, EpiConvF16{Qb, C, w->q_b, nullptr}, st));
+      RC(launch_gemm_tn(ASrcRowMajor{t1, C, M, 0}, (const half_t*)w->k_w, C, M, C, C, EpiConvF16{Kb, C, w->k_b, nullptr}, st));
+      RC(launch_gemm_tn(ASrcRowMajor{t1, C, M, 0}, (const half_t*)w->v_w, C, M, C, C, EpiTransposeF16{Vt, w->v_b, T, C}, st));
+      RC(launch_gemm_tn(ASrcRowMajor{Qb, C, T, 0}, Kb, C, T, T, C, EpiBatchF32{ws.S, T}, st, n, (long)T * C, (long)T * C, (long)T * T));
+      hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv((long)n * T, 4)), dim3(256), 0, st, ws.S, Pb, (long)n * T, T,
+                         1.4426950408889634f / sqrtf((float)C));
+      LFM_CHECK_LAUNCH();
+      half_t* Ob = t1;  // GN output is dead now
+      RC(launch_gemm_tn(ASrcRowMajor{Pb, T, T, 0}, Vt, T, T, C, T, EpiBatchF16{Ob, C}, st, n, (long)T * T, (long)C * T, (long)T * C));
+      RC(launch_gemm_tn(ASrcRowMajor{Ob, C, M, 0}, (const half_t*)w->o_w, C, M, C, C, EpiConvF16{t2, C, w->o_b, x}, st));
+      half_t* o = t2;
+      t2 = x;
+      x = o;
+    }
+    RC(resnet(&w->mid[1], x, t1, t2, t3, ws, n, H, H, st));
+    for (int i = 0; i < 4; ++i) {
+      for (int j = 0; j < 3; ++j) RC(resnet(&w->up[i][j], x, t1, t2, t3, ws, n, H, H, st));
+      if (i < 3) {
+        const int C = w->up[i][2].cout;
+        H *= 2;
+        RC(conv3(x, (const half_t*)w->ups_w[i], w->ups_b[i], nullptr, t1, ws.zeros, n, H, H, C, C, true, st));
+        half_t* o = t1;
+        t1 = x;
+        x = o;
+      }
+    }
+    RC(gn(x, t1, ws.stats, w->no_g, w->no_b, n, H * H, 128, true, st));
+    const int M = n * H * H;
+    RC(launch_gemm_tn(ASrcConv3x3<0>{t1, ws.zeros, H, H, 128, M, 0, 0}, (const half_t*)w->cout_w, 9L * 128, M, 4, 9 * 128,
+                      EpiConvOutNCHW{out + (long)n0 * 3 * H * H, w->cout_b, H * H}, st));
+  }
+  return LFM_OK;
+}
+
+// images: u8 NHWC = trunc(clamp((x + 1) / 2, 0, 1) * 255)   (test_flow_latent_ddp.py:131-135)
+__global__ void to_uint8_nhwc_kernel(const float* __restrict__ x, uint8_t* __restrict__ o, int HW, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over N*HW pixels
+  if (i >= total) return;
+  const long n = i / HW, p = i - n * HW;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float v = (x[(n * 3 + c) * HW + p] + 1.0f) * 0.5f;
+    v = fminf(fmaxf(v, 0.f), 1.f) * 255.0f;
+    o[i * 3 + c] = (uint8_t)v;
+  }
+}
+
+extern "C" int lfm_images_to_uint8(const float* x, uint8_t* out, int N, int H, int W, lfm_stream_t stream) {
+  if (!x || !out) return LFM_ERR_ARG;
+  const long total = (long)N * H * W;
+  hipLaunchKernelGGL(to_uint8_nhwc_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, out, H * W, total);
+  LFM_CHECK_LAUNCH();
+  return LFM_OK;
+}

@@ -61,9 +61,15 @@ def lib():
     L.lfm_dit_attention.restype = C.c_int
     L.lfm_dit_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.lfm_grid_advance.restype = C.c_int
-    L.lfm_grid_advance.argtypes = [C.c_void_p] * 5 + [C.c_void_p]
+    L.lfm_grid_advance.argtypes = [C.c_void_p] * 7
     L.lfm_lincomb.restype = C.c_int
-    L.lfm_lincomb.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_long, C.c_void_p]
+    L.lfm_lincomb.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_void_p]
+    L.lfm_vae_workspace_bytes.restype = C.c_size_t
+    L.lfm_vae_workspace_bytes.argtypes = [C.c_int, C.c_int]
+    L.lfm_vae_decode.restype = C.c_int
+    L.lfm_vae_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.lfm_images_to_uint8.restype = C.c_int
+    L.lfm_images_to_uint8.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     _lib = L
     return L
 
@@ -112,3 +118,11 @@ def dit_attention(Q, K, Vt, batch, heads, T):
     O = torch.empty_like(Q)
     check(lib().lfm_dit_attention(ptr(Q), ptr(K), ptr(Vt), ptr(O), batch, heads, T, stream_ptr()), "lfm_dit_attention")
     return O
+
+
+def lincomb(out, base, ks, coef, scale=None):
+    """out = base + (*scale) * sum coef[i]*ks[i]  (device fp32 tensors; coef/scale are device tensors)."""
+    require_gpu(out, "lincomb")
+    arr = (C.c_void_p * len(ks))(*[k.data_ptr() for k in ks])
+    check(lib().lfm_lincomb(ptr(out), ptr(base), arr, ptr(coef), ptr(scale), len(ks), out.numel(), stream_ptr(out.device)), "lfm_lincomb")
+    return out

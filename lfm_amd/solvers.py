@@ -1,0 +1,324 @@
+"""ODE solvers of the sampling loop (what the reference gets from torchdiffeq at test_flow_latent.py:23,61-73).
+
+``odeint(func, y0, t, method=, rtol=, atol=, options=)`` follows torchdiffeq's contract for the call the reference
+makes -- ``t = tensor([1., 0.])`` (decreasing => time is negated internally), fixed-grid ``euler / midpoint / rk4``
+with ``options={"step_size": h}`` and adaptive ``dopri5`` with fp64 time -- and returns ``[len(t), *y0.shape]``.
+It is host control flow over device tensors and works for any callable.
+
+The production path is ``GraphedFixedGrid``: for the HIP DiT the whole solver interval (time-grid advance, velocity
+field incl. CFG doubling, and the update x <- x + dt*v fused into the model's last kernel) is captured once in a
+hipGraph and replayed per interval; the time grid lives in device memory so the replay needs no host value.
+"""
+import math
+
+import torch
+
+from . import hip
+
+ADAPTIVE_SOLVER = ["dopri5", "dopri8", "adaptive_heun", "bosh3"]
+FIXER_SOLVER = ["euler", "rk4", "midpoint", "stochastic"]
+
+
+# ============================================================================ generic odeint
+def fixed_grid(t, step_size):
+    """torchdiffeq grid constructor: arange(n)*h + t0 with the last point forced to t_end (t already increasing)."""
+    niters = torch.ceil((t[-1] - t[0]) / step_size + 1).item()
+    grid = torch.arange(0, niters, dtype=t.dtype, device=t.device) * step_size + t[0]
+    grid[-1] = t[-1]
+    return grid
+
+
+def _euler_step(f, t0, dt, t1, y0):
+    return dt * f(t0, y0)
+
+
+def _midpoint_step(f, t0, dt, t1, y0):
+    half = 0.5 * dt
+    return dt * f(t0 + half, y0 + f(t0, y0) * half)
+
+
+def _rk4_step(f, t0, dt, t1, y0):  # torchdiffeq's "rk4" is the 3/8 rule
+    k1 = f(t0, y0)
+    k2 = f(t0 + dt / 3, y0 + dt * k1 / 3)
+    k3 = f(t0 + dt * 2 / 3, y0 + dt * (k2 - k1 / 3))
+    k4 = f(t1, y0 + dt * (k1 - k2 + k3))
+    return (k1 + 3 * (k2 + k3) + k4) * dt * 0.125
+
+
+_STEP = {"euler": _euler_step, "midpoint": _midpoint_step, "rk4": _rk4_step}
+
+# Dormand-Prince 5(4), Shampine's dense-output midpoint coefficients
+_DP_A = (1 / 5, 3 / 10, 4 / 5, 8 / 9, 1.0, 1.0)
+_DP_B = ((1 / 5,), (3 / 40, 9 / 40), (44 / 45, -56 / 15, 32 / 9), (19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729),
+         (9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656), (35 / 384, 0.0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84))
+_DP_E = (35 / 384 - 1951 / 21600, 0.0, 500 / 1113 - 22642 / 50085, 125 / 192 - 451 / 720, -2187 / 6784 + 12231 / 42400,
+         11 / 84 - 649 / 6300, -1.0 / 60.0)
+_DP_MID = (6025192743 / 30085553152 / 2, 0.0, 51252292925 / 65400821598 / 2, -2691868925 / 45128329728 / 2,
+           187940372067 / 1594534317056 / 2, -1776094331 / 19743644256 / 2, 11237099 / 235043384 / 2)
+
+
+def _rms(x):
+    return x.pow(2).mean().sqrt()
+
+
+def _comb(ks, coefs, dt):
+    acc = None
+    for k, c in zip(ks, coefs):
+        if c != 0:
+            term = k * (c * dt)
+            acc = term if acc is None else acc + term
+    return acc
+
+
+class Dopri5:
+    """Adaptive Dormand-Prince as torchdiffeq runs it: fp64 time, RMS error norm over the WHOLE state tensor (step sizes
+    are batch-coupled), accept iff ratio <= 1, dt *= min(10, max(0.9 ratio^-1/5, 0.2|1)), FSAL, steps not clipped to the end
+    time (the model is queried slightly past it), 4th-order dense output evaluated at the requested time."""
+
+    def __init__(self, f, y0, t0, rtol, atol, max_num_steps=2 ** 31 - 1):
+        self.f, self.rtol, self.atol, self.max_num_steps = f, rtol, atol, max_num_steps
+        self.nfe_steps = 0
+        self.accepted = 0
+        f0 = f(t0, y0)
+        self.y0, self.f0 = y0, f0
+        self.t0 = self.t1 = t0
+        self.dt = self._initial_step(t0, y0, f0)
+        self.coef = [y0] * 5
+
+    def _initial_step(self, t0, y0, f0, order=4):
+        scale = self.atol + y0.abs() * self.rtol
+        d0, d1 = _rms(y0 / scale), _rms(f0 / scale)
+        h0 = torch.full_like(d0, 1e-6) if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
+        f1 = self.f(t0.to(y0.dtype) + h0, y0 + h0 * f0)
+        d2 = _rms((f1 - f0) / scale) / h0
+        if d1 <= 1e-15 and d2 <= 1e-15:
+            h1 = torch.max(torch.full_like(h0, 1e-6), h0 * 1e-3)
+        else:
+            h1 = (0.01 / torch.max(d1, d2)) ** (1.0 / (order + 1))
+        return torch.min(100 * h0, h1).to(t0.dtype)
+
+    def _step(self):
+        y0, f0, t0, dt = self.y0, self.f0, self.t1, self.dt
+        t1 = t0 + dt
+        t0y, dty, t1y = t0.to(y0.dtype), dt.to(y0.dtype), t1.to(y0.dtype)
+        k = [f0]
+        yi = y0
+        for a, b in zip(_DP_A, _DP_B):
+            yi = y0 + _comb(k, b, dty)
+            k.append(self.f(t1y if a == 1.0 else t0y + a * dty, yi))
+        y1, f1 = yi, k[-1]
+        err = _comb(k, _DP_E, dty)
+        tol = self.atol + self.rtol * torch.max(y0.abs(), y1.abs())
+        ratio = _rms(err / tol)  # the one device->host read of the step
+        ratio_h = float(ratio)
+        self.nfe_steps += 1
+        if ratio_h <= 1:
+            y_mid = y0 + _comb(k, _DP_MID, dty)
+            a = 2 * dty * (f1 - f0) - 8 * (y1 + y0) + 16 * y_mid
+            b = dty * (5 * f0 - 3 * f1) + 18 * y0 + 14 * y1 - 32 * y_mid
+            c = dty * (f1 - 4 * f0) - 11 * y0 - 5 * y1 + 16 * y_mid
+            self.coef = [y0, dty * f0, c, b, a]
+            self.t0, self.t1, self.y0, self.f0 = t0, t1, y1, f1
+            self.accepted += 1
+        if ratio_h == 0:
+            factor = 10.0
+        else:
+            factor = min(10.0, max(0.9 / ratio_h ** 0.2, 1.0 if ratio_h < 1 else 0.2))
+        self.dt = dt * factor
+
+    def advance(self, t_next):
+        n = 0
+        while bool(t_next > self.t1):
+            assert n < self.max_num_steps
+            self._step()
+            n += 1
+        x = ((t_next - self.t0) / (self.t1 - self.t0)).to(self.coef[0].dtype)
+        total = self.coef[0] + x * self.coef[1]
+        xp = x
+        for c in self.coef[2:]:
+            xp = xp * x
+            total = total + xp * c
+        return total
+
+
+@torch.no_grad()
+def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, stats=None):
+    method = method or "dopri5"
+    options = dict(options or {})
+    t = t.detach().clone()
+    f = func
+    if len(t) > 1 and bool(t[0] > t[1]):  # decreasing time: integrate s = -t with f'(s, y) = -f(-s, y)
+        t = -t
+        f = lambda s, y, _f=func: -_f(-s, y)  # noqa: E731
+    g = lambda s, y, _f=f: _f(s.to(y.dtype), y)  # noqa: E731  -- the model always sees time in y's dtype
+    if method in _STEP:
+        if "step_size" not in options:
+            raise ValueError("fixed-grid solvers need options['step_size']")
+        grid = fixed_grid(t, options["step_size"])
+        step = _STEP[method]
+        sol, j = [y0], 1
+        tl = t.tolist()
+        gl = grid.tolist()
+        for i in range(len(gl) - 1):
+            t0, t1 = grid[i], grid[i + 1]
+            y1 = y0 + step(g, t0, t1 - t0, t1, y0)
+            while j < len(tl) and gl[i + 1] >= tl[j]:
+                if tl[j] == gl[i + 1]:
+                    sol.append(y1)
+                elif tl[j] == gl[i]:
+                    sol.append(y0)
+                else:
+                    sol.append(y0 + (t[j] - t0) / (t1 - t0) * (y1 - y0))
+                j += 1
+            y0 = y1
+        return torch.stack(sol, 0)
+    if method == "dopri5":
+        t = t.to(torch.float64)
+        solver = Dopri5(g, y0, t[0], rtol, atol)
+        sol = [y0] + [solver.advance(t[j]) for j in range(1, len(t))]
+        if stats is not None:
+            stats.update(steps=solver.nfe_steps, accepted=solver.accepted, nfe=2 + 6 * solver.nfe_steps)
+        return torch.stack(sol, 0)
+    raise NotImplementedError(f"method {method!r}: euler / midpoint / rk4 / dopri5 are built (SURVEY.md §8 a5)")
+
+
+def torchdiffeq_euler_grid(step_size, device=None):
+    """Model-time grid of ``odeint(..., t=[1,0], method='euler', options={'step_size': h})``: returns (ts[n+1], dts[n]) with
+    t_k = -(k*h - 1) evaluated in fp32 exactly like the grid constructor and x_{k+1} = x_k + dts[k] * v(ts[k], x_k)."""
+    s = fixed_grid(torch.tensor([-1.0, -0.0]), step_size)
+    ts = -s
+    dts = -(s[1:] - s[:-1])
+    return ts.to(device), dts.to(device)
+
+
+# ============================================================================ fused, graph-captured fixed grid
+def fused_fixed_grid_available(model, x):
+    from .models.DiT import DiT
+
+    return isinstance(model, DiT) and x.is_cuda and not model.training
+
+
+class GraphedFixedGrid:
+    """One captured hipGraph per (model, batch, cfg) for the intervals of a fixed time grid.
+
+    euler interval :  advance(t, dt) -> DiT forward with  x <- x + dt * v(t, x)  fused into its final kernel.
+    heun interval  :  advance -> d1 = v(t, x);  xp = x + dt*d1;  d2 = v(t_next, xp);  x <- x + dt*(0.5 d1 + 0.5 d2).
+    """
+
+    def __init__(self, model, batch, y=None, cfg_scale=1.0, use_cfg=False, graph=True):
+        dev = model.pos_embed.device
+        C, R = model.in_channels, model.img_resolution
+        self.model, self.batch, self.dev = model, batch, dev
+        self.y = None if y is None else y.to(dev, torch.long).contiguous()
+        self.use_cfg, self.cfg_scale = bool(use_cfg), float(cfg_scale)
+        self.x = torch.zeros(batch, C, R, R, device=dev)
+        self.d1 = torch.zeros_like(self.x)
+        self.d2 = torch.zeros_like(self.x)
+        self.xp = torch.zeros_like(self.x)
+        self.step = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.tcur = torch.zeros(1, device=dev)
+        self.tnext = torch.zeros(1, device=dev)
+        self.dt = torch.zeros(1, device=dev)
+        self.c1 = torch.ones(1, device=dev)
+        self.c2 = torch.full((2,), 0.5, device=dev)
+        self.ts = self.dts = None
+        self.use_graph = graph
+        self.graphs = {}
+
+    def set_grid(self, ts, dts):
+        self.ts = ts.to(self.dev, torch.float32).contiguous()
+        self.dts = dts.to(self.dev, torch.float32).contiguous()
+
+    def _advance(self):
+        hip.check(hip.lib().lfm_grid_advance(hip.ptr(self.ts), hip.ptr(self.dts), hip.ptr(self.step), hip.ptr(self.tcur), hip.ptr(self.tnext),
+                                             hip.ptr(self.dt), hip.stream_ptr(self.dev)), "lfm_grid_advance")
+
+    def _euler(self):
+        self._advance()
+        self.model._run(self.tcur, self.x, self.y, self.use_cfg, self.cfg_scale, out=self.x, axpy_base=self.x, axpy_dt=self.dt)
+
+    def _heun(self):
+        self._advance()
+        self.model._run(self.tcur, self.x, self.y, self.use_cfg, self.cfg_scale, out=self.d1)
+        hip.lincomb(self.xp, self.x, [self.d1], self.c1, self.dt)
+        self.model._run(self.tnext, self.xp, self.y, self.use_cfg, self.cfg_scale, out=self.d2)
+        hip.lincomb(self.x, self.x, [self.d1, self.d2], self.c2, self.dt)
+
+    def _get(self, kind):
+        fn = self._euler if kind == "euler" else self._heun
+        if not self.use_graph:
+            return fn
+        if kind not in self.graphs:
+            # warm up on a side stream (packs weights, sizes the workspace, sets kernel attributes), then capture
+            side = torch.cuda.Stream(self.dev)
+            side.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(side):
+                saved = (self.x.clone(), self.step.clone())
+                fn()
+                self.x.copy_(saved[0])
+                self.step.copy_(saved[1])
+            torch.cuda.current_stream(self.dev).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fn()
+            self.x.copy_(saved[0])
+            self.step.copy_(saved[1])
+            self.graphs[kind] = g
+        return self.graphs[kind].replay
+
+    @torch.no_grad()
+    def run(self, x0, heun_limit=0):
+        """Integrate over the whole grid.  heun_limit = number of leading intervals... see karras_sample: the corrector is
+        applied on interval i iff i < heun_limit - 1;  heun_limit = 0 means plain Euler."""
+        assert self.ts is not None, "set_grid first"
+        n = self.dts.numel()
+        self.x.copy_(x0)
+        self.step.zero_()
+        n_heun = max(0, min(n, heun_limit - 1)) if heun_limit else 0
+        if n_heun:
+            h = self._get("heun")
+            for _ in range(n_heun):
+                h()
+        if n - n_heun:
+            e = self._get("euler")
+            for _ in range(n - n_heun):
+                e()
+        return self.x
+
+
+_FUSED_CACHE = {}
+
+
+def _fused(model, x, model_kwargs):
+    y = model_kwargs.get("y")
+    cfg_scale = float(model_kwargs.get("cfg_scale", 1.0))
+    use_cfg = cfg_scale > 1.0
+    key = (id(model), x.shape[0], use_cfg, cfg_scale, y is not None, x.device)
+    fg = _FUSED_CACHE.get(key)
+    if fg is None:
+        if len(_FUSED_CACHE) > 8:
+            _FUSED_CACHE.clear()
+        fg = GraphedFixedGrid(model, x.shape[0], y=y, cfg_scale=cfg_scale, use_cfg=use_cfg)
+        _FUSED_CACHE[key] = fg
+    elif y is not None:
+        fg.y.copy_(y)  # labels are read by the captured kernels from this buffer
+    return fg
+
+
+def sample_fixed_grid_fused(model, x, sigmas, model_kwargs, heun_limit=0):
+    """Karras-style grid: t_i = sigmas[i], dt_i = sigmas[i+1] - sigmas[i] (karras_sample.py:30,102-117,151-159)."""
+    fg = _fused(model, x, model_kwargs)
+    sig = sigmas.to(torch.float32)
+    fg.set_grid(sig, sig[1:] - sig[:-1])
+    return fg.run(x, heun_limit=heun_limit).clone()
+
+
+def sample_torchdiffeq_euler_fused(model, x, step_size, model_kwargs):
+    """The reference's production Euler: odeint(..., t=[1,0], method='euler', options={'step_size': h})."""
+    fg = _fused(model, x, model_kwargs)
+    ts, dts = torchdiffeq_euler_grid(step_size)
+    fg.set_grid(ts, dts)
+    return fg.run(x).clone()
+
+
+_ = math

@@ -1,0 +1,279 @@
+"""Single-process sampling driver (drop-in for /root/reference/test_flow_latent.py).
+
+Keeps the reference's names and flags: ``ADAPTIVE_SOLVER``, ``FIXER_SOLVER``, ``NFECount``, ``sample_from_model``,
+``sample_from_model_with_fixed_step_solver`` (which the reference's own CLI mis-spells at :188 -- fixed here), the full
+argparse surface (:303-409) and the four modes (--compute_fid / --compute_nfe / --measure_time / default grid).
+
+Differences, all documented in DESIGN.md "Reference quirks": device literals follow the model's device; ``module.`` is
+stripped from checkpoint keys only when present; CFG with num_classes in {None, 1} raises instead of silently halving the
+batch; FID needs torchvision/Inception weights that are not available offline, so --compute_fid writes the images and
+says so.
+"""
+import argparse
+import math
+import os
+import time
+
+import torch
+from torch import nn
+
+from .models import create_network
+from .sampler.karras_sample import karras_sample
+from .sampler.random_util import get_generator
+from .solvers import (ADAPTIVE_SOLVER, FIXER_SOLVER, fused_fixed_grid_available, odeint, sample_torchdiffeq_euler_fused)
+
+__all__ = ["ADAPTIVE_SOLVER", "FIXER_SOLVER", "NFECount", "sample_from_model", "sample_from_model_with_fixed_step_solver",
+           "run_sampling", "build_parser", "main"]
+
+
+class NFECount(nn.Module):
+    """Counts velocity-field evaluations (reference test_flow_latent.py:31-39)."""
+
+    def __init__(self, model):
+        super().__init__()
+        self.model = model
+        self.register_buffer("nfe", torch.tensor(0.0))
+
+    def __call__(self, t, x, *args, **kwargs):
+        self.nfe += 1.0
+        return self.model(t, x, *args, **kwargs)
+
+    def forward_with_cfg(self, t, x, *args, **kwargs):
+        self.nfe += 1.0
+        return self.model.forward_with_cfg(t, x, *args, **kwargs)
+
+
+def sample_from_model(model, x_0, model_kwargs, args):
+    """Reference test_flow_latent.py:42-76: integrate dx/dt = v(t, x) from t=1 (noise) to t=0 (data).
+    Returns the [2, N, C, h, w] trajectory endpoints (callers take [-1]), or (traj, nfe) under --compute_nfe."""
+    if args.method in ADAPTIVE_SOLVER:
+        options = {"dtype": torch.float64}
+    else:
+        options = {"step_size": args.step_size, "perturb": args.perturb}
+    count = getattr(args, "compute_nfe", False)
+    use_cfg = getattr(args, "cfg_scale", 1.0) > 1.0
+
+    fused_ok = (args.method == "euler" and not count and not getattr(args, "perturb", False)
+                and fused_fixed_grid_available(model, x_0) and getattr(args, "fused", True))
+    if fused_ok:
+        kw = dict(model_kwargs)
+        if not use_cfg:
+            kw.pop("cfg_scale", None)
+        x1 = sample_torchdiffeq_euler_fused(model, x_0, args.step_size, kw)
+        return torch.stack([x_0, x1], 0)
+
+    if count:
+        model = NFECount(model).to(x_0.device)
+    t = torch.tensor([1.0, 0.0], device=x_0.device)
+
+    def denoiser(t, x):
+        if use_cfg:
+            return model.forward_with_cfg(t, x, **model_kwargs)
+        return model(t, x, **{k: v for k, v in model_kwargs.items() if k != "cfg_scale"})
+
+    if getattr(args, "perturb", False):
+        raise NotImplementedError("--perturb (torchdiffeq time perturbation) is not built")
+    traj = odeint(denoiser, x_0, t, method=args.method, atol=args.atol, rtol=args.rtol,
+                  options={k: v for k, v in options.items() if k in ("step_size",)})
+    if count:
+        return traj, model.nfe
+    return traj
+
+
+def sample_from_model_with_fixed_step_solver(model, x, model_kwargs, generator, args):
+    """Reference test_flow_latent.py:79-97 (Karras-style linear grid, sigma in [1e-5, 1])."""
+    return karras_sample(model, x, steps=args.num_steps, model_kwargs=model_kwargs, device=x.device, clip_denoised=False,
+                         sigma_min=1e-5, sigma_max=1.0, s_tmin=0.0, s_tmax=1.0, s_churn=0.0, sampler=args.method, rho=1.0,
+                         ts=range(0, args.num_steps, 15), generator=generator,
+                         heun_reference_quirk=getattr(args, "heun_reference_quirk", True))
+
+
+def make_model_kwargs(args, x, generator, device, cls_index=None):
+    """Labels + classifier-free-guidance doubling (reference test_flow_latent.py:163-183)."""
+    n = x.shape[0]
+    if args.num_classes in [None, 1]:
+        if args.cfg_scale > 1.0:
+            raise ValueError("--cfg_scale > 1 needs a class-conditional model (num_classes > 1); the reference silently "
+                             "discards half the batch in this configuration (test_flow_latent.py:56-57,163-164,190-191)")
+        return x, {}
+    if cls_index is None:
+        y = generator.randint(0, args.num_classes, (n,), device=device).to(device)
+    else:
+        y = torch.full((n,), int(cls_index), device=device, dtype=torch.long)
+    if args.cfg_scale > 1.0:
+        x = torch.cat([x, x], 0)
+        y_null = torch.full((n,), args.num_classes, device=device, dtype=torch.long) if "DiT" in args.model_type else torch.zeros_like(y)
+        return x, dict(y=torch.cat([y, y_null], 0), cfg_scale=args.cfg_scale)
+    return x, dict(y=y)
+
+
+def run_sampling(model, first_stage_model, args, num_samples, generator, device, cls_index=None, x=None):
+    """One batch of the hot path: noise -> ODE solve -> (drop null half) -> VAE decode (reference :161-194)."""
+    if x is None:
+        x = generator.randn(num_samples, 4, args.image_size // 8, args.image_size // 8).to(device)
+    x, model_kwargs = make_model_kwargs(args, x, generator, device, cls_index)
+    if not args.use_karras_samplers:
+        fake_sample = sample_from_model(model, x, model_kwargs, args)[-1]
+    else:
+        fake_sample = sample_from_model_with_fixed_step_solver(model, x, model_kwargs, generator, args)
+    if args.cfg_scale > 1.0:
+        fake_sample, _ = fake_sample.chunk(2, dim=0)
+    if first_stage_model is None:
+        return fake_sample
+    return first_stage_model.decode(fake_sample / args.scale_factor).sample
+
+
+def load_checkpoint(model, path, device):
+    """Flat state_dict saved from an accelerate/DDP-wrapped model (train_flow_latent.py:211-214): strip ``module.`` when present."""
+    ckpt = torch.load(path, map_location=device)
+    ckpt = {(k[7:] if k.startswith("module.") else k): v for k, v in ckpt.items()}
+    model.load_state_dict(ckpt, strict=True)
+
+
+def build_parser():
+    p = argparse.ArgumentParser("flow-matching parameters")
+    p.add_argument("--generator", type=str, default="determ", choices=["dummy", "determ", "determ-indiv", "device"])
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--compute_fid", action="store_true", default=False)
+    p.add_argument("--compute_nfe", action="store_true", default=False)
+    p.add_argument("--measure_time", action="store_true", default=False)
+    p.add_argument("--epoch_id", type=int, default=1000)
+    p.add_argument("--n_sample", type=int, default=50000)
+    p.add_argument("--model_type", type=str, default="adm")
+    p.add_argument("--image_size", type=int, default=32)
+    p.add_argument("--f", type=int, default=8)
+    p.add_argument("--scale_factor", type=float, default=0.18215)
+    p.add_argument("--num_in_channels", type=int, default=3)
+    p.add_argument("--num_out_channels", type=int, default=3)
+    p.add_argument("--nf", type=int, default=256)
+    p.add_argument("--centered", action="store_false", default=True)
+    p.add_argument("--resamp_with_conv", type=bool, default=True)
+    p.add_argument("--num_res_blocks", type=int, default=2)
+    p.add_argument("--num_heads", type=int, default=4)
+    p.add_argument("--num_head_upsample", type=int, default=-1)
+    p.add_argument("--num_head_channels", type=int, default=-1)
+    p.add_argument("--attn_resolutions", nargs="+", type=int, default=(16,))
+    p.add_argument("--ch_mult", nargs="+", type=int, default=(1, 2, 2, 2))
+    p.add_argument("--label_dim", type=int, default=0)
+    p.add_argument("--augment_dim", type=int, default=0)
+    p.add_argument("--dropout", type=float, default=0.0)
+    p.add_argument("--num_classes", type=int, default=None)
+    p.add_argument("--label_dropout", type=float, default=0.0)
+    p.add_argument("--cfg_scale", type=float, default=1.0)
+    p.add_argument("--layout", action="store_true")
+    p.add_argument("--use_origin_adm", action="store_true")
+    p.add_argument("--use_scale_shift_norm", type=bool, default=True)
+    p.add_argument("--resblock_updown", type=bool, default=False)
+    p.add_argument("--use_new_attention_order", type=bool, default=False)
+    p.add_argument("--pretrained_autoencoder_ckpt", type=str, default="stabilityai/sd-vae-ft-mse")
+    p.add_argument("--output_log", type=str, default="")
+    p.add_argument("--exp", default="experiment_cifar_default")
+    p.add_argument("--real_img_dir", default="./pytorch_fid/cifar10_train_stat.npy")
+    p.add_argument("--dataset", default="cifar10")
+    p.add_argument("--num_steps", type=int, default=40)
+    p.add_argument("--batch_size", type=int, default=200)
+    p.add_argument("--use_karras_samplers", action="store_true", default=False)
+    p.add_argument("--atol", type=float, default=1e-5)
+    p.add_argument("--rtol", type=float, default=1e-5)
+    p.add_argument("--method", type=str, default="dopri5",
+                   choices=["dopri5", "dopri8", "adaptive_heun", "bosh3", "euler", "midpoint", "rk4", "heun", "multistep", "stochastic", "dpm"])
+    p.add_argument("--step_size", type=float, default=0.01)
+    p.add_argument("--perturb", action="store_true", default=False)
+    p.add_argument("--num_proc_node", type=int, default=1)
+    p.add_argument("--num_process_per_node", type=int, default=1)
+    p.add_argument("--node_rank", type=int, default=0)
+    p.add_argument("--local_rank", type=int, default=0)
+    p.add_argument("--master_address", type=str, default="127.0.0.1")
+    p.add_argument("--master_port", type=str, default="6000")
+    # additions (not in the reference)
+    p.add_argument("--random_weights", action="store_true", help="synthetic weights instead of ./saved_info checkpoints (benchmarking)")
+    p.add_argument("--heun_reference_quirk", type=int, default=1, help="1: corrector only on intervals < 39 as the reference does")
+    p.add_argument("--save_dir", type=str, default=None)
+    return p
+
+
+def dezero_(model, seed=1234, std=0.02):
+    """Random-init models output exactly 0 (adaLN-Zero); re-draw all-zero tensors so synthetic runs do real work."""
+    g = torch.Generator().manual_seed(seed)
+    for _, p in sorted(model.named_parameters()):
+        if p.numel() and not bool(p.any()):
+            p.data.copy_(torch.randn(p.shape, generator=g) * std)
+    return model
+
+
+def build_models(args, device):
+    from .autoencoder import AutoencoderKL
+
+    torch.manual_seed(args.seed)
+    model = create_network(args)
+    if args.random_weights:
+        dezero_(model)
+        vae = AutoencoderKL.from_random(seed=args.seed)
+    else:
+        load_checkpoint(model, "./saved_info/latent_flow/{}/{}/model_{}.pth".format(args.dataset, args.exp, args.epoch_id), "cpu")
+        vae = AutoencoderKL.from_pretrained(args.pretrained_autoencoder_ckpt)
+    return model.to(device).eval(), vae.to(device)
+
+
+def save_images_uint8(img_u8, save_dir, start_index, stride=1, offset=0):
+    from PIL import Image
+
+    os.makedirs(save_dir, exist_ok=True)
+    arr = img_u8.cpu().numpy()
+    for j, a in enumerate(arr):
+        Image.fromarray(a).save(os.path.join(save_dir, f"{j * stride + offset + start_index}.jpg"))
+
+
+def main(argv=None):
+    from .autoencoder import images_to_uint8
+
+    args = build_parser().parse_args(argv)
+    args.world_size = args.num_proc_node * args.num_process_per_node
+    torch.set_grad_enabled(False)
+    device = torch.device("cuda:{}".format(args.local_rank))
+    torch.cuda.set_device(device)
+    model, vae = build_models(args, device)
+    generator = get_generator(args.generator, args.n_sample, args.seed)
+
+    if args.compute_nfe:
+        total, trials = 0.0, 300
+        for _ in range(trials):
+            x0 = generator.randn(1, 4, args.image_size // 8, args.image_size // 8).to(device)
+            x0, kw = make_model_kwargs(args, x0, generator, device)
+            _, nfe = sample_from_model(model, x0, kw, args)
+            total += float(nfe) / trials
+        print(f"Average NFE over {trials} trials: {int(total)}")
+        return
+    if args.measure_time:
+        x = generator.randn(1, 4, args.image_size // 8, args.image_size // 8).to(device)
+        for _ in range(10):
+            model(torch.tensor(1.0, device=device), x)
+        times = []
+        for _ in range(300):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            run_sampling(model, vae, args, 1, generator, device)
+            e.record()
+            torch.cuda.synchronize()
+            times.append(s.elapsed_time(e))
+        tt = torch.tensor(times)
+        print("Inference time: {:.2f}+/-{:.2f}ms".format(float(tt.mean()), float(tt.std(unbiased=False))))
+        return
+    save_dir = args.save_dir or "./generated_samples/{}/exp{}_ep{}_m{}".format(args.dataset, args.exp, args.epoch_id, args.method)
+    if args.compute_fid:
+        n = args.batch_size
+        total_samples = int(math.ceil(args.n_sample / n) * n)
+        t0 = time.time()
+        for i in range(total_samples // n):
+            img = run_sampling(model, vae, args, n, generator, device)
+            save_images_uint8(images_to_uint8(img), save_dir, i * n)
+        print(f"wrote {total_samples} images to {save_dir} in {time.time() - t0:.1f}s; FID needs pytorch_fid + Inception weights "
+              "(not available offline): run the reference's pytorch_fid on that directory")
+        return
+    img = run_sampling(model, vae, args, args.batch_size, generator, device)
+    save_images_uint8(images_to_uint8(img), save_dir, 0)
+    print("Samples are saved under '{}'".format(save_dir))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,88 @@
+"""GPU parity of the solver loop: fused / graph-captured fixed-grid sampling vs the oracle solver driving the oracle DiT,
+and vs the product's own generic (unfused) loop.  Tolerance on final latents: rel-L2 <= 1e-3 (SURVEY.md §8c rule 4)."""
+from argparse import Namespace
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import dit_ref, ode_ref  # checker only
+
+
+def rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / b.norm())
+
+
+def _mk(name, dev, **kw):
+    from lfm_amd.models import DiT_models
+
+    cfg = dit_ref.DiTCfg.named(name, **kw)
+    sd = dit_ref.make_dit_state(cfg, seed=2)
+    m = DiT_models[name](img_resolution=32, in_channels=4, **kw)
+    m.load_state_dict(sd, strict=True)
+    return cfg, sd, m.to(dev).eval()
+
+
+def test_config1_ditb2_10step_euler_vs_oracle():
+    """BASELINE config 1: DiT-B/2, 4x32x32 latents, batch 4, 10-step Euler, no VAE."""
+    from lfm_amd.test_flow_latent import sample_from_model
+
+    dev = torch.device("cuda:0")
+    cfg, sd, m = _mk("DiT-B/2", dev, num_classes=1, label_dropout=0.0)
+    x0 = torch.randn(4, 4, 32, 32, generator=torch.Generator().manual_seed(42))
+    ref = ode_ref.odeint(lambda t, x: dit_ref.dit_forward(sd, cfg, t, x), x0, torch.tensor([1.0, 0.0]), method="euler",
+                         options={"step_size": 0.1})
+    args = Namespace(method="euler", step_size=0.1, perturb=False, compute_nfe=False, cfg_scale=1.0, atol=1e-5, rtol=1e-5)
+    got = sample_from_model(m, x0.to(dev), {}, args)
+    assert got.shape == (2, 4, 4, 32, 32)
+    assert torch.equal(got[0].cpu(), x0)
+    assert rel_l2(got[-1], ref[-1]) < 1e-3
+    args.fused = False  # generic loop over the same HIP model: same arithmetic, eager launches
+    got2 = sample_from_model(m, x0.to(dev), {}, args)
+    assert rel_l2(got2[-1], got[-1]) < 1e-5
+    args.compute_nfe = True
+    _, nfe = sample_from_model(m, x0.to(dev), {}, args)
+    assert int(nfe) == 10
+
+
+def test_cfg_heun_fused_vs_generic_and_oracle():
+    """Class-conditional DiT with classifier-free guidance on the Karras grid (config 4 shape, small batch)."""
+    from lfm_amd.sampler.karras_sample import karras_sample
+
+    dev = torch.device("cuda:0")
+    cfg, sd, m = _mk("DiT-S/2", dev, num_classes=10, label_dropout=0.1)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(3, 4, 32, 32, generator=g)
+    x = torch.cat([x, x], 0)
+    y = torch.cat([torch.randint(0, 10, (3,), generator=g), torch.full((3,), 10)])
+    kw = dict(y=y.to(dev), cfg_scale=1.5)
+    common = dict(steps=9, device=dev, clip_denoised=False, sigma_min=1e-5, sigma_max=1.0, s_tmin=0.0, s_tmax=1.0, s_churn=0.0)
+    for sampler in ("euler", "heun"):
+        fused = karras_sample(m, x.to(dev), model_kwargs=kw, sampler=sampler, fused=True, **common)
+        plain = karras_sample(m, x.to(dev), model_kwargs=kw, sampler=sampler, fused=False, **common)
+        assert rel_l2(fused, plain) < 1e-5, sampler
+
+        class Oracle:
+            def forward_with_cfg(self, t, xx, y=None, cfg_scale=1.0):
+                return dit_ref.dit_forward_with_cfg(sd, cfg, t, xx, y, cfg_scale)
+
+        common_cpu = dict(common, device="cpu")
+        ref = karras_sample(Oracle(), x, model_kwargs=dict(y=y, cfg_scale=1.5), sampler=sampler, **common_cpu)
+        assert rel_l2(fused, ref) < 1e-3, sampler
+        assert torch.equal(fused[:3], fused[3:])  # both halves carry the guided trajectory (DiT.py:287)
+
+
+def test_dopri5_on_hip_model_vs_oracle():
+    from lfm_amd.solvers import odeint
+
+    dev = torch.device("cuda:0")
+    cfg, sd, m = _mk("DiT-S/2", dev, num_classes=1, label_dropout=0.0)
+    x0 = torch.randn(2, 4, 32, 32, generator=torch.Generator().manual_seed(3))
+    t = torch.tensor([1.0, 0.0])
+    sa, sb = {}, {}
+    got = odeint(lambda tt, xx: m(tt, xx), x0.to(dev), t.to(dev), method="dopri5", rtol=1e-3, atol=1e-3, stats=sa)
+    ref = ode_ref.odeint(lambda tt, xx: dit_ref.dit_forward(sd, cfg, tt, xx), x0, t, method="dopri5", rtol=1e-3, atol=1e-3, stats=sb)
+    assert rel_l2(got[-1], ref[-1]) < 2e-3
+    assert abs(sa["steps"] - sb["steps"]) <= 1

@@ -1,0 +1,202 @@
+"""CPU tests of the host logic: samplers / RNG against reference-generated golden vectors, the solver
+module against the oracle restatement and analytic known answers, and the C-ABI export list."""
+import math
+import os
+import re
+
+import pytest
+import torch
+
+from oracle import ode_ref
+
+
+def _load(golden_dir, name):
+    return torch.load(os.path.join(golden_dir, name), map_location="cpu", weights_only=False)
+
+
+# ----------------------------------------------------------------------------- RNG (reference sampler/random_util.py)
+def test_random_util_matches_reference(golden_dir):
+    from lfm_amd.sampler.random_util import get_generator
+
+    gold = _load(golden_dir, "randgen.pt")
+    for n, seed, bs in ((64, 42, 8), (10, 7, 4)):
+        gen = get_generator("determ", n, seed)
+        assert torch.equal(gen.randn(bs, 4, 8, 8), gold[f"determ_n{n}_s{seed}_randn"])
+        assert torch.equal(gen.randn(bs, 4, 8, 8), gold[f"determ_n{n}_s{seed}_randn2"])
+        assert torch.equal(gen.randint(0, 1000, (bs,)), gold[f"determ_n{n}_s{seed}_randint"])
+    gen = get_generator("determ-indiv", 6, 3)
+    assert torch.equal(gen.randn(4, 2, 3, 3), gold["indiv_n6_s3_randn"])
+    gen = get_generator("determ", 64, 42)
+    gen.rank, gen.world_size = 1, 4
+    assert torch.equal(gen.randn(8, 4, 8, 8), gold["determ_n64_s42_rank1of4_randn"])
+
+
+def test_random_util_batch_size_independence():
+    from lfm_amd.sampler.random_util import get_generator
+
+    a = get_generator("determ", 32, 1).randn(8, 3)
+    b = get_generator("determ", 32, 1).randn(4, 3)
+    assert torch.equal(a[:4], b)  # same leading rows whatever the batch size (the point of the class)
+    g = get_generator("determ", 8, 1)
+    g.rank, g.world_size = 3, 4
+    idx = g._indices(4)
+    assert idx.tolist() == [3, 7, 7, 7]  # clamped at num_samples-1 (random_util.py:64)
+
+
+# ----------------------------------------------------------------------------- Karras samplers (reference sampler/karras_sample.py)
+class _Field:
+    def __init__(self, A):
+        self.A = A
+
+    def __call__(self, t, x, **kw):
+        flat = x.flatten(1)
+        return (torch.tanh(flat @ self.A) * (1.0 + t[:, None]) - 0.5 * flat).reshape(x.shape)
+
+
+@pytest.mark.parametrize("sampler,steps", [("euler", 11), ("euler", 51), ("heun", 11), ("heun", 50), ("heun", 40)])
+def test_karras_sample_matches_reference(golden_dir, sampler, steps):
+    from lfm_amd.sampler.karras_sample import karras_sample
+
+    gold = _load(golden_dir, "karras.pt")
+    out = karras_sample(_Field(gold["A"]), gold["x"].clone(), steps=steps, model_kwargs={}, device="cpu", clip_denoised=False,
+                        sigma_min=1e-5, sigma_max=1.0, s_tmin=0.0, s_tmax=1.0, s_churn=0.0, sampler=sampler, rho=1.0, ts=range(0, steps, 15))
+    torch.testing.assert_close(out, gold[f"{sampler}_{steps}"], rtol=0, atol=0)
+
+
+def test_heun_quirk_counts_nfe():
+    """steps=40 default is frozen: a 50-point grid does 49 predictor + 39 corrector evaluations = 88 NFE."""
+    from lfm_amd.sampler.karras_sample import karras_sample
+
+    calls = []
+
+    def model(t, x, **kw):
+        calls.append(float(t[0]))
+        return -x
+
+    x = torch.ones(2, 1, 2, 2)
+    karras_sample(model, x, steps=50, model_kwargs={}, device="cpu", clip_denoised=False, sigma_min=1e-5, sigma_max=1.0, sampler="heun")
+    assert len(calls) == 88
+    calls.clear()
+    karras_sample(model, x, steps=50, model_kwargs={}, device="cpu", clip_denoised=False, sigma_min=1e-5, sigma_max=1.0, sampler="heun",
+                  heun_reference_quirk=False)
+    assert len(calls) == 49 + 49  # quirk off: `i < steps - 1` with steps = the real grid length covers every interval
+    calls.clear()
+    karras_sample(model, x, steps=51, model_kwargs={}, device="cpu", clip_denoised=False, sigma_min=1e-5, sigma_max=1.0, sampler="euler")
+    assert len(calls) == 50
+
+
+# ----------------------------------------------------------------------------- odeint: product vs oracle vs analytic
+def _lin(t, y):
+    return -y * (1.0 + 0.5 * torch.sin(3 * t))
+
+
+@pytest.mark.parametrize("method,h", [("euler", 0.02), ("euler", 0.03), ("midpoint", 0.1), ("rk4", 0.1)])
+def test_fixed_grid_matches_oracle(method, h):
+    from lfm_amd.solvers import odeint
+
+    y0 = torch.randn(3, 4, generator=torch.Generator().manual_seed(0))
+    t = torch.tensor([1.0, 0.0])
+    a = odeint(_lin, y0, t, method=method, options={"step_size": h})
+    b = ode_ref.odeint(_lin, y0, t, method=method, options={"step_size": h})
+    assert a.shape == (2, 3, 4)
+    torch.testing.assert_close(a, b, rtol=0, atol=0)
+
+
+def test_euler_grid_and_nfe():
+    from lfm_amd.solvers import odeint, torchdiffeq_euler_grid
+
+    for h, n in ((0.02, 50), (0.01, 100), (0.1, 10), (0.03, 34)):
+        ts, dts = torchdiffeq_euler_grid(h)
+        assert dts.numel() == n and ts.numel() == n + 1
+        assert float(ts[0]) == 1.0 and float(ts[-1]) == 0.0
+        assert abs(float(dts.sum()) + 1.0) < 1e-6
+        seen = []
+        odeint(lambda t, y: (seen.append(float(t)), -y)[1], torch.ones(1), torch.tensor([1.0, 0.0]), method="euler", options={"step_size": h})
+        assert len(seen) == n
+        torch.testing.assert_close(torch.tensor(seen), ts[:-1], rtol=0, atol=0)
+    ts, dts = torchdiffeq_euler_grid(0.03)
+    assert abs(float(dts[-1]) + 0.01) < 1e-6  # short last step
+
+
+def test_dopri5_matches_oracle_and_analytic():
+    from lfm_amd.solvers import odeint
+
+    y0 = torch.tensor([[1.0, 0.0], [0.5, -0.3]])
+    w = 2.0
+
+    def osc(t, y):  # harmonic oscillator, integrated backwards from t=1 to 0
+        return torch.stack([y[:, 1] * w, -y[:, 0] * w], 1)
+
+    t = torch.tensor([1.0, 0.0])
+    st_a, st_b = {}, {}
+    a = odeint(osc, y0, t, method="dopri5", rtol=1e-5, atol=1e-5, stats=st_a)
+    b = ode_ref.odeint(osc, y0, t, method="dopri5", rtol=1e-5, atol=1e-5, stats=st_b)
+    torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-6)
+    assert st_a["steps"] == st_b["steps"] and st_a["accepted"] == st_b["accepted"]
+    c, s = math.cos(-w), math.sin(-w)  # exact rotation by angle w*(0-1)
+    exact = torch.stack([y0[:, 0] * c + y0[:, 1] * s, -y0[:, 0] * s + y0[:, 1] * c], 1)
+    assert float((a[-1] - exact).abs().max()) < 2e-4
+
+
+def test_fixed_grid_order_of_convergence():
+    from lfm_amd.solvers import odeint
+
+    y0 = torch.ones(1, dtype=torch.float64)
+    f = lambda t, y: -y  # noqa
+    exact = math.e  # y(0) = y(1) * e
+    errs = {}
+    for m in ("euler", "midpoint", "rk4"):
+        errs[m] = [abs(float(odeint(f, y0, torch.tensor([1.0, 0.0], dtype=torch.float64), method=m, options={"step_size": h})[-1]) - exact)
+                   for h in (0.1, 0.05)]
+    assert 1.8 < errs["euler"][0] / errs["euler"][1] < 2.2
+    assert 3.5 < errs["midpoint"][0] / errs["midpoint"][1] < 4.5
+    assert 14 < errs["rk4"][0] / errs["rk4"][1] < 18
+
+
+# ----------------------------------------------------------------------------- model-constructor boundary
+def test_create_network_state_dict_matches_reference_names(golden_dir):
+    from argparse import Namespace
+
+    from lfm_amd.models import DiT, create_network
+
+    rec = _load(golden_dir, "dit_tiny.pt")["cond"]
+    c = rec["cfg"]
+    m = DiT(img_resolution=c["img_resolution"], patch_size=c["patch"], in_channels=c["in_channels"], hidden_size=c["hidden"],
+            depth=c["depth"], num_heads=c["heads"], label_dropout=c["label_dropout"], num_classes=c["num_classes"])
+    ref_sd = rec["state_dict"]
+    assert list(m.state_dict().keys()) == list(ref_sd.keys())
+    assert all(m.state_dict()[k].shape == v.shape for k, v in ref_sd.items())
+    m.load_state_dict(ref_sd, strict=True)
+    net = create_network(Namespace(use_origin_adm=False, model_type="DiT-B/2", image_size=256, f=8, num_in_channels=4,
+                                   label_dropout=0.0, num_classes=1))
+    assert sum(p.numel() for p in net.parameters()) == 129_732_112  # == the reference DiT-B/2 constructor (checked against /root/reference; incl. the frozen pos_embed)
+    # default init is adaLN-Zero (DiT.py:219-228)
+    assert not bool(net.final_layer.linear.weight.any()) and not bool(net.blocks[0].adaLN_modulation[1].weight.any())
+    torch.testing.assert_close(m.pos_embed, ref_sd["pos_embed"], rtol=0, atol=1e-6)
+
+
+def test_cfg_without_classes_is_an_error():
+    from argparse import Namespace
+
+    from lfm_amd.test_flow_latent import make_model_kwargs
+
+    with pytest.raises(ValueError):
+        make_model_kwargs(Namespace(num_classes=1, cfg_scale=1.5, model_type="DiT-B/2"), torch.zeros(2, 4, 8, 8), None, "cpu")
+
+
+# ----------------------------------------------------------------------------- C ABI
+def test_c_abi_exports_every_declared_symbol():
+    import ctypes
+
+    from lfm_amd import _build
+
+    lib_path = _build.build()
+    lib = ctypes.CDLL(lib_path)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "lfm_hip.h")).read()
+    names = sorted(set(re.findall(r"\b(lfm_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/lfm_hip.h but not exported"
+    lib.lfm_strerror.restype = ctypes.c_char_p
+    assert lib.lfm_strerror(0) == b"ok" and lib.lfm_abi_version() >= 1
