@@ -193,7 +193,7 @@ def main():
         dur = e0.elapsed_time(e1) / n * 1e-3
         ach = 2.0 * M * H * D / dur / 1e12
         res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
-                           "traffic": None, "kernel": "gemm_tn_kernel<ASrcRowMajor,EpiBiasGeluF16> (DiT fc1 + GELU)",
+                           "traffic": None, "kernel": "gemm256_tn_kernel<ASrcRowMajor,EpiBiasGeluF16> (DiT fc1 + GELU)",
                            "shape": {"M": M, "N": H, "K": D}, "avg_launch_us": dur * 1e6}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(a.model, a.nfe)

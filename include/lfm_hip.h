@@ -104,6 +104,10 @@ int lfm_dit_forward(const lfm_dit_shape* shape, const lfm_dit_weights* w, void* 
 int lfm_gemm_f16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N, int K, const float* bias,
                  int epilogue, const float* gate, long gate_stride, int tokens, lfm_stream_t stream);
 
+/* Kernel selection for the GEMMs: 0 = automatic (256x256 ping-pong kernel for chip-filling shapes, 128x128 otherwise),
+ * 1 = force the 128x128 kernel, 2 = force the 256x256 kernel.  For A/B measurement and parity tests. */
+int lfm_gemm_select(int which);
+
 /* A fp16 [M,D] = LayerNorm(X fp32 [M,D], eps 1e-6, no affine) * (1 + scale[img]) + shift[img]
  * (models/DiT.py:20-21,119,121,129-130).  mod_stride = floats between images' rows (0 = shared). */
 int lfm_ln_modulate(const float* X, void* A, int M, int D, int tokens, const float* shift, const float* scale, long mod_stride,

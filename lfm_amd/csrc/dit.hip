@@ -1,40 +1,49 @@
 // DiT velocity field on gfx950: the kernels around the MFMA GEMMs and the per-call driver.
 // Reference behaviour: /root/reference/models/DiT.py (cited per kernel).
 #include "../../include/lfm_hip.h"
-#include "gemm_kernel.h"
+#include "gemm256_kernel.h"
+
+static int g_gemm_sel = 0;
+int lfm_gemm_selected() { return g_gemm_sel; }
+static int g_gemm_dbg = 0;
+int lfm_gemm_debug_flags() { return g_gemm_dbg; }
+extern "C" int lfm_gemm_select(int which) {  // low 2 bits: kernel choice; bits 4,5: ablation flags (measurement only)
+  if ((which & 15) > 2 || which < 0) return LFM_ERR_ARG;
+  g_gemm_sel = which & 15;
+  g_gemm_dbg = which >> 4;
+  return LFM_OK;
+}
 
 // ------------------------------------------------------------------ timestep embedder (DiT.py:29-69)
-// temb[r] = W2 * silu(W0 * [cos(t f) | sin(t f)] + b0) + b2, one block per row, fp32 throughout.
-__global__ __launch_bounds__(256) void temb_kernel(const float* __restrict__ t, const float* __restrict__ w0, const float* __restrict__ b0,
-                                                   const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ temb,
-                                                   int D) {
-  __shared__ float emb[256];
-  extern __shared__ float h1[];  // [D]
-  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// temb[r] = W2 * silu(W0 * [cos(t f) | sin(t f)] + b0) + b2, fp32 throughout; one wave per output element.
+__global__ __launch_bounds__(256) void temb1_kernel(const float* __restrict__ t, const float* __restrict__ w0, const float* __restrict__ b0,
+                                                    float* __restrict__ h1, int D) {
+  const int r = blockIdx.y, lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= D) return;
   const float tv = t[r];
-  {
-    const int i = tid & 127;
-    const float f = __expf(-9.210340371976184f * (float)i / 128.0f);  // exp(-ln(1e4) i/half)
-    const float a = tv * f;
-    emb[tid] = (tid < 128) ? cosf(a) : sinf(a);
-  }
-  __syncthreads();
-  for (int j = wave; j < D; j += 4) {
-    const float* w = w0 + (long)j * 256;
-    float s = 0.f;
+  const float* w = w0 + (long)j * 256;
+  float s = 0.f;
 #pragma unroll
-    for (int k = lane; k < 256; k += 64) s += w[k] * emb[k];
-    s = wave_sum(s);
-    if (lane == 0) h1[j] = silu_f(s + b0[j]);
+  for (int k = lane; k < 256; k += 64) {
+    const int i = k & 127;
+    const float a = tv * __expf(-9.210340371976184f * (float)i / 128.0f);  // t * exp(-ln(1e4) i/half)
+    s += w[k] * (k < 128 ? cosf(a) : sinf(a));
   }
-  __syncthreads();
-  for (int j = wave; j < D; j += 4) {
-    const float* w = w2 + (long)j * D;
-    float s = 0.f;
-    for (int k = lane; k < D; k += 64) s += w[k] * h1[k];
-    s = wave_sum(s);
-    if (lane == 0) temb[(long)r * D + j] = s + b2[j];
-  }
+  s = wave_sum(s);
+  if (lane == 0) h1[(long)r * D + j] = silu_f(s + b0[j]);
+}
+__global__ __launch_bounds__(256) void temb2_kernel(const float* __restrict__ h1, const float* __restrict__ w2, const float* __restrict__ b2,
+                                                    float* __restrict__ temb, int D) {
+  const int r = blockIdx.y, lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= D) return;
+  const float* w = w2 + (long)j * D;
+  const float* h = h1 + (long)r * D;
+  float s = 0.f;
+  for (int k = lane; k < D; k += 64) s += w[k] * h[k];
+  s = wave_sum(s);
+  if (lane == 0) temb[(long)r * D + j] = s + b2[j];
 }
 
 // c_half[r] = fp16(silu(temb[t_len==1 ? 0 : r] + y_table[y ? y[r] : null_row]))   (DiT.py:259-264 + the SiLU of :125)
@@ -49,30 +58,42 @@ __global__ void cond_kernel(const float* __restrict__ temb, int t_len, const flo
 }
 
 // ------------------------------------------------------------------ patch embed (timm PatchEmbed + pos_embed, DiT.py:179,261)
-// X[n*T + tok][j] = b[j] + pos[tok][j] + sum_{c,p,q} W[j][c][p][q] * x[n % xmod][c][hp+p][wp+q]; 4 outputs per thread.
-__global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
-                                                          const float* __restrict__ pos, float* __restrict__ X, int batch, int xmod, int C,
-                                                          int R, int p, int D) {
+// X[n*T + tok][j] = b[j] + pos[tok][j] + sum_{c,p,q} W[j][c][p][q] * x[n % xmod][c][hp+p][wp+q]
+// blockDim = D/4 threads, thread = 4 consecutive output channels whose weight rows stay in registers (KK <= 16 here);
+// a block walks PE_TOK tokens, whose KK input values are wave-uniform loads.
+#define PE_TOK 16
+#define PE_MAXK 16
+__global__ __launch_bounds__(320) void patch_embed_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                          const float* __restrict__ pos, float* __restrict__ X, int M, int xmod, int C, int R,
+                                                          int p, int D) {
   const int grid = R / p, T = grid * grid, KK = C * p * p;
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int d4 = D / 4;
-  if (idx >= (long)batch * T * d4) return;
-  const int j = (int)(idx % d4) * 4;
-  const long m = idx / d4;
-  const int tok = (int)(m % T), n = (int)(m / T) % xmod;
-  const int hp = (tok / grid) * p, wp = (tok % grid) * p;
-  f32x4 acc = *(const f32x4*)(b + j) + *(const f32x4*)(pos + (long)tok * D + j);
-  for (int c = 0; c < C; ++c)
-    for (int pp = 0; pp < p; ++pp)
-      for (int q = 0; q < p; ++q) {
+  const int j = threadIdx.x * 4;
+  float wr[4][PE_MAXK];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int k = 0; k < PE_MAXK; ++k) wr[i][k] = (k < KK) ? w[(long)(j + i) * KK + k] : 0.f;
+  const f32x4 bias = *(const f32x4*)(b + j);
+  const long m_begin = (long)blockIdx.x * PE_TOK;
+  for (int tt = 0; tt < PE_TOK; ++tt) {
+    const long m = m_begin + tt;
+    if (m >= M) break;
+    const int tok = (int)(m % T), n = (int)(m / T) % xmod;
+    const int hp = (tok / grid) * p, wp = (tok % grid) * p;
+    f32x4 acc = bias + *(const f32x4*)(pos + (long)tok * D + j);
+#pragma unroll
+    for (int k = 0; k < PE_MAXK; ++k) {
+      if (k < KK) {
+        const int c = k / (p * p), pp = (k / p) % p, q = k % p;
         const float xv = x[(((long)n * C + c) * R + hp + pp) * R + wp + q];
-        const int k = (c * p + pp) * p + q;
-        acc.x += w[(long)(j + 0) * KK + k] * xv;
-        acc.y += w[(long)(j + 1) * KK + k] * xv;
-        acc.z += w[(long)(j + 2) * KK + k] * xv;
-        acc.w += w[(long)(j + 3) * KK + k] * xv;
+        acc.x += wr[0][k] * xv;
+        acc.y += wr[1][k] * xv;
+        acc.z += wr[2][k] * xv;
+        acc.w += wr[3][k] * xv;
       }
-  *(f32x4*)(X + m * D + j) = acc;
+    }
+    *(f32x4*)(X + m * D + j) = acc;
+  }
 }
 
 // ------------------------------------------------------------------ LayerNorm + modulate -> fp16 (DiT.py:20-21,119,129-130)
@@ -373,6 +394,7 @@ struct DitWs {
   half_t* A;      // [M, D] LN output / attention output
   half_t* QKVH;   // max(3*M*D, M*H): Q | K | Vt, later the fc1 activation
   float* temb;    // [B, D]
+  float* temb_h;  // [B, D] hidden layer of the t-MLP
   half_t* c_half; // [B, D]
   float* mod;     // [B, J]
   size_t total;
@@ -394,6 +416,7 @@ static DitWs carve(const lfm_dit_shape* s, int B, void* ws) {
   const size_t qkvh = (3 * M * D > M * H ? 3 * M * D : M * H) * 2;
   w.QKVH = (half_t*)take(qkvh);
   w.temb = (float*)take((size_t)B * D * 4);
+  w.temb_h = (float*)take((size_t)B * D * 4);
   w.c_half = (half_t*)take((size_t)B * D * 2);
   w.mod = (float*)take((size_t)B * J * 4);
   w.total = off;
@@ -408,7 +431,7 @@ static int check_shape(const lfm_dit_shape* s) {
   const int T = (s->res / s->patch) * (s->res / s->patch);
   if (T != 64 && T != 128 && T != 256) return LFM_ERR_SHAPE;
   if (s->hidden % 64 || s->hidden > 256 * LN_MAXV || s->mlp_hidden % 64) return LFM_ERR_SHAPE;
-  if (s->patch * s->patch * s->in_ch > FIN_MAXO) return LFM_ERR_SHAPE;
+  if (s->patch * s->patch * s->in_ch > FIN_MAXO || s->patch * s->patch * s->in_ch > PE_MAXK) return LFM_ERR_SHAPE;
   if (s->label_rows <= 0) return LFM_ERR_SHAPE;
   return LFM_OK;
 }
@@ -485,14 +508,14 @@ extern "C" int lfm_gemm_f16(const void* A, long lda, const void* W, long ldw, vo
   hipStream_t st = (hipStream_t)stream;
   ASrcRowMajor a{(const half_t*)A, lda, M, 0};
   switch (epilogue) {
-    case 0: return launch_gemm_tn(a, (const half_t*)W, ldw, M, N, K, EpiBiasF16{(half_t*)C, ldc, bias}, st);
+    case 0: return launch_gemm_auto(a, (const half_t*)W, ldw, M, N, K, EpiBiasF16{(half_t*)C, ldc, bias}, st);
     case 1:
       if (!bias) return LFM_ERR_ARG;
-      return launch_gemm_tn(a, (const half_t*)W, ldw, M, N, K, EpiBiasGeluF16{(half_t*)C, ldc, bias}, st);
-    case 2: return launch_gemm_tn(a, (const half_t*)W, ldw, M, N, K, EpiBiasF32{(float*)C, ldc, bias}, st);
+      return launch_gemm_auto(a, (const half_t*)W, ldw, M, N, K, EpiBiasGeluF16{(half_t*)C, ldc, bias}, st);
+    case 2: return launch_gemm_auto(a, (const half_t*)W, ldw, M, N, K, EpiBiasF32{(float*)C, ldc, bias}, st);
     case 3:
       if (!bias || !gate || tokens <= 0) return LFM_ERR_ARG;
-      return launch_gemm_tn(a, (const half_t*)W, ldw, M, N, K, EpiGateResidF32{(float*)C, ldc, bias, gate, gate_stride, tokens}, st);
+      return launch_gemm_auto(a, (const half_t*)W, ldw, M, N, K, EpiGateResidF32{(float*)C, ldc, bias, gate, gate_stride, tokens}, st);
   }
   return LFM_ERR_ARG;
 }
@@ -517,7 +540,9 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
   // conditioning rows: one shared row when time is scalar and there are no labels
   const int rows = (c->t_len == 1 && !c->y) ? 1 : B;
   const long mstride = rows == 1 ? 0 : J;
-  hipLaunchKernelGGL(temb_kernel, dim3(c->t_len), dim3(256), D * sizeof(float), st, c->t, w->t_w0, w->t_b0, w->t_w2, w->t_b2, ws.temb, D);
+  hipLaunchKernelGGL(temb1_kernel, dim3(cdiv(D, 4), c->t_len), dim3(256), 0, st, c->t, w->t_w0, w->t_b0, ws.temb_h, D);
+  LFM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(temb2_kernel, dim3(cdiv(D, 4), c->t_len), dim3(256), 0, st, ws.temb_h, w->t_w2, w->t_b2, ws.temb, D);
   LFM_CHECK_LAUNCH();
   hipLaunchKernelGGL(cond_kernel, dim3(cdiv((long)rows * D, 256)), dim3(256), 0, st, ws.temb, c->t_len, w->y_table, c->y, s->label_rows - 1,
                      ws.c_half, D, rows);
@@ -525,8 +550,8 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
   rc = launch_gemm_tn(ASrcRowMajor{ws.c_half, D, rows, 0}, (const half_t*)w->ada_w, D, rows, (int)J, D, EpiBiasF32{ws.mod, J, w->ada_b}, st);
   if (rc) return rc;
 
-  hipLaunchKernelGGL(patch_embed_kernel, dim3(cdiv((long)M * (D / 4), 256)), dim3(256), 0, st, c->x, w->patch_w, w->patch_b, w->pos_embed, ws.X,
-                     B, cfg ? B / 2 : B, s->in_ch, s->res, s->patch, D);
+  hipLaunchKernelGGL(patch_embed_kernel, dim3(cdiv(M, PE_TOK)), dim3(D / 4), 0, st, c->x, w->patch_w, w->patch_b, w->pos_embed, ws.X, M,
+                     cfg ? B / 2 : B, s->in_ch, s->res, s->patch, D);
   LFM_CHECK_LAUNCH();
 
   half_t* Qb = ws.QKVH;
@@ -536,20 +561,20 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
     const float* mod = ws.mod + (long)i * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
     rc = ln_modulate_launch(ws.X, ws.A, M, D, T, mod, mod + D, mstride, st);
     if (rc) return rc;
-    rc = launch_gemm_tn(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->qkv_w + (size_t)i * 3 * D * D, D, M, 3 * D, D,
+    rc = launch_gemm_auto(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->qkv_w + (size_t)i * 3 * D * D, D, M, 3 * D, D,
                         EpiQKV{Qb, Kb, Vb, w->qkv_b + (size_t)i * 3 * D, D, 64, T}, st);
     if (rc) return rc;
     rc = attention_launch(Qb, Kb, Vb, ws.A, B, s->heads, T, st);
     if (rc) return rc;
-    rc = launch_gemm_tn(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D,
+    rc = launch_gemm_auto(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D,
                         EpiGateResidF32{ws.X, D, w->proj_b + (size_t)i * D, mod + 2 * D, mstride, T}, st);
     if (rc) return rc;
     rc = ln_modulate_launch(ws.X, ws.A, M, D, T, mod + 3 * D, mod + 4 * D, mstride, st);
     if (rc) return rc;
-    rc = launch_gemm_tn(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->fc1_w + (size_t)i * H * D, D, M, H, D,
+    rc = launch_gemm_auto(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->fc1_w + (size_t)i * H * D, D, M, H, D,
                         EpiBiasGeluF16{ws.QKVH, H, w->fc1_b + (size_t)i * H}, st);
     if (rc) return rc;
-    rc = launch_gemm_tn(ASrcRowMajor{ws.QKVH, H, M, 0}, (const half_t*)w->fc2_w + (size_t)i * D * H, H, M, D, H,
+    rc = launch_gemm_auto(ASrcRowMajor{ws.QKVH, H, M, 0}, (const half_t*)w->fc2_w + (size_t)i * D * H, H, M, D, H,
                         EpiGateResidF32{ws.X, D, w->fc2_b + (size_t)i * D, mod + 5 * D, mstride, T}, st);
     if (rc) return rc;
   }

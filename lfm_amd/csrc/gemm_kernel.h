@@ -117,6 +117,7 @@ struct EpiQKV {
   const float* bias;
   int D, hd, tokens;
   typedef f32x4 Aux;
+  __device__ __forceinline__ bool direct(int n0) const { return n0 >= 2 * D; }  // V tiles: 32 consecutive tokens per lane group
   __device__ __forceinline__ Aux load(int, int n) const { return *(const f32x4*)(bias + n); }
   __device__ __forceinline__ void store(int m, int n, f32x4 v, const Aux& b) const {
     v += b;
@@ -144,6 +145,16 @@ __device__ __forceinline__ auto epi_batch(Epi& e, int bz, long bs, int) -> declt
 }
 template <class Epi>
 __device__ __forceinline__ void epi_batch(Epi&, int, long, long) {}
+
+// epilogues that need the raw MFMA fragment layout (lane = 32 consecutive m) for some column range provide direct(n0).
+template <class Epi>
+__device__ __forceinline__ auto epi_direct(const Epi& e, int n0, int) -> decltype(e.direct(n0)) {
+  return e.direct(n0);
+}
+template <class Epi>
+__device__ __forceinline__ bool epi_direct(const Epi&, int, long) {
+  return false;
+}
 
 template <class ASrc, class Epi>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(ASrc asrc, const half_t* __restrict__ W, long ldw, int M, int N, int K,

@@ -5,7 +5,7 @@
 // k = tap*Cin + ci; the A-tile gather (shifted pixel rows, zero padding, optional nearest-2x upsample) is done
 // by the per-lane LDS-DMA source address.  GroupNorm statistics / apply+SiLU are bandwidth-bound side kernels.
 #include "../../include/lfm_hip.h"
-#include "gemm_kernel.h"
+#include "gemm256_kernel.h"
 
 // ------------------------------------------------------------------ implicit-GEMM A source: 3x3 conv, pad 1, NHWC
 // UPS=1: the convolution runs on the nearest-2x upsampled image (diffusers Upsample2D) without materialising it.
@@ -77,6 +77,7 @@ struct EpiTransposeF16 {  // per image: Ct[img][n][m % T] = acc + bias[n]   (V^T
   const float* bias;
   int T, N;
   typedef f32x4 Aux;
+  __device__ __forceinline__ bool direct(int) const { return true; }
   __device__ __forceinline__ Aux load(int, int n) const { return *(const f32x4*)(bias + n); }
   __device__ __forceinline__ void store(int m, int n, f32x4 v, const Aux& b) const {
     v += b;
@@ -316,8 +317,8 @@ static int conv3(const half_t* in, const half_t* w, const float* b, const half_t
   if (Cin % 64 || Cout % 4) return LFM_ERR_SHAPE;
   const int M = n * H * W;
   EpiConvF16 epi{out, Cout, b, resid};
-  if (ups) return launch_gemm_tn(ASrcConv3x3<1>{in, zeros, H, W, Cin, M, 0, 0}, w, 9L * Cin, M, Cout, 9 * Cin, epi, st);
-  return launch_gemm_tn(ASrcConv3x3<0>{in, zeros, H, W, Cin, M, 0, 0}, w, 9L * Cin, M, Cout, 9 * Cin, epi, st);
+  if (ups) return launch_gemm_auto(ASrcConv3x3<1>{in, zeros, H, W, Cin, M, 0, 0}, w, 9L * Cin, M, Cout, 9 * Cin, epi, st);
+  return launch_gemm_auto(ASrcConv3x3<0>{in, zeros, H, W, Cin, M, 0, 0}, w, 9L * Cin, M, Cout, 9 * Cin, epi, st);
 }
 
 static int resnet(const lfm_vae_resnet* r, half_t*& x, half_t*& t1, half_t*& t2, half_t*& t3, const VaeWs& ws, int n, int H, int W, hipStream_t st) {
@@ -327,7 +328,7 @@ static int resnet(const lfm_vae_resnet* r, half_t*& x, half_t*& t1, half_t*& t2,
   RC(gn(t2, t1, ws.stats, r->n2_g, r->n2_b, n, HW, r->cout, true, st));
   const half_t* skip = x;
   if (r->sc_w) {  // 1x1 conv shortcut
-    RC(launch_gemm_tn(ASrcRowMajor{x, r->cin, M, 0}, (const half_t*)r->sc_w, r->cin, M, r->cout, r->cin, EpiConvF16{t3, r->cout, r->sc_b, nullptr}, st));
+    RC(launch_gemm_auto(ASrcRowMajor{x, r->cin, M, 0}, (const half_t*)r->sc_w, r->cin, M, r->cout, r->cin, EpiConvF16{t3, r->cout, r->sc_b, nullptr}, st));
     skip = t3;
   }
   RC(conv3(t1, (const half_t*)r->c2_w, r->c2_b, skip, t2, ws.zeros, n, H, W, r->cout, r->cout, false, st));

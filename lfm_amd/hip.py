@@ -56,6 +56,8 @@ def lib():
     L.lfm_gemm_f16.restype = C.c_int
     L.lfm_gemm_f16.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int,
                                C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.c_int, C.c_void_p]
+    L.lfm_gemm_select.restype = C.c_int
+    L.lfm_gemm_select.argtypes = [C.c_int]
     L.lfm_ln_modulate.restype = C.c_int
     L.lfm_ln_modulate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
     L.lfm_dit_attention.restype = C.c_int

@@ -55,6 +55,54 @@ def test_gemm_epilogues(dev, M, N, K, epi):
     assert rel_l2(got, ref) < (2e-3 if epi in (0, 1) else 2e-4)
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 512, 128), (1024, 768, 1024), (300, 260, 64), (4096, 1024, 4096), (8192, 3072, 1024)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+def test_gemm256_pingpong_kernel(dev, M, N, K, epi):
+    """Same checks with the 256x256 ping-pong kernel forced (lfm_gemm_select(2)); repeated launches screen for races."""
+    from lfm_amd import hip
+
+    g = torch.Generator().manual_seed(M + N * 3 + K + epi)
+    A = (torch.randn(M, K, generator=g) * 0.5).half()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).half()
+    bias = torch.randn(N, generator=g) * 0.1
+    ref = A.float() @ W.float().t() + bias
+    tokens = 4
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref, approximate="tanh")
+    X = gate = None
+    if epi == 3:
+        X = torch.randn(M, N, generator=g)
+        gate = torch.randn(M // tokens, N, generator=g)
+        ref = X + gate.repeat_interleave(tokens, 0) * ref
+        gate = gate.to(dev)
+    hip.lib().lfm_gemm_select(2)
+    try:
+        Ad, Wd, bd = A.to(dev), W.to(dev), bias.to(dev)
+        outs = []
+        for _ in range(4):
+            out = X.clone().to(dev) if epi == 3 else None
+            outs.append(hip.gemm_f16(Ad, Wd, bd, epilogue=epi, out=out, gate=gate, gate_stride=N, tokens=tokens))
+        torch.cuda.synchronize()
+    finally:
+        hip.lib().lfm_gemm_select(0)
+    assert rel_l2(outs[0], ref) < (2e-3 if epi in (0, 1) else 2e-4)
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])  # deterministic across launches (no data race on the LDS stages)
+
+
+def test_gemm256_detects_transpose(dev):
+    from lfm_amd import hip
+
+    A = torch.eye(256, 256).half()
+    W = (torch.arange(512 * 256).reshape(512, 256) % 97).half()
+    hip.lib().lfm_gemm_select(2)
+    try:
+        got = hip.gemm_f16(A.to(dev), W.to(dev), None, epilogue=2)
+    finally:
+        hip.lib().lfm_gemm_select(0)
+    assert torch.equal(got.cpu(), W.float().t())
+
+
 def test_gemm_detects_transpose(dev):
     """A = I with an asymmetric W: a swapped C write cannot pass (cdna guide: always A=I-check)."""
     from lfm_amd import hip

@@ -25,7 +25,10 @@ def timeit(fn, n=10, warm=3):
 
 
 M = 16384
-for N, K, epi in [(3072, 1024, 0), (1024, 1024, 3), (4096, 1024, 1), (1024, 4096, 3), (8192, 8192, 0)]:
+for sel in (1, 2):
+  hip.lib().lfm_gemm_select(sel)
+  print("---- gemm kernel", {1: "v1 128x128", 2: "v2 256x256 ping-pong"}[sel])
+  for N, K, epi in [(3072, 1024, 0), (1024, 1024, 3), (4096, 1024, 1), (1024, 4096, 3), (8192, 8192, 0)]:
     MM = 8192 if N == 8192 else M
     A = (torch.randn(MM, K, device=dev) * 0.5).half()
     W = (torch.randn(N, K, device=dev) * 0.03).half()
@@ -34,6 +37,7 @@ for N, K, epi in [(3072, 1024, 0), (1024, 1024, 3), (4096, 1024, 1), (1024, 4096
     gate = torch.randn(MM // 256, N, device=dev)
     ms = timeit(lambda: hip.gemm_f16(A, W, b, epilogue=epi, out=out, gate=gate, gate_stride=N, tokens=256))
     print(f"gemm M={MM} N={N} K={K} epi={epi}: {ms*1e3:.1f} us  {2*MM*N*K/ms/1e9:.0f} TFLOP/s", flush=True)
+hip.lib().lfm_gemm_select(0)
 
 for name, bs in [("DiT-B/2", 64), ("DiT-L/2", 64)]:
     m = DiT_models[name](img_resolution=32, in_channels=4, num_classes=1, label_dropout=0.0)
