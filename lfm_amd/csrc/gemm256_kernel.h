@@ -1,22 +1,27 @@
-// 256x256x64 "ping-pong" MFMA GEMM for gfx950 (v2):  C[m][n] = sum_k A[m][k] * W[n][k]  (+ fused epilogue).
+// 256x256 "ping-pong" MFMA GEMM for gfx950 (v2):  C[m][n] = sum_k A[m][k] * W[n][k]  (+ fused epilogue).
 // Same operand / epilogue / A-source interfaces as gemm_kernel.h (v1); used for the large GEMMs of the hot path.
 //
 // 512 threads = 8 waves = two wave-GROUPS of four (one wave per SIMD each).  Group g owns rows g*128..+128 of the
 // tile, wave (g, wn) the 128x64 block at columns wn*64: 4(m) x 2(n) fragments of v_mfma_f32_32x32x16_f16 = 128
-// accumulator registers.  A K-tile is consumed in two PHASES of 16 MFMAs (m-fragments {0,1} then {2,3}); every phase
-// has a LOAD segment (ds_read_b128 fragments into registers, plus a share of the next tile's LDS-DMA) and a COMPUTE
-// segment (pure MFMA).  The two groups run the same program shifted by ONE segment, separated by workgroup barriers:
+// accumulator registers.  K is consumed in tiles of 32: per K-tile a wave runs a LOAD segment (12 ds_read_b128
+// fragments into registers + its share of a future tile's LDS-DMA) and a COMPUTE segment (16 MFMAs, nothing else).
+// The two groups run the same program shifted by ONE segment, separated by workgroup barriers:
 //
-//   slot      4t        4t+1      4t+2      4t+3      4t+4 ...
-//   group 0   L0(t)     C0(t)     L1(t)     C1(t)     L0(t+1)
-//   group 1   C1(t-1)   L0(t)     C0(t)     L1(t)     C1(t)
+//   slot      2t       2t+1     2t+2     2t+3
+//   group 0   L(t)     C(t)     L(t+1)   C(t+1)
+//   group 1   C(t-1)   L(t)     C(t)     L(t+1)
 //
 // so on every SIMD one wave is always in a COMPUTE segment while its partner loads: the matrix pipe sees a
-// back-to-back MFMA stream.  LDS holds two stages of (A 256x64 + W 256x64) fp16 = 2 x 64 KiB, XOR-swizzled exactly
-// like v1 (source-side swizzle for the LDS-DMA, same key on the reads).  Tile t+1 is DMA'd into the other stage
-// during slots 4t..4t+2 and must have landed (vmcnt(0) on every wave + the barrier ending slot 4t+3) before slot 4t+4;
-// every LOAD segment drains its own ds_reads (lgkmcnt(0)) before its barrier, so a stage is never refilled while a
-// read of it is in flight.
+// back-to-back MFMA stream.
+//
+// LDS = a RING of four stages of (A 256x32 + W 256x32) fp16 = 4 x 32 KiB.  Measurement drove this shape: with two
+// 64-deep stages only ONE K-tile (64 KiB per CU) could be in flight and the loop ran at the DMA round-trip latency
+// (~1.9 us per 64-deep K-tile, equal with and without the MFMAs).  With the ring, K-tile t+3 is issued in L(t) and is
+// not needed before slot 2t+6: three tiles (96 KiB per CU) are always in flight and a load has ~6 segments to land.
+// Waits are COUNTED (s_waitcnt vmcnt(8): "everything except my last two tiles has landed"), never 0 in steady state.
+// Rows are 64 B, so the XOR swizzle key is (row>>2)&3 on 16-B chunks (a 256-B bank row = four tile rows); as in v1 it
+// is applied to the DMA source address and to the fragment read.  Every LOAD segment drains its own ds_reads
+// (lgkmcnt(0)) before its barrier, so a stage is never refilled while a read of it is in flight.
 #pragma once
 #include "gemm_kernel.h"
 
@@ -25,10 +30,11 @@ int lfm_gemm_debug_flags();  // ablation switches, measurement only
 
 #define G256_BM 256
 #define G256_BN 256
-#define G256_BK 64
-#define G256_TILE_BYTES (256 * 64 * 2)          // one operand tile, 32 KiB
-#define G256_STAGE_BYTES (2 * G256_TILE_BYTES)  // A + W
-#define G256_LDS_BYTES (2 * G256_STAGE_BYTES)   // 128 KiB
+#define G256_BK 32
+#define G256_NSTAGE 4
+#define G256_TILE_BYTES (256 * G256_BK * 2)     // one operand tile, 16 KiB
+#define G256_STAGE_BYTES (2 * G256_TILE_BYTES)  // A + W, 32 KiB
+#define G256_LDS_BYTES (G256_NSTAGE * G256_STAGE_BYTES)  // 128 KiB (the epilogue scratch reuses it)
 
 template <class ASrc, class Epi>
 __global__ __launch_bounds__(512) void gemm256_tn_kernel(ASrc asrc, const half_t* __restrict__ W, long ldw, int M, int N, int K,
@@ -57,29 +63,29 @@ __global__ __launch_bounds__(512) void gemm256_tn_kernel(ASrc asrc, const half_t
   asrc.init(bz, bsA);
   W += (long)bz * bsW;
 
-  // ---- DMA sources: 4 passes of 64 rows per operand, 8 lanes per 128-B row
-  typename ASrc::Row arow[4];
-  const half_t* wrow[4];
-  int cswz[4];
+  // ---- DMA sources: 2 passes of 128 rows per operand, 4 lanes per 64-B row
+  typename ASrc::Row arow[2];
+  const half_t* wrow[2];
+  int cswz[2];
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int r = p * 64 + (tid >> 3);
+  for (int p = 0; p < 2; ++p) {
+    const int r = p * 128 + (tid >> 2);
     arow[p] = asrc.row(m0 + r);
     const int n = n0 + r;
     wrow[p] = W + (long)(n < N ? n : N - 1) * ldw;
-    cswz[p] = ((tid & 7) ^ ((r >> 1) & 7)) * 8;
+    cswz[p] = ((tid & 3) ^ ((r >> 2) & 3)) * 8;
   }
   const int nk = K / G256_BK;
 
-  // 8 DMAs per thread per K-tile (4 A + 4 W)
-  auto issue_tile = [&](int kt, int stage) {
-    char* sA = smem + stage * G256_STAGE_BYTES;
+  // 4 DMAs per thread per K-tile (2 A + 2 W)
+  auto issue_tile = [&](int kt) {
+    char* sA = smem + (kt & (G256_NSTAGE - 1)) * G256_STAGE_BYTES;
     char* sW = sA + G256_TILE_BYTES;
     const int k0 = kt * G256_BK;
-    asrc.begin_tile(kt);
+    asrc.begin_tile(kt, G256_BK);
     if (dbg_noload && kt > 0) return;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < 2; ++p) {
       glds16(asrc.ptr(arow[p], cswz[p]), sA + (p * 512 + wave * 64) * 16);
       glds16(wrow[p] + k0 + cswz[p], sW + (p * 512 + wave * 64) * 16);
     }
@@ -93,47 +99,45 @@ __global__ __launch_bounds__(512) void gemm256_tn_kernel(ASrc asrc, const half_t
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  // fragment read offsets
+  // fragment read offsets (bytes inside an operand tile); chunk c of row r sits at c ^ ((r>>2)&3)
   int a_off[4], a_key[4], w_off[2], w_key[2];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = g * 128 + i * 32 + (lane & 31);
-    a_off[i] = r * 128;
-    a_key[i] = (r >> 1) & 7;
+    a_off[i] = r * 64;
+    a_key[i] = (r >> 2) & 3;
   }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int r = wn * 64 + j * 32 + (lane & 31);
-    w_off[j] = r * 128;
-    w_key[j] = (r >> 1) & 7;
+    w_off[j] = r * 64;
+    w_key[j] = (r >> 2) & 3;
   }
   const int chalf = lane >> 5;
 
-  half8_t af[2][4], wf[2][4];  // [frag][k16 step]
+  half8_t af[4][2], wf[2][2];  // [frag][k16 step]
 
-  auto load_w = [&](const char* sW) {
+  auto load_frags = [&](int kt) {
+    const char* sA = smem + (kt & (G256_NSTAGE - 1)) * G256_STAGE_BYTES;
+    const char* sW = sA + G256_TILE_BYTES;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) wf[j][ks] = *(const half8_t*)(sW + w_off[j] + (((ks * 2 + chalf) ^ w_key[j]) << 4));
-  };
-  auto load_a = [&](const char* sA, int pair) {
+      for (int ks = 0; ks < 2; ++ks) wf[j][ks] = *(const half8_t*)(sW + w_off[j] + (((ks * 2 + chalf) ^ w_key[j]) << 4));
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-        af[i][ks] = *(const half8_t*)(sA + a_off[pair * 2 + i] + (((ks * 2 + chalf) ^ a_key[pair * 2 + i]) << 4));
+      for (int ks = 0; ks < 2; ++ks) af[i][ks] = *(const half8_t*)(sA + a_off[i] + (((ks * 2 + chalf) ^ a_key[i]) << 4));
   };
-  auto compute = [&](int pair) {
+  auto compute = [&]() {
     if (dbg_nomfma) return;
-    __builtin_amdgcn_s_setprio(1);
+    if (!(dbg & 8)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[pair * 2 + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j][ks], af[i][ks], acc[pair * 2 + i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j][ks], af[i][ks], acc[i][j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
   };
 #define G256_BARRIER()                  \
@@ -148,59 +152,41 @@ __global__ __launch_bounds__(512) void gemm256_tn_kernel(ASrc asrc, const half_t
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
     __builtin_amdgcn_sched_barrier(0);                  \
   } while (0)
-#define G256_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+  // "K-tile kt has landed" for this wave's share: every tile up to min(kt+2, nk-1) has been issued, 4 DMAs each, in order
+  auto wait_tile = [&](int kt) {
+    const int newer = (nk - 1 - kt) < 2 ? (nk - 1 - kt) : 2;
+    if (newer >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (newer == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
 
-  // ---- prologue: tile 0 -> stage 0
-  issue_tile(0, 0);
-  G256_VM0();
+  // ---- prologue: K-tiles 0..2 in flight, tile 0 landed
+  issue_tile(0);
+  if (nk > 1) issue_tile(1);
+  if (nk > 2) issue_tile(2);
+  wait_tile(0);
   G256_BARRIER();
 
   if (g == 0) {
     for (int t = 0; t < nk; ++t) {
-      const char* sA = smem + (t & 1) * G256_STAGE_BYTES;
-      const char* sW = sA + G256_TILE_BYTES;
-      const bool more = t + 1 < nk;
-      // slot 4t: L0
-      load_w(sW);
-      load_a(sA, 0);
-      if (more) issue_tile(t + 1, (t + 1) & 1);
+      load_frags(t);  // slot 2t: L(t)
+      if (t + 3 < nk) issue_tile(t + 3);
       G256_LGKM0();
       G256_BARRIER();
-      // slot 4t+1: C0
-      compute(0);
-      G256_BARRIER();
-      // slot 4t+2: L1
-      load_a(sA, 1);
-      G256_LGKM0();
-      G256_BARRIER();
-      // slot 4t+3: C1
-      compute(1);
-      if (more) G256_VM0();
-      G256_BARRIER();  // (last tile: all stage reads are finished -> the epilogue may reuse the LDS)
+      compute();  // slot 2t+1: C(t)
+      if (t + 1 < nk) wait_tile(t + 1);
+      G256_BARRIER();  // (after the last tile: every stage read is finished -> the epilogue may reuse the LDS)
     }
   } else {
-    G256_BARRIER();  // slot 0: group 1 idles
+    G256_BARRIER();  // slot 0: group 1 idles, then stays one segment behind
     for (int t = 0; t < nk; ++t) {
-      const char* sA = smem + (t & 1) * G256_STAGE_BYTES;
-      const char* sW = sA + G256_TILE_BYTES;
-      const bool more = t + 1 < nk;
-      // slot 4t+1: L0
-      load_w(sW);
-      load_a(sA, 0);
-      if (more) issue_tile(t + 1, (t + 1) & 1);
+      load_frags(t);  // slot 2t+1: L(t)
+      if (t + 3 < nk) issue_tile(t + 3);
       G256_LGKM0();
+      if (t + 1 < nk) wait_tile(t + 1);
       G256_BARRIER();
-      // slot 4t+2: C0
-      compute(0);
-      G256_BARRIER();
-      // slot 4t+3: L1
-      load_a(sA, 1);
-      G256_LGKM0();
-      if (more) G256_VM0();
-      G256_BARRIER();
-      // slot 4t+4: C1
-      compute(1);
-      if (more) G256_BARRIER();
+      compute();  // slot 2t+2: C(t)
+      if (t + 1 < nk) G256_BARRIER();
     }
   }
 
@@ -210,6 +196,7 @@ __global__ __launch_bounds__(512) void gemm256_tn_kernel(ASrc asrc, const half_t
   // 272 B: conflict-free ds_write_b128) and re-reads it row-major: 16 lanes cover one 256-B row, so a global access
   // instruction touches 4 rows x full lines.  Epilogues that want the fragment layout (V^T scatter) opt out.
   epi_batch(epi, bz, bsC, 0);
+  if (dbg & 4) return;  // ablation: no epilogue
   if (epi_direct(epi, n0, 0)) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

@@ -41,7 +41,7 @@ struct ASrcRowMajor {
     return r;
   }
   int k0;
-  __device__ __forceinline__ void begin_tile(int kt) { k0 = kt * 64; }
+  __device__ __forceinline__ void begin_tile(int kt, int bk) { k0 = kt * bk; }
   __device__ __forceinline__ const half_t* ptr(const Row& r, int koff) const { return r.p + k0 + koff; }
 };
 
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(ASrc asrc, const half_t
     char* sA = smem + stage * GEMM_STAGE_BYTES;
     char* sW = sA + GEMM_BM * GEMM_BK * 2;
     const int k0 = kt * GEMM_BK;
-    asrc.begin_tile(kt);
+    asrc.begin_tile(kt, GEMM_BK);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       glds16(asrc.ptr(arow[p], cswz[p]), sA + (p * 256 + wave * 64) * 16);

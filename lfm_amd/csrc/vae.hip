@@ -28,12 +28,12 @@ struct ASrcConv3x3 {
     r.n = t / H;
     return r;
   }
-  __device__ __forceinline__ void begin_tile(int kt) {  // called with kt = 0, 1, 2, ... in order
+  __device__ __forceinline__ void begin_tile(int kt, int bk) {  // called with kt = 0, 1, 2, ... in order
     if (kt == 0) {
       tap = 0;
       ci0 = 0;
     } else {
-      ci0 += GEMM_BK;
+      ci0 += bk;
       if (ci0 >= Cin) {
         ci0 = 0;
         ++tap;
