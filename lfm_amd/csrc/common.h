@@ -45,14 +45,13 @@ __device__ __forceinline__ float wave_max(float v) {
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
-// GELU(tanh) as torch: 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715 x^3)))
+// GELU(tanh) as torch: 0.5*x*(1+tanh(u)), u = sqrt(2/pi)*(x+0.044715 x^3)  ==  x * sigmoid(2u)  ==  x / (1 + 2^(-z)),
+// z = 2u*log2(e) = x*(c0 + c1*x^2).  Two transcendentals (v_exp_f32, v_rcp_f32) and four plain VALU per element; saturates
+// correctly without clamps (2^+inf -> rcp(inf) = 0, 2^-inf = 0 -> x).
 __device__ __forceinline__ float gelu_tanh_f(float x) {
-  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-  float u = k0 * (x + k1 * x * x * x);
-  // tanh(u) = 1 - 2/(exp(2u)+1); clamp to keep exp finite
-  float e = __expf(2.0f * fminf(fmaxf(u, -15.0f), 15.0f));
-  float th = 1.0f - 2.0f / (e + 1.0f);
-  return 0.5f * x * (1.0f + th);
+  const float c0 = 2.3022081985f, c1 = 0.1029432397f;  // 2*sqrt(2/pi)*log2(e), c0*0.044715
+  const float z = x * (c0 + c1 * x * x);
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-z));
 }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -167,22 +167,16 @@ __global__ __launch_bounds__(T, 2) void dit_attention_kernel(const half_t* __res
   const half_t* Kg = K + (long)img * T * D + head * 64;
   const half_t* Vg = Vt + ((long)img * heads + head) * 64 * T;
 
-  // ---- stage K and V^T (T*128 bytes each)
+  // ---- stage K (8 DMAs per thread), fetch this wave's Q fragments, then stage V^T (8 DMAs).  Issue order = completion
+  // order for loads, so vmcnt(8) below means "K and Q are here, V^T may still be flying"; V^T is awaited before the first PV.
+  constexpr int NPASS = (T * 8) / (NW * 64);
+  static_assert(NPASS == 8, "wait counts below assume 8 DMAs per operand");
 #pragma unroll
-  for (int p = 0; p < (T * 8) / (NW * 64); ++p) {
+  for (int p = 0; p < NPASS; ++p) {
     const int s = p * (NW * 64) + tid;
-    {
-      const int row = s >> 3, c = (s & 7) ^ ((row >> 1) & 7);
-      glds16(Kg + (long)row * D + c * 8, Ks + (p * NW * 64 + wave * 64) * 16);
-    }
-    {
-      constexpr int CPR = T / 8;  // 16-B chunks per V^T row
-      const int row = s / CPR, c = (s % CPR) ^ (row & VKEY);
-      glds16(Vg + (long)row * T + c * 8, Vs + (p * NW * 64 + wave * 64) * 16);
-    }
+    const int row = s >> 3, c = (s & 7) ^ ((row >> 1) & 7);
+    glds16(Kg + (long)row * D + c * 8, Ks + (p * NW * 64 + wave * 64) * 16);
   }
-
-  // ---- Q fragments straight from global (each used by this wave only)
   const int q0 = wave * 64;
   const int hsel = lane >> 5, l31 = lane & 31;
   half8_t qf[2][4];
@@ -191,6 +185,13 @@ __global__ __launch_bounds__(T, 2) void dit_attention_kernel(const half_t* __res
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
       qf[jq][ks] = *(const half8_t*)(Q + ((long)img * T + q0 + jq * 32 + l31) * D + head * 64 + ks * 16 + hsel * 8);
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p) {
+    const int s = p * (NW * 64) + tid;
+    constexpr int CPR = T / 8;  // 16-B chunks per V^T row
+    const int row = s / CPR, c = (s % CPR) ^ (row & VKEY);
+    glds16(Vg + (long)row * T + c * 8, Vs + (p * NW * 64 + wave * 64) * 16);
+  }
 
   f32x16 Oa[2][2];  // [jq][db]
 #pragma unroll
@@ -201,8 +202,9 @@ __global__ __launch_bounds__(T, 2) void dit_attention_kernel(const half_t* __res
       for (int e = 0; e < 16; ++e) Oa[jq][db][e] = 0.f;
   float mrun[2] = {-3.0e38f, -3.0e38f}, lrun[2] = {0.f, 0.f};
 
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // raw barrier: __syncthreads() would drain the in-flight V^T DMAs
+  asm volatile("" ::: "memory");
 
   const int vkey = l31 & VKEY;  // rows d and d+32 share the key (VKEY <= 15)
 #pragma unroll 1
@@ -244,8 +246,15 @@ __global__ __launch_bounds__(T, 2) void dit_attention_kernel(const half_t* __res
         P[jq][e >> 3][e & 7] = (half_t)pe;
       }
       lrun[jq] = lrun[jq] * alpha + sum;
+      if (!__all(alpha == 1.0f)) {  // wave-uniform: most key blocks do not raise any query's running max
 #pragma unroll
-      for (int db = 0; db < 2; ++db) Oa[jq][db] *= alpha;
+        for (int db = 0; db < 2; ++db) Oa[jq][db] *= alpha;
+      }
+    }
+    if (kb == 0) {  // V^T was issued after K and Q: only now must it have landed (every wave's share)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
     }
     // ---- O^T[d][q] += sum_key V^T[d][key] P[q][key]
 #pragma unroll

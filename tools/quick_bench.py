@@ -50,3 +50,12 @@ for name, bs in [("DiT-B/2", 64), ("DiT-L/2", 64)]:
     ms = timeit(lambda: m(t, x), n=5, warm=2)
     fl = {"DiT-B/2": 46.0e9, "DiT-L/2": 161.4e9}[name] * bs
     print(f"{name} bs={bs} forward: {ms:.2f} ms  {fl/ms/1e9:.0f} TFLOP/s  => {bs/(50*ms/1e3):.1f} img/s at 50 NFE (no VAE)", flush=True)
+
+# attention alone (DiT-L shape)
+Bh, heads, T = 64, 16, 256
+Q = torch.randn(Bh * T, heads * 64, device=dev).half(); K = torch.randn_like(Q); Vt = torch.randn(Bh, heads, 64, T, device=dev).half()
+ms = timeit(lambda: hip.dit_attention(Q, K, Vt, Bh, heads, T), n=20)
+print(f"attention b={Bh} h={heads} T={T}: {ms*1e3:.1f} us  {4*Bh*heads*T*T*64/ms/1e9:.0f} TFLOP/s")
+X = torch.randn(Bh * T, 1024, device=dev); sh = torch.randn(1, 1024, device=dev); sc = torch.randn(1, 1024, device=dev)
+ms = timeit(lambda: hip.ln_modulate(X, sh, sc, T, 0), n=20)
+print(f"ln_modulate M={Bh*T} D=1024: {ms*1e3:.1f} us  {Bh*T*1024*6/ms/1e6:.0f} GB/s")
