@@ -174,27 +174,33 @@ def main():
     res["split_ms"] = {"solver": ev[0].elapsed_time(ev[1]), "vae_decode_u8": ev[1].elapsed_time(ev[2])}
 
     if rank == 0 and not a.no_roofline:
-        # dominant kernel: the fc1 MFMA GEMM + GELU epilogue (gemm_tn_kernel<ASrcRowMajor, EpiBiasGeluF16>), timed live with
-        # HIP events on the stream it is launched on, at exactly the shape/operands the model uses.
+        # dominant kernel: the fc1 MFMA GEMM + GELU epilogue (gemm256_tn_kernel<ASrcRowMajor, EpiBiasGeluF16>, 24 % of the step).
+        # Timed LIVE and IN SITU: eager forwards of the real model on the solver's latents with one HIP event pair recorded
+        # around every block's fc1 launch on the launching stream (lfm_profile_fc1; a captured graph cannot be bracketed).
+        import ctypes as C
+
         D, H, M = model.hidden_size, model.mlp_hidden, B * 256
-        A = (torch.randn(M, D, device=dev) * 0.5).half()
-        W = (torch.randn(H, D, device=dev) * 0.03).half()
-        bias = torch.randn(H, device=dev) * 0.02
-        C = torch.empty(M, H, device=dev, dtype=torch.float16)
+        L = hip.lib()
+        tmid = torch.tensor(0.5, device=dev)
+        model(tmid, lat)  # warm
+        durs = []
         for _ in range(3):
-            hip.gemm_f16(A, W, bias, epilogue=1, out=C)
-        n = 20
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(n):
-            hip.gemm_f16(A, W, bias, epilogue=1, out=C)
-        e1.record()
-        torch.cuda.synchronize()
-        dur = e0.elapsed_time(e1) / n * 1e-3
+            hip.check(L.lfm_profile_fc1(1), "lfm_profile_fc1")
+            model(tmid, lat)
+            buf = (C.c_float * 64)()
+            n = L.lfm_profile_fc1_read(buf, 64)
+            durs += [buf[i] for i in range(n)]
+        L.lfm_profile_fc1(0)
+        dur = sum(durs) / len(durs) * 1e-3
         ach = 2.0 * M * H * D / dur / 1e12
+        # HBM traffic per launch from PMC (profiles/r01_b_fc1_gemm_hbm_pmc.json): FETCH_SIZE 98.58 MB raw -> x2 (gfx950
+        # correction of MI355X_MICROARCH.md) + WRITE_SIZE 134.22 MB; measured at this shape on the shipped kernel.
+        traffic = (2 * 98576.7 + 131072.0) * 1024 if (M, H, D) == (16384, 4096, 1024) else None
         res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
-                           "traffic": None, "kernel": "gemm256_tn_kernel<ASrcRowMajor,EpiBiasGeluF16> (DiT fc1 + GELU)",
-                           "shape": {"M": M, "N": H, "K": D}, "avg_launch_us": dur * 1e6}
+                           "traffic": traffic, "traffic_unit": "bytes/launch (HBM, rocprofv3 PMC, separate passes)",
+                           "algorithmic_bytes": 2.0 * (M * D + H * D + M * H), "algorithmic_flop": 2.0 * M * H * D,
+                           "kernel": "gemm256_tn_kernel<ASrcRowMajor,EpiBiasGeluF16> (DiT fc1 + GELU)",
+                           "shape": {"M": M, "N": H, "K": D}, "avg_launch_us": dur * 1e6, "launches_timed": len(durs)}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(a.model, a.nfe)
     if rank == 0:

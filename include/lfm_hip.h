@@ -108,6 +108,11 @@ int lfm_gemm_f16(const void* A, long lda, const void* W, long ldw, void* C, long
  * 1 = force the 128x128 kernel, 2 = force the 256x256 kernel.  For A/B measurement and parity tests. */
 int lfm_gemm_select(int which);
 
+/* Measurement only: when enabled, every eager lfm_dit_forward records a HIP event pair around each block's fc1 GEMM (the
+ * dominant kernel); lfm_profile_fc1_read synchronises and returns the per-launch durations in ms (bench.py roofline row). */
+int lfm_profile_fc1(int enable);
+int lfm_profile_fc1_read(float* host_ms_out, int max_n);
+
 /* A fp16 [M,D] = LayerNorm(X fp32 [M,D], eps 1e-6, no affine) * (1 + scale[img]) + shift[img]
  * (models/DiT.py:20-21,119,121,129-130).  mod_stride = floats between images' rows (0 = shared). */
 int lfm_ln_modulate(const float* X, void* A, int M, int D, int tokens, const float* shift, const float* scale, long mod_stride,
@@ -152,6 +157,37 @@ int lfm_vae_decode(const lfm_vae_weights* w, void* workspace, size_t workspace_b
 
 /* u8 NHWC = trunc(clamp((x+1)/2, 0, 1) * 255) of fp32 NCHW images (test_flow_latent_ddp.py:131-135). */
 int lfm_images_to_uint8(const float* x, uint8_t* out, int N, int H, int W, lfm_stream_t stream);
+
+/* ------------------------------------------------------------------ NHWC-fp16 building blocks (origin-ADM UNet)
+ * The guided-diffusion UNet (models/guided_diffusion/unet.py:376-655) has a data-dependent layer list, so its forward is
+ * sequenced by the host (lfm_amd/models/unet.py) over these ops.  Activations: fp16 NHWC [N*H*W, C].
+ *
+ * lfm_conv3x3_f16: out[N,H,W,Cout] = conv3x3(in, pad 1) + bias (+ resid); w fp16 [Cout][ky*3+kx][Cin], Cin % 64 == 0.
+ *   mode 0: in is [N,H,W,Cin] (ResBlock convs, unet.py:171-175,193-198);  mode 1: in is [N,H/2,W/2,Cin], nearest-2x upsampled on
+ *   the fly (Upsample, :73-100);  mode 2: in is [N,2H,2W,Cin], stride 2 (Downsample, :103-128). */
+int lfm_conv3x3_f16(const void* in, const void* w, const float* bias, const void* resid, void* out, int N, int H, int W, int Cin, int Cout,
+                    int mode, lfm_stream_t stream);
+/* first conv (unet.py:475): fp32 NCHW [N,Cin<=16,H,W] -> fp16 NHWC [N,H,W,Cout]; w fp32 [Cout,Cin,3,3] */
+int lfm_conv3x3_in_f32(const float* x_nchw, const float* w, const float* bias, void* out_nhwc, int N, int H, int W, int Cin, int Cout,
+                       lfm_stream_t stream);
+/* last conv (unet.py:594): fp16 NHWC -> fp32 NCHW [N,nch<=4,H,W]; w4 fp16 [4][9][Cin] (rows >= nch zero), bias4 fp32 [4] */
+int lfm_conv3x3_out_f32(const void* in, const void* w4, const float* bias4, float* out_nchw, int N, int H, int W, int Cin, int nch,
+                        lfm_stream_t stream);
+/* C fp16 [M,N] = A[M,K] W[N,K]^T + bias (+ resid fp16 [M,N]): 1x1 convs / Conv1d(k=1) / skip connections (unet.py:204,266,276) */
+int lfm_linear_f16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N, int K, const float* bias,
+                   const void* resid, lfm_stream_t stream);
+/* y = silu?( GroupNorm32(x; gamma, beta, eps) * (1 + scale[n]) + shift[n] );  film = fp32 [N][scale(C) | shift(C)] rows film_stride apart,
+ * or NULL (nn.py:17-19,93-100; scale-shift-norm unet.py:228-233).  scratch: lfm_groupnorm_scratch_bytes(N, C) bytes. */
+size_t lfm_groupnorm_scratch_bytes(int N, int C);
+int lfm_groupnorm_f16(const void* x, void* y, const float* gamma, const float* beta, const float* film, long film_stride, void* scratch, int N,
+                      int HW, int C, float eps, int silu, lfm_stream_t stream);
+/* out[p][0:Ca | Ca:Ca+Cb] = a[p], b[p]   (th.cat([h, hs.pop()], dim=1), unet.py:649) */
+int lfm_concat_channels_f16(const void* a, const void* b, void* out, long pixels, int Ca, int Cb, lfm_stream_t stream);
+/* QKVAttentionLegacy (unet.py:310-334): qkv fp16 [N*T, 3C], columns [head][q|k|v][ch]; out fp16 [N*T, C] columns [head][ch] */
+int lfm_attention_small_f16(const void* qkv, void* out, int N, int T, int heads, int ch, lfm_stream_t stream);
+/* emb = time_embed(timestep_embedding(t, F)) (+ label_emb[y]) (nn.py:103-121, unet.py:633-641): fp32 [N,E] and fp16 silu(emb) */
+int lfm_time_embed(const float* t, int t_len, const float* w0, const float* b0, const float* w2, const float* b2, const float* label_table,
+                   const int64_t* y, float* scratch_h1, float* emb, void* emb_silu_f16, int N, int F, int E, lfm_stream_t stream);
 
 /* ------------------------------------------------------------------ solver helpers (device-resident time grid)
  * Advance the captured step:  s = *step;  t_cur[0] = ts[s];  t_next[0] = ts[s+1];  dt_cur[0] = dts[s];  *step = s+1.

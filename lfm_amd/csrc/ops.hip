@@ -1,0 +1,432 @@
+// Generic NHWC-fp16 building blocks behind the C ABI, used by the origin-ADM UNet (reference
+// models/guided_diffusion/unet.py) whose layer sequence is data-dependent and therefore driven from the host side:
+// implicit-GEMM 3x3 convolution (same / nearest-2x-upsampled input / stride 2), 1x1 convolution / linear with residual,
+// general GroupNorm(32) with optional FiLM scale-shift and SiLU, channel concat, small-T attention, timestep embedding.
+#include "../../include/lfm_hip.h"
+#include "gemm256_kernel.h"
+
+// ------------------------------------------------------------------ implicit-GEMM A source, NHWC fp16, 3x3, pad 1
+// MODE 0: same size.  MODE 1: input is nearest-2x upsampled on the fly (Upsample, unet.py:73-100).
+// MODE 2: stride 2 (Downsample, unet.py:103-128): output (oy,ox) reads input (2oy+dy-1, 2ox+dx-1).
+template <int MODE>
+struct ASrcConv {
+  const half_t* in;
+  const half_t* zeros;
+  int H, W, Cin, M;  // OUTPUT spatial size; M = N*H*W
+  int tap, ci0;
+  __device__ __forceinline__ void init(int, long) {}
+  struct Row {
+    int n, y, x;
+  };
+  __device__ __forceinline__ Row row(int m) const {
+    if (m >= M) m = M - 1;
+    Row r;
+    r.x = m % W;
+    const int t = m / W;
+    r.y = t % H;
+    r.n = t / H;
+    return r;
+  }
+  __device__ __forceinline__ void begin_tile(int kt, int bk) {
+    if (kt == 0) {
+      tap = 0;
+      ci0 = 0;
+    } else {
+      ci0 += bk;
+      if (ci0 >= Cin) {
+        ci0 = 0;
+        ++tap;
+      }
+    }
+  }
+  __device__ __forceinline__ const half_t* ptr(const Row& r, int koff) const {
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+    if (MODE == 2) {
+      const int Hi = H * 2, Wi = W * 2;
+      const int iy = 2 * r.y + dy, ix = 2 * r.x + dx;
+      if ((unsigned)iy >= (unsigned)Hi || (unsigned)ix >= (unsigned)Wi) return zeros + koff;
+      return in + (((long)r.n * Hi + iy) * Wi + ix) * Cin + ci0 + koff;
+    }
+    const int iy = r.y + dy, ix = r.x + dx;
+    if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) return zeros + koff;
+    const int Hs = H >> (MODE == 1), Ws = W >> (MODE == 1);
+    return in + (((long)r.n * Hs + (iy >> (MODE == 1))) * Ws + (ix >> (MODE == 1))) * Cin + ci0 + koff;
+  }
+};
+
+struct EpiResidF16 {  // out = acc + bias (+ residual) -> fp16
+  half_t* C;
+  long ldc;
+  const float* bias;
+  const half_t* resid;
+  struct Aux {
+    f32x4 b;
+    half4_t r;
+  };
+  __device__ __forceinline__ Aux load(int m, int n) const {
+    Aux a;
+    a.b = bias ? *(const f32x4*)(bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    a.r = resid ? *(const half4_t*)(resid + (long)m * ldc + n) : (half4_t){0, 0, 0, 0};
+    return a;
+  }
+  __device__ __forceinline__ void store(int m, int n, f32x4 v, const Aux& a) const {
+    v += a.b;
+    half4_t h = {(half_t)(v.x + (float)a.r.x), (half_t)(v.y + (float)a.r.y), (half_t)(v.z + (float)a.r.z), (half_t)(v.w + (float)a.r.w)};
+    *(half4_t*)(C + (long)m * ldc + n) = h;
+  }
+};
+
+struct EpiNCHWF32 {  // Cout <= 4 output conv: fp32 NCHW, channels beyond nch are padding
+  float* out;
+  const float* bias;  // [4]
+  int HW, nch;
+  typedef f32x4 Aux;
+  __device__ __forceinline__ Aux load(int, int n) const { return *(const f32x4*)(bias + n); }
+  __device__ __forceinline__ void store(int m, int n, f32x4 v, const Aux& b) const {
+    if (n != 0) return;
+    v += b;
+    const int img = m / HW, pix = m - img * HW;
+    float* o = out + (long)img * nch * HW + pix;
+    o[0] = v.x;
+    if (nch > 1) o[HW] = v.y;
+    if (nch > 2) o[2 * HW] = v.z;
+    if (nch > 3) o[3 * HW] = v.w;
+  }
+};
+
+static __device__ half_t g_zero_page[64];  // zero padding rows for the conv gathers (zero-initialised device global)
+
+static const half_t* zero_page() {
+  static const half_t* p = nullptr;
+  if (!p) {
+    void* d = nullptr;
+    if (hipGetSymbolAddress(&d, HIP_SYMBOL(g_zero_page)) != hipSuccess) return nullptr;
+    p = (const half_t*)d;
+  }
+  return p;
+}
+
+extern "C" int lfm_conv3x3_f16(const void* in, const void* w, const float* bias, const void* resid, void* out, int N, int H, int W, int Cin,
+                               int Cout, int mode, lfm_stream_t stream) {
+  if (!in || !w || !out) return LFM_ERR_ARG;
+  if (N <= 0 || H <= 0 || W <= 0 || Cin % 64 || Cout % 4 || mode < 0 || mode > 2) return LFM_ERR_SHAPE;
+  if (mode == 1 && ((H | W) & 1)) return LFM_ERR_SHAPE;
+  const half_t* z = zero_page();
+  if (!z) return LFM_ERR_LAUNCH;
+  const int M = N * H * W;
+  EpiResidF16 epi{(half_t*)out, Cout, bias, (const half_t*)resid};
+  hipStream_t st = (hipStream_t)stream;
+  const half_t* wi = (const half_t*)w;
+  const half_t* xi = (const half_t*)in;
+  if (mode == 0) return launch_gemm_auto(ASrcConv<0>{xi, z, H, W, Cin, M, 0, 0}, wi, 9L * Cin, M, Cout, 9 * Cin, epi, st);
+  if (mode == 1) return launch_gemm_auto(ASrcConv<1>{xi, z, H, W, Cin, M, 0, 0}, wi, 9L * Cin, M, Cout, 9 * Cin, epi, st);
+  return launch_gemm_auto(ASrcConv<2>{xi, z, H, W, Cin, M, 0, 0}, wi, 9L * Cin, M, Cout, 9 * Cin, epi, st);
+}
+
+extern "C" int lfm_conv3x3_out_f32(const void* in, const void* w4, const float* bias4, float* out_nchw, int N, int H, int W, int Cin, int nch,
+                                   lfm_stream_t stream) {
+  if (!in || !w4 || !bias4 || !out_nchw) return LFM_ERR_ARG;
+  if (N <= 0 || Cin % 64 || nch < 1 || nch > 4) return LFM_ERR_SHAPE;
+  const half_t* z = zero_page();
+  if (!z) return LFM_ERR_LAUNCH;
+  const int M = N * H * W;
+  return launch_gemm_tn(ASrcConv<0>{(const half_t*)in, z, H, W, Cin, M, 0, 0}, (const half_t*)w4, 9L * Cin, M, 4, 9 * Cin,
+                        EpiNCHWF32{out_nchw, bias4, H * W, nch}, (hipStream_t)stream);
+}
+
+extern "C" int lfm_linear_f16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N, int K, const float* bias,
+                              const void* resid, lfm_stream_t stream) {
+  if (!A || !W || !C) return LFM_ERR_ARG;
+  if ((lda % 8) || ((uintptr_t)A & 15)) return LFM_ERR_ALIGN;
+  return launch_gemm_auto(ASrcRowMajor{(const half_t*)A, lda, M, 0}, (const half_t*)W, ldw, M, N, K,
+                          EpiResidF16{(half_t*)C, ldc, bias, (const half_t*)resid}, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------ first conv: fp32 NCHW (Cin <= 8) -> fp16 NHWC
+__global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                      half_t* __restrict__ out, int N, int H, int W, int Cin, int Cout) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c8 = Cout / 8;
+  if (idx >= (long)N * H * W * c8) return;
+  const int co = (int)(idx % c8) * 8;
+  const long pix = idx / c8;
+  const int xx = (int)(pix % W), yy = (int)((pix / W) % H), n = (int)(pix / ((long)H * W));
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = b[co + j];
+  for (int ky = 0; ky < 3; ++ky)
+    for (int kx = 0; kx < 3; ++kx) {
+      const int iy = yy + ky - 1, ix = xx + kx - 1;
+      if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) continue;
+      for (int c = 0; c < Cin; ++c) {
+        const float v = x[(((long)n * Cin + c) * H + iy) * W + ix];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += w[(((long)(co + j) * Cin + c) * 3 + ky) * 3 + kx] * v;
+      }
+    }
+  half8_t h;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) h[j] = (half_t)acc[j];
+  *(half8_t*)(out + pix * Cout + co) = h;
+}
+
+extern "C" int lfm_conv3x3_in_f32(const float* x_nchw, const float* w, const float* bias, void* out_nhwc, int N, int H, int W, int Cin,
+                                  int Cout, lfm_stream_t stream) {
+  if (!x_nchw || !w || !bias || !out_nhwc) return LFM_ERR_ARG;
+  if (N <= 0 || Cin <= 0 || Cin > 16 || Cout % 8) return LFM_ERR_SHAPE;
+  hipLaunchKernelGGL(conv_in_kernel, dim3(cdiv((long)N * H * W * (Cout / 8), 256)), dim3(256), 0, (hipStream_t)stream, x_nchw, w, bias,
+                     (half_t*)out_nhwc, N, H, W, Cin, Cout);
+  LFM_CHECK_LAUNCH();
+  return LFM_OK;
+}
+
+// ------------------------------------------------------------------ general GroupNorm(32 groups) on NHWC fp16
+// 1) stats: one block per (group, image, pixel-slab) -> atomics into stats[n][g] = {sum, sumsq}
+// 2) coef : per (n, c):  a = rstd*gamma*(1+scale),  b = (beta - mean*rstd*gamma)*(1+scale) + shift     (FiLM optional)
+// 3) apply: y = silu?(x*a + b), 8 channels per thread
+template <int VEC>
+__global__ __launch_bounds__(256) void gn_stats_general_kernel(const half_t* __restrict__ x, float* __restrict__ stats, int HW, int C, int cpg,
+                                                               int pix_per_block) {
+  const int g = blockIdx.x, n = blockIdx.y;
+  const int p0 = blockIdx.z * pix_per_block, p1 = min(p0 + pix_per_block, HW);
+  const int vpp = cpg / VEC;  // vectors per pixel in this group
+  const long total = (long)(p1 - p0) * vpp;
+  const half_t* base = x + (long)n * HW * C + g * cpg;
+  float s = 0.f, q = 0.f;
+  for (long e = threadIdx.x; e < total; e += 256) {
+    const int p = p0 + (int)(e / vpp), v = (int)(e % vpp);
+    const half_t* ptr = base + (long)p * C + v * VEC;
+    if (VEC == 4) {
+      const half4_t h = *(const half4_t*)ptr;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float f = (float)h[j];
+        s += f;
+        q += f * f;
+      }
+    } else {
+      const float f = (float)ptr[0];
+      s += f;
+      q += f * f;
+    }
+  }
+  __shared__ float rs[4], rq[4];
+  s = wave_sum(s);
+  q = wave_sum(q);
+  if ((threadIdx.x & 63) == 0) {
+    rs[threadIdx.x >> 6] = s;
+    rq[threadIdx.x >> 6] = q;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&stats[((long)n * 32 + g) * 2], rs[0] + rs[1] + rs[2] + rs[3]);
+    atomicAdd(&stats[((long)n * 32 + g) * 2 + 1], rq[0] + rq[1] + rq[2] + rq[3]);
+  }
+}
+
+__global__ void gn_coef_kernel(const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ film, long film_stride, float* __restrict__ ab, int N, int C, int cpg, float cnt,
+                               float eps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * C) return;
+  const int n = i / C, c = i - n * C, g = c / cpg;
+  const float mean = stats[((long)n * 32 + g) * 2] / cnt;
+  const float var = fmaxf(stats[((long)n * 32 + g) * 2 + 1] / cnt - mean * mean, 0.f);
+  const float rstd = rsqrtf(var + eps);
+  float a = rstd * gamma[c], b = beta[c] - mean * rstd * gamma[c];
+  if (film) {  // h = norm(h) * (1 + scale) + shift   (unet.py:229-232; film row = [scale(C) | shift(C)])
+    const float sc = 1.0f + film[(long)n * film_stride + c], sh = film[(long)n * film_stride + C + c];
+    a *= sc;
+    b = b * sc + sh;
+  }
+  ab[(long)i * 2] = a;
+  ab[(long)i * 2 + 1] = b;
+}
+
+template <bool SILU>
+__global__ __launch_bounds__(256) void gn_affine_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, const float* __restrict__ ab,
+                                                        int HW, int C, long total8) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total8) return;
+  const int c8n = C / 8;
+  const int c0 = (int)(i % c8n) * 8;
+  const int n = (int)(i / ((long)c8n * HW));
+  const half8_t v = ((const half8_t*)x)[i];
+  const f32x4* p = (const f32x4*)(ab + ((long)n * C + c0) * 2);
+  half8_t o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const f32x4 t = p[j];  // a0 b0 a1 b1
+    float f0 = (float)v[2 * j] * t.x + t.y, f1 = (float)v[2 * j + 1] * t.z + t.w;
+    if (SILU) {
+      f0 = silu_f(f0);
+      f1 = silu_f(f1);
+    }
+    o[2 * j] = (half_t)f0;
+    o[2 * j + 1] = (half_t)f1;
+  }
+  ((half8_t*)y)[i] = o;
+}
+
+extern "C" size_t lfm_groupnorm_scratch_bytes(int N, int C) { return (size_t)N * 64 * 4 + (size_t)N * C * 8 + 256; }
+
+extern "C" int lfm_groupnorm_f16(const void* x, void* y, const float* gamma, const float* beta, const float* film, long film_stride, void* scratch,
+                                 int N, int HW, int C, float eps, int silu, lfm_stream_t stream) {
+  if (!x || !y || !gamma || !beta || !scratch) return LFM_ERR_ARG;
+  if (N <= 0 || HW <= 0 || C % 32 || C % 8) return LFM_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  float* stats = (float*)scratch;
+  float* ab = (float*)((char*)scratch + (((size_t)N * 64 * 4 + 255) / 256) * 256);
+  if (hipMemsetAsync(stats, 0, (size_t)N * 64 * 4, st) != hipSuccess) return LFM_ERR_LAUNCH;
+  const int cpg = C / 32;
+  const int ppb = 2048;
+  dim3 grid(32, N, cdiv(HW, ppb));
+  if (cpg % 4 == 0) hipLaunchKernelGGL(gn_stats_general_kernel<4>, grid, dim3(256), 0, st, (const half_t*)x, stats, HW, C, cpg, ppb);
+  else hipLaunchKernelGGL(gn_stats_general_kernel<1>, grid, dim3(256), 0, st, (const half_t*)x, stats, HW, C, cpg, ppb);
+  LFM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gn_coef_kernel, dim3(cdiv((long)N * C, 256)), dim3(256), 0, st, stats, gamma, beta, film, film_stride, ab, N, C, cpg,
+                     (float)HW * (float)cpg, eps);
+  LFM_CHECK_LAUNCH();
+  const long total8 = (long)N * HW * C / 8;
+  if (silu) hipLaunchKernelGGL(gn_affine_kernel<true>, dim3(cdiv(total8, 256)), dim3(256), 0, st, (const half_t*)x, (half_t*)y, ab, HW, C, total8);
+  else hipLaunchKernelGGL(gn_affine_kernel<false>, dim3(cdiv(total8, 256)), dim3(256), 0, st, (const half_t*)x, (half_t*)y, ab, HW, C, total8);
+  LFM_CHECK_LAUNCH();
+  return LFM_OK;
+}
+
+// ------------------------------------------------------------------ channel concat (th.cat([h, skip], dim=1), unet.py:649)
+__global__ void concat_c_kernel(const half8_t* __restrict__ a, const half8_t* __restrict__ b, half8_t* __restrict__ o, long pixels, int Ca8, int Cb8) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int Co8 = Ca8 + Cb8;
+  if (i >= pixels * Co8) return;
+  const long p = i / Co8;
+  const int c = (int)(i - p * Co8);
+  o[i] = c < Ca8 ? a[p * Ca8 + c] : b[p * Cb8 + (c - Ca8)];
+}
+extern "C" int lfm_concat_channels_f16(const void* a, const void* b, void* out, long pixels, int Ca, int Cb, lfm_stream_t stream) {
+  if (!a || !b || !out) return LFM_ERR_ARG;
+  if (Ca % 8 || Cb % 8 || pixels <= 0) return LFM_ERR_SHAPE;
+  hipLaunchKernelGGL(concat_c_kernel, dim3(cdiv(pixels * ((Ca + Cb) / 8), 256)), dim3(256), 0, (hipStream_t)stream, (const half8_t*)a,
+                     (const half8_t*)b, (half8_t*)out, pixels, Ca / 8, Cb / 8);
+  LFM_CHECK_LAUNCH();
+  return LFM_OK;
+}
+
+// ------------------------------------------------------------------ small-T attention (QKVAttentionLegacy, unet.py:310-334)
+// qkv: fp16 [N*T, 3*C], column layout [head][q | k | v][ch] (what reshape(bs*heads, 3*ch, T).split(ch) means for a
+// token-major tensor); out: fp16 [N*T, C] with columns [head][ch].  softmax((q*s)(k*s)^T) v with s = ch^-1/4, fp32 softmax.
+// One workgroup per (head, image); T <= 256, ch <= 256.  FLOPs are negligible (T <= 64 in every reference config), so this
+// is a plain VALU kernel: K and V rows in LDS as fp32, one query per thread-group.
+__global__ __launch_bounds__(256) void attention_small_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out, int T, int heads, int ch) {
+  extern __shared__ __attribute__((aligned(16))) char smraw[];  // S fp32 [T][T+1], then K, V fp16 [T][ch+2]
+  const int head = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  const int C = heads * ch, ldq = 3 * C, ks = ch + 2;
+  float* S = (float*)smraw;
+  half_t* Ks = (half_t*)(S + T * (T + 1));
+  half_t* Vs = Ks + T * ks;
+  const half_t* base = qkv + (long)n * T * ldq + head * 3 * ch;
+  for (int e = tid; e < T * ch; e += 256) {
+    const int t = e / ch, c = e - t * ch;
+    Ks[t * ks + c] = base[(long)t * ldq + ch + c];
+    Vs[t * ks + c] = base[(long)t * ldq + 2 * ch + c];
+  }
+  __syncthreads();
+  const float scale = rsqrtf((float)ch);  // (ch^-1/4)^2
+  for (int e = tid; e < T * T; e += 256) {
+    const int t = e / T, s = e - t * T;
+    const half_t* q = base + (long)t * ldq;
+    float a = 0.f;
+    for (int c = 0; c < ch; ++c) a += (float)q[c] * (float)Ks[s * ks + c];
+    S[t * (T + 1) + s] = a * scale;
+  }
+  __syncthreads();
+  for (int t = tid; t < T; t += 256) {
+    float* r = S + t * (T + 1);
+    float mx = r[0];
+    for (int s = 1; s < T; ++s) mx = fmaxf(mx, r[s]);
+    float sum = 0.f;
+    for (int s = 0; s < T; ++s) {
+      r[s] = __expf(r[s] - mx);
+      sum += r[s];
+    }
+    const float inv = 1.0f / sum;
+    for (int s = 0; s < T; ++s) r[s] *= inv;
+  }
+  __syncthreads();
+  half_t* ob = out + (long)n * T * C + head * ch;
+  for (int e = tid; e < T * ch; e += 256) {
+    const int t = e / ch, c = e - t * ch;
+    const float* r = S + t * (T + 1);
+    float a = 0.f;
+    for (int s = 0; s < T; ++s) a += r[s] * (float)Vs[s * ks + c];
+    ob[(long)t * C + c] = (half_t)a;
+  }
+}
+
+extern "C" int lfm_attention_small_f16(const void* qkv, void* out, int N, int T, int heads, int ch, lfm_stream_t stream) {
+  if (!qkv || !out) return LFM_ERR_ARG;
+  if (N <= 0 || T <= 0 || heads <= 0 || ch <= 0) return LFM_ERR_SHAPE;
+  const size_t lds = (size_t)T * (T + 1) * 4 + (size_t)2 * T * (ch + 2) * 2;
+  if (lds > 160 * 1024) return LFM_ERR_SHAPE;
+  static bool set = false;
+  if (!set) {
+    if (hipFuncSetAttribute((const void*)attention_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return LFM_ERR_LAUNCH;
+    set = true;
+  }
+  hipLaunchKernelGGL(attention_small_kernel, dim3(heads, N), dim3(256), lds, (hipStream_t)stream, (const half_t*)qkv, (half_t*)out, T, heads, ch);
+  LFM_CHECK_LAUNCH();
+  return LFM_OK;
+}
+
+// ------------------------------------------------------------------ timestep embedding MLP (nn.py:103-121 + unet.py:633-641)
+// emb[r] = W2 silu(W0 [cos(t f) | sin(t f)] + b0) + b2 (+ label_emb[y[r]]);  also emits fp16 silu(emb) for the ResBlock emb_layers
+__global__ __launch_bounds__(256) void time_embed1_kernel(const float* __restrict__ t, int t_len, const float* __restrict__ w0,
+                                                          const float* __restrict__ b0, float* __restrict__ h1, int F, int E) {
+  const int r = blockIdx.y, lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= E) return;
+  const float tv = t[t_len == 1 ? 0 : r];
+  const int half = F / 2;
+  const float* w = w0 + (long)j * F;
+  float s = 0.f;
+  for (int k = lane; k < 2 * half; k += 64) {
+    const int i = k < half ? k : k - half;
+    const float a = tv * __expf(-9.210340371976184f * (float)i / (float)half);
+    s += w[k] * (k < half ? cosf(a) : sinf(a));
+  }
+  s = wave_sum(s);
+  if (lane == 0) h1[(long)r * E + j] = silu_f(s + b0[j]);
+}
+__global__ __launch_bounds__(256) void time_embed2_kernel(const float* __restrict__ h1, const float* __restrict__ w2, const float* __restrict__ b2,
+                                                          const float* __restrict__ label_table, const int64_t* __restrict__ y,
+                                                          float* __restrict__ emb, half_t* __restrict__ emb_silu, int E) {
+  const int r = blockIdx.y, lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= E) return;
+  const float* w = w2 + (long)j * E;
+  const float* h = h1 + (long)r * E;
+  float s = 0.f;
+  for (int k = lane; k < E; k += 64) s += w[k] * h[k];
+  s = wave_sum(s);
+  if (lane == 0) {
+    float v = s + b2[j];
+    if (label_table) v += label_table[(long)y[r] * E + j];
+    emb[(long)r * E + j] = v;
+    emb_silu[(long)r * E + j] = (half_t)silu_f(v);
+  }
+}
+
+extern "C" int lfm_time_embed(const float* t, int t_len, const float* w0, const float* b0, const float* w2, const float* b2,
+                              const float* label_table, const int64_t* y, float* scratch_h1, float* emb, void* emb_silu_f16, int N, int F, int E,
+                              lfm_stream_t stream) {
+  if (!t || !w0 || !b0 || !w2 || !b2 || !scratch_h1 || !emb || !emb_silu_f16) return LFM_ERR_ARG;
+  if ((label_table != nullptr) != (y != nullptr)) return LFM_ERR_ARG;
+  if (N <= 0 || F <= 0 || (F & 1) || E <= 0 || (t_len != 1 && t_len != N)) return LFM_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(time_embed1_kernel, dim3(cdiv(E, 4), N), dim3(256), 0, st, t, t_len, w0, b0, scratch_h1, F, E);
+  LFM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(time_embed2_kernel, dim3(cdiv(E, 4), N), dim3(256), 0, st, scratch_h1, w2, b2, label_table, y, emb, (half_t*)emb_silu_f16, E);
+  LFM_CHECK_LAUNCH();
+  return LFM_OK;
+}

@@ -58,6 +58,10 @@ def lib():
                                C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.c_int, C.c_void_p]
     L.lfm_gemm_select.restype = C.c_int
     L.lfm_gemm_select.argtypes = [C.c_int]
+    L.lfm_profile_fc1.restype = C.c_int
+    L.lfm_profile_fc1.argtypes = [C.c_int]
+    L.lfm_profile_fc1_read.restype = C.c_int
+    L.lfm_profile_fc1_read.argtypes = [C.POINTER(C.c_float), C.c_int]
     L.lfm_ln_modulate.restype = C.c_int
     L.lfm_ln_modulate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
     L.lfm_dit_attention.restype = C.c_int
@@ -72,6 +76,25 @@ def lib():
     L.lfm_vae_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.lfm_images_to_uint8.restype = C.c_int
     L.lfm_images_to_uint8.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    V, I, LG, F = C.c_void_p, C.c_int, C.c_long, C.c_float
+    L.lfm_conv3x3_f16.restype = I
+    L.lfm_conv3x3_f16.argtypes = [V, V, V, V, V, I, I, I, I, I, I, V]
+    L.lfm_conv3x3_in_f32.restype = I
+    L.lfm_conv3x3_in_f32.argtypes = [V, V, V, V, I, I, I, I, I, V]
+    L.lfm_conv3x3_out_f32.restype = I
+    L.lfm_conv3x3_out_f32.argtypes = [V, V, V, V, I, I, I, I, I, V]
+    L.lfm_linear_f16.restype = I
+    L.lfm_linear_f16.argtypes = [V, LG, V, LG, V, LG, I, I, I, V, V, V]
+    L.lfm_groupnorm_scratch_bytes.restype = C.c_size_t
+    L.lfm_groupnorm_scratch_bytes.argtypes = [I, I]
+    L.lfm_groupnorm_f16.restype = I
+    L.lfm_groupnorm_f16.argtypes = [V, V, V, V, V, LG, V, I, I, I, F, I, V]
+    L.lfm_concat_channels_f16.restype = I
+    L.lfm_concat_channels_f16.argtypes = [V, V, V, LG, I, I, V]
+    L.lfm_attention_small_f16.restype = I
+    L.lfm_attention_small_f16.argtypes = [V, V, I, I, I, I, V]
+    L.lfm_time_embed.restype = I
+    L.lfm_time_embed.argtypes = [V, I, V, V, V, V, V, V, V, V, V, I, I, I, V]
     _lib = L
     return L
 
