@@ -317,12 +317,14 @@ extern "C" int lfm_concat_channels_f16(const void* a, const void* b, void* out, 
 // token-major tensor); out: fp16 [N*T, C] with columns [head][ch].  softmax((q*s)(k*s)^T) v with s = ch^-1/4, fp32 softmax.
 // One workgroup per (head, image); T <= 256, ch <= 256.  FLOPs are negligible (T <= 64 in every reference config), so this
 // is a plain VALU kernel: K and V rows in LDS as fp32, one query per thread-group.
-__global__ __launch_bounds__(256) void attention_small_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out, int T, int heads, int ch) {
-  extern __shared__ __attribute__((aligned(16))) char smraw[];  // S fp32 [T][T+1], then K, V fp16 [T][ch+2]
-  const int head = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+__global__ __launch_bounds__(256) void attention_small_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out, int T, int heads, int ch,
+                                                              int QB) {
+  extern __shared__ __attribute__((aligned(16))) char smraw[];  // S fp32 [QB][T+1], then K, V fp16 [T][ch+2]
+  const int head = blockIdx.x, n = blockIdx.y, q0 = blockIdx.z * QB, tid = threadIdx.x;
+  const int nq = min(QB, T - q0);
   const int C = heads * ch, ldq = 3 * C, ks = ch + 2;
   float* S = (float*)smraw;
-  half_t* Ks = (half_t*)(S + T * (T + 1));
+  half_t* Ks = (half_t*)(S + QB * (T + 1));
   half_t* Vs = Ks + T * ks;
   const half_t* base = qkv + (long)n * T * ldq + head * 3 * ch;
   for (int e = tid; e < T * ch; e += 256) {
@@ -332,15 +334,15 @@ __global__ __launch_bounds__(256) void attention_small_kernel(const half_t* __re
   }
   __syncthreads();
   const float scale = rsqrtf((float)ch);  // (ch^-1/4)^2
-  for (int e = tid; e < T * T; e += 256) {
+  for (int e = tid; e < nq * T; e += 256) {
     const int t = e / T, s = e - t * T;
-    const half_t* q = base + (long)t * ldq;
+    const half_t* q = base + (long)(q0 + t) * ldq;
     float a = 0.f;
     for (int c = 0; c < ch; ++c) a += (float)q[c] * (float)Ks[s * ks + c];
     S[t * (T + 1) + s] = a * scale;
   }
   __syncthreads();
-  for (int t = tid; t < T; t += 256) {
+  for (int t = tid; t < nq; t += 256) {
     float* r = S + t * (T + 1);
     float mx = r[0];
     for (int s = 1; s < T; ++s) mx = fmaxf(mx, r[s]);
@@ -353,8 +355,8 @@ __global__ __launch_bounds__(256) void attention_small_kernel(const half_t* __re
     for (int s = 0; s < T; ++s) r[s] *= inv;
   }
   __syncthreads();
-  half_t* ob = out + (long)n * T * C + head * ch;
-  for (int e = tid; e < T * ch; e += 256) {
+  half_t* ob = out + ((long)n * T + q0) * C + head * ch;
+  for (int e = tid; e < nq * ch; e += 256) {
     const int t = e / ch, c = e - t * ch;
     const float* r = S + t * (T + 1);
     float a = 0.f;
@@ -366,15 +368,17 @@ __global__ __launch_bounds__(256) void attention_small_kernel(const half_t* __re
 extern "C" int lfm_attention_small_f16(const void* qkv, void* out, int N, int T, int heads, int ch, lfm_stream_t stream) {
   if (!qkv || !out) return LFM_ERR_ARG;
   if (N <= 0 || T <= 0 || heads <= 0 || ch <= 0) return LFM_ERR_SHAPE;
-  const size_t lds = (size_t)T * (T + 1) * 4 + (size_t)2 * T * (ch + 2) * 2;
-  if (lds > 160 * 1024) return LFM_ERR_SHAPE;
+  const int QB = T < 64 ? T : 64;  // queries per workgroup
+  const size_t lds = (size_t)QB * (T + 1) * 4 + (size_t)2 * T * (ch + 2) * 2;
+  if (lds > 160 * 1024) return LFM_ERR_SHAPE;  // every reference config has T <= 64 (8x8 / 4x4 feature maps)
   static bool set = false;
   if (!set) {
     if (hipFuncSetAttribute((const void*)attention_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return LFM_ERR_LAUNCH;
     set = true;
   }
-  hipLaunchKernelGGL(attention_small_kernel, dim3(heads, N), dim3(256), lds, (hipStream_t)stream, (const half_t*)qkv, (half_t*)out, T, heads, ch);
+  hipLaunchKernelGGL(attention_small_kernel, dim3(heads, N, cdiv(T, QB)), dim3(256), lds, (hipStream_t)stream, (const half_t*)qkv, (half_t*)out,
+                     T, heads, ch, QB);
   LFM_CHECK_LAUNCH();
   return LFM_OK;
 }

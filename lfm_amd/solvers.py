@@ -194,8 +194,9 @@ def torchdiffeq_euler_grid(step_size, device=None):
 # ============================================================================ fused, graph-captured fixed grid
 def fused_fixed_grid_available(model, x):
     from .models.DiT import DiT
+    from .models.unet import UNetModel
 
-    return isinstance(model, DiT) and x.is_cuda and not model.training
+    return isinstance(model, (DiT, UNetModel)) and x.is_cuda and not model.training
 
 
 class GraphedFixedGrid:
@@ -205,9 +206,15 @@ class GraphedFixedGrid:
     heun interval  :  advance -> d1 = v(t, x);  xp = x + dt*d1;  d2 = v(t_next, xp);  x <- x + dt*(0.5 d1 + 0.5 d2).
     """
 
-    def __init__(self, model, batch, y=None, cfg_scale=1.0, use_cfg=False, graph=True):
-        dev = model.pos_embed.device
-        C, R = model.in_channels, model.img_resolution
+    def __init__(self, model, batch, y=None, cfg_scale=1.0, use_cfg=False, graph=True, resolution=None):
+        from .models.DiT import DiT
+
+        self.is_dit = isinstance(model, DiT)
+        dev = next(model.parameters()).device
+        C = model.in_channels
+        R = model.img_resolution if self.is_dit else (resolution or model.image_size)
+        if use_cfg and not self.is_dit:
+            raise NotImplementedError("classifier-free guidance needs forward_with_cfg, which the origin-ADM UNet does not have")
         self.model, self.batch, self.dev = model, batch, dev
         self.y = None if y is None else y.to(dev, torch.long).contiguous()
         self.use_cfg, self.cfg_scale = bool(use_cfg), float(cfg_scale)
@@ -293,12 +300,12 @@ def _fused(model, x, model_kwargs):
     y = model_kwargs.get("y")
     cfg_scale = float(model_kwargs.get("cfg_scale", 1.0))
     use_cfg = cfg_scale > 1.0
-    key = (id(model), x.shape[0], use_cfg, cfg_scale, y is not None, x.device)
+    key = (id(model), tuple(x.shape), use_cfg, cfg_scale, y is not None, x.device)
     fg = _FUSED_CACHE.get(key)
     if fg is None:
         if len(_FUSED_CACHE) > 8:
             _FUSED_CACHE.clear()
-        fg = GraphedFixedGrid(model, x.shape[0], y=y, cfg_scale=cfg_scale, use_cfg=use_cfg)
+        fg = GraphedFixedGrid(model, x.shape[0], y=y, cfg_scale=cfg_scale, use_cfg=use_cfg, resolution=x.shape[-1])
         _FUSED_CACHE[key] = fg
     elif y is not None:
         fg.y.copy_(y)  # labels are read by the captured kernels from this buffer

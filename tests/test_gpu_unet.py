@@ -52,7 +52,8 @@ def test_building_blocks_against_torch():
                             2: (F.conv2d(xh.float(), w.half().float(), b, stride=2, padding=1), H // 2)}.items():
         out = torch.empty(N * Ho * Ho, Cout, dtype=torch.float16, device=dev)
         xin = nhwc(xh).to(dev)
-        hip.check(L.lfm_conv3x3_f16(hip.ptr(xin), hip.ptr(wp), hip.ptr(b.to(dev)), None, hip.ptr(out), N, Ho, Ho, Cin, Cout, mode,
+        bd = b.to(dev)  # keep device tensors alive across the call (a temporary's block would be recycled)
+        hip.check(L.lfm_conv3x3_f16(hip.ptr(xin), hip.ptr(wp), hip.ptr(bd), None, hip.ptr(out), N, Ho, Ho, Cin, Cout, mode,
                                     hip.stream_ptr()), "conv")
         assert rel_l2(out.reshape(N, Ho, Ho, Cout).permute(0, 3, 1, 2), ref) < 2e-3, mode
     # GroupNorm32 + FiLM + SiLU on a channel count whose groups are 6 wide (192 / 32)
@@ -65,7 +66,8 @@ def test_building_blocks_against_torch():
     xin = nhwc(xg).to(dev)
     y = torch.empty_like(xin)
     scr = torch.empty(L.lfm_groupnorm_scratch_bytes(N, C), dtype=torch.uint8, device=dev)
-    hip.check(L.lfm_groupnorm_f16(hip.ptr(xin), hip.ptr(y), hip.ptr(gamma.to(dev)), hip.ptr(beta.to(dev)), hip.ptr(film.to(dev)), 2 * C,
+    gd, bd, fd = gamma.to(dev), beta.to(dev), film.to(dev)
+    hip.check(L.lfm_groupnorm_f16(hip.ptr(xin), hip.ptr(y), hip.ptr(gd), hip.ptr(bd), hip.ptr(fd), 2 * C,
                                   hip.ptr(scr), N, H * W, C, 1e-5, 1, hip.stream_ptr()), "gn")
     assert rel_l2(y.permute(0, 3, 1, 2), ref) < 2e-3
     # legacy attention: [N, heads*3*ch, T] with per-head [q|k|v]
@@ -78,3 +80,37 @@ def test_building_blocks_against_torch():
     out = torch.empty(N * T, heads * ch, dtype=torch.float16, device=dev)
     hip.check(L.lfm_attention_small_f16(hip.ptr(tok), hip.ptr(out), N, T, heads, ch, hip.stream_ptr()), "attn")
     assert rel_l2(out.reshape(N, T, heads * ch).permute(0, 2, 1), ref) < 2e-3
+
+
+def test_unet_fullsize_vs_oracle_and_fused_sampling():
+    """celeb256-ADM-like configuration (nf 256, ch_mult 1 2 2 2, attn at ds 16/8, 4 heads) at reduced depth of batch:
+    one velocity evaluation vs the CPU oracle, then a 4-step Euler solve: graph-captured vs eager loop vs oracle."""
+    from argparse import Namespace
+
+    from lfm_amd.models import create_network
+    from lfm_amd.test_flow_latent import sample_from_model
+    from oracle import ode_ref, unet_ref
+
+    dev = torch.device("cuda:0")
+    args = Namespace(use_origin_adm=True, layout=False, model_type="adm", image_size=128, f=8, num_in_channels=4, num_out_channels=4,
+                     nf=128, num_res_blocks=1, attn_resolutions=(4, 2), dropout=0.0, ch_mult=(1, 2, 2), resamp_with_conv=True, num_classes=None,
+                     num_heads=4, num_head_channels=-1, num_head_upsample=-1)  # the _ddp parser's missing flags take their defaults
+    cfg = dict(image_size=16, in_channels=4, model_channels=128, out_channels=4, num_res_blocks=1, attention_resolutions=(4, 2),
+               channel_mult=(1, 2, 2), num_classes=None, num_heads=4, num_head_channels=-1, num_heads_upsample=-1)
+    sd = unet_ref.make_unet_state(cfg, seed=3)
+    m = create_network(args)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).eval()
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(3, 4, 16, 16, generator=g)
+    t = torch.tensor([0.9, 0.4, 0.1])
+    ref = unet_ref.unet_forward(sd, cfg, t, x0)
+    assert rel_l2(m(t.to(dev), x0.to(dev)), ref) < 3e-3
+    sargs = Namespace(method="euler", step_size=0.25, perturb=False, compute_nfe=False, cfg_scale=1.0, atol=1e-5, rtol=1e-5)
+    fused = sample_from_model(m, x0.to(dev), {}, sargs)[-1]
+    sargs.fused = False
+    eager = sample_from_model(m, x0.to(dev), {}, sargs)[-1]
+    oracle = ode_ref.odeint(lambda tt, xx: unet_ref.unet_forward(sd, cfg, tt, xx), x0, torch.tensor([1.0, 0.0]), method="euler",
+                            options={"step_size": 0.25})[-1]
+    assert rel_l2(fused, eager) < 1e-5
+    assert rel_l2(fused, oracle) < 2e-3

@@ -51,3 +51,16 @@ def test_make_dit_state_names_match_reference(golden_dir):
 def test_flops_closed_form():
     assert abs(dit_ref.dit_flops_per_image(dit_ref.DiTCfg.named("DiT-L/2")) / 1e9 - 161.4) < 0.5
     assert abs(dit_ref.dit_flops_per_image(dit_ref.DiTCfg.named("DiT-B/2")) / 1e9 - 46.0) < 0.3
+
+
+@pytest.mark.parametrize("which", ["ssn", "cls"])
+def test_unet_ref_matches_reference(golden_dir, which):
+    from oracle import unet_ref
+
+    rec = _load(golden_dir, "unet_tiny.pt")[which]
+    v = unet_ref.unet_forward(rec["state_dict"], rec["cfg"], rec["t"], rec["x"], rec.get("y"))
+    assert float(rec["v"].abs().mean()) > 1e-2
+    torch.testing.assert_close(v, rec["v"], rtol=1e-4, atol=1e-5)
+    mine = unet_ref.make_unet_state(rec["cfg"], seed=1)
+    assert set(mine) == set(rec["state_dict"])
+    assert all(tuple(mine[k].shape) == tuple(rec["state_dict"][k].shape) for k in mine)
