@@ -61,7 +61,7 @@ __global__ void cond_kernel(const float* __restrict__ temb, int t_len, const flo
 // X[n*T + tok][j] = b[j] + pos[tok][j] + sum_{c,p,q} W[j][c][p][q] * x[n % xmod][c][hp+p][wp+q]
 // blockDim = D/4 threads, thread = 4 consecutive output channels whose weight rows stay in registers (KK <= 16 here);
 // a block walks PE_TOK tokens, whose KK input values are wave-uniform loads.
-#define PE_TOK 16
+#define PE_TOK 4
 #define PE_MAXK 16
 __global__ __launch_bounds__(320) void patch_embed_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
                                                           const float* __restrict__ pos, float* __restrict__ X, int M, int xmod, int C, int R,

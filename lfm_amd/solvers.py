@@ -240,16 +240,28 @@ class GraphedFixedGrid:
         hip.check(hip.lib().lfm_grid_advance(hip.ptr(self.ts), hip.ptr(self.dts), hip.ptr(self.step), hip.ptr(self.tcur), hip.ptr(self.tnext),
                                              hip.ptr(self.dt), hip.stream_ptr(self.dev)), "lfm_grid_advance")
 
+    def _velocity(self, t, x, out=None):
+        if self.is_dit:
+            return self.model._run(t, x, self.y, self.use_cfg, self.cfg_scale, out=out)
+        v = self.model(t, x, self.y)  # host-sequenced UNet: its launches are captured like any others
+        if out is not None:
+            out.copy_(v)
+            return out
+        return v
+
     def _euler(self):
         self._advance()
-        self.model._run(self.tcur, self.x, self.y, self.use_cfg, self.cfg_scale, out=self.x, axpy_base=self.x, axpy_dt=self.dt)
+        if self.is_dit:  # x <- x + dt*v fused into the model's last kernel
+            self.model._run(self.tcur, self.x, self.y, self.use_cfg, self.cfg_scale, out=self.x, axpy_base=self.x, axpy_dt=self.dt)
+        else:
+            hip.lincomb(self.x, self.x, [self._velocity(self.tcur, self.x)], self.c1, self.dt)
 
     def _heun(self):
         self._advance()
-        self.model._run(self.tcur, self.x, self.y, self.use_cfg, self.cfg_scale, out=self.d1)
-        hip.lincomb(self.xp, self.x, [self.d1], self.c1, self.dt)
-        self.model._run(self.tnext, self.xp, self.y, self.use_cfg, self.cfg_scale, out=self.d2)
-        hip.lincomb(self.x, self.x, [self.d1, self.d2], self.c2, self.dt)
+        d1 = self._velocity(self.tcur, self.x, out=self.d1)
+        hip.lincomb(self.xp, self.x, [d1], self.c1, self.dt)
+        d2 = self._velocity(self.tnext, self.xp, out=self.d2)
+        hip.lincomb(self.x, self.x, [d1, d2], self.c2, self.dt)
 
     def _get(self, kind):
         fn = self._euler if kind == "euler" else self._heun
