@@ -336,19 +336,50 @@ __global__ __launch_bounds__(256) void final_layer_kernel(const float* __restric
       const int c = lane + 64 * i;
       if (c < nv) v[i] = v[i] * rstd * (1.0f + sc[c]) + sh[c];
     }
-    for (int o = 0; o < NO; ++o) {
-      const f32x4* wr = (const f32x4*)(Wf + (long)o * D);
-      float a = 0.f;
+    // NO (<= 64) dot products of length D: per-lane partials for 16 outputs at a time, then a butterfly that halves the
+    // number of live values per exchange (16 -> 1 in 4 steps) instead of 16 full wave reductions.
+    for (int ob = 0; ob < NO; ob += 16) {
+      float part[16];
 #pragma unroll
-      for (int i = 0; i < LN_MAXV; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nv) {
-          const f32x4 w4 = wr[c];
-          a += v[i].x * w4.x + v[i].y * w4.y + v[i].z * w4.z + v[i].w * w4.w;
+      for (int o = 0; o < 16; ++o) {
+        float a = 0.f;
+        if (ob + o < NO) {
+          const f32x4* wr = (const f32x4*)(Wf + (long)(ob + o) * D);
+#pragma unroll
+          for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+              const f32x4 w4 = wr[c];
+              a += v[i].x * w4.x + v[i].y * w4.y + v[i].z * w4.z + v[i].w * w4.w;
+            }
+          }
+        }
+        part[o] = a;
+      }
+      // step s exchanges with lane ^ (32 >> s) and keeps the half of the values selected by that lane bit
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int width = 16 >> s, half_w = width >> 1, mask = 32 >> s;
+        const bool upper = (lane & mask) != 0;
+#pragma unroll
+        for (int k = 0; k < half_w; ++k) {
+          const float keep = upper ? part[k + half_w] : part[k];
+          const float send = upper ? part[k] : part[k + half_w];
+          part[k] = keep + __shfl_xor(send, mask, 64);
         }
       }
-      a = wave_sum(a) + bf[o];
-      if (lane == o) res[half] = a;
+      // part[0] now holds output index o = (lane>>2)&15 bit-reversed ... summed over 16 lanes groups; finish over the low 2 bits
+      float r = part[0];
+      r += __shfl_xor(r, 2, 64);
+      r += __shfl_xor(r, 1, 64);
+      // which output does this lane hold?  bit (32>>s) of the lane selected the upper half at step s => o = b5*8 + b4*4 + b3*2 + b2
+      const int o_here = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+      // lane o (< NO) must end up with output o: fetch it from lane src whose o_here == o - ob
+      const int want = lane - ob;
+      const int src = ((want >> 3) & 1) * 32 + ((want >> 2) & 1) * 16 + ((want >> 1) & 1) * 8 + (want & 1) * 4;
+      const float got = __shfl(r, (want >= 0 && want < 16) ? src : lane, 64);
+      if (want >= 0 && want < 16 && lane < NO) res[half] = got + bf[lane];
+      (void)o_here;
     }
   }
   if (lane < NO) {
