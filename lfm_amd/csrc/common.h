@@ -43,6 +43,13 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// value held by lane ^ 32 (the other half-wave): one v_permlane32_swap instead of a ds_bpermute round trip through the LDS
+__device__ __forceinline__ float xhalf(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);  // r[0] = [lo|lo], r[1] = [hi|hi]
+  return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
+}
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
 // GELU(tanh) as torch: 0.5*x*(1+tanh(u)), u = sqrt(2/pi)*(x+0.044715 x^3)  ==  x * sigmoid(2u)  ==  x / (1 + 2^(-z)),

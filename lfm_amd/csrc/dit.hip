@@ -207,45 +207,50 @@ __global__ __launch_bounds__(T, 2) void dit_attention_kernel(const half_t* __res
   asm volatile("" ::: "memory");
 
   const int vkey = l31 & VKEY;  // rows d and d+32 share the key (VKEY <= 15)
-#pragma unroll 1
-  for (int kb = 0; kb < NKB; ++kb) {
-    // ---- S^T block: 32 keys x 64 queries
-    f32x16 S[2];
+  f32x16 zero16;
 #pragma unroll
-    for (int jq = 0; jq < 2; ++jq)
+  for (int e = 0; e < 16; ++e) zero16[e] = 0.f;
+  // S^T block kb: 32 keys x 64 queries (the first MFMA takes a shared all-zero C: no per-block accumulator clears)
+  auto qk = [&](f32x16 (&S)[2], int kb) {
+    const int row = kb * 32 + l31;
+    const int key = (row >> 1) & 7;
+    const char* kp = Ks + row * 128;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) S[jq][e] = 0.f;
-    {
-      const int row = kb * 32 + l31;
-      const int key = (row >> 1) & 7;
-      const char* kp = Ks + row * 128;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const half8_t kf = *(const half8_t*)(kp + (((ks * 2 + hsel) ^ key) << 4));
-        S[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[0][ks], S[0], 0, 0, 0);
-        S[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[1][ks], S[1], 0, 0, 0);
-      }
+    for (int ks = 0; ks < 4; ++ks) {
+      const half8_t kf = *(const half8_t*)(kp + (((ks * 2 + hsel) ^ key) << 4));
+      S[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[0][ks], ks == 0 ? zero16 : S[0], 0, 0, 0);
+      S[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[1][ks], ks == 0 ? zero16 : S[1], 0, 0, 0);
     }
-    // ---- online softmax update for the two queries this lane owns
+  };
+  // online softmax update for the two queries this lane owns, then O^T[d][q] += sum_key V^T[d][key] P[q][key].
+  // VALU diet (the kernel is VALU-bound: ~2.3k VALU per wave vs 128 MFMAs): 3-input max, packed fp32 FMA / ADD on
+  // register pairs, one v_permlane32_swap instead of a ds_bpermute round trip for the lane^32 exchange.
+  auto softmax_pv = [&](f32x16 (&S)[2], int kb) {
     half8_t P[2][2];
 #pragma unroll
     for (int jq = 0; jq < 2; ++jq) {
-      float mx = S[jq][0];
+      float mx = fmaxf(fmaxf(S[jq][0], S[jq][1]), S[jq][2]);
 #pragma unroll
-      for (int e = 1; e < 16; ++e) mx = fmaxf(mx, S[jq][e]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      for (int e = 3; e < 15; e += 2) mx = fmaxf(fmaxf(mx, S[jq][e]), S[jq][e + 1]);
+      mx = fmaxf(mx, S[jq][15]);
+      mx = fmaxf(mx, xhalf(mx));
       const float mnew = fmaxf(mrun[jq], mx);
       const float alpha = __builtin_amdgcn_exp2f((mrun[jq] - mnew) * scale_log2e);
       mrun[jq] = mnew;
-      const float mb = mnew * scale_log2e;
-      float sum = 0.f;
+      const f32x2 sc2 = {scale_log2e, scale_log2e};
+      const float mbs = mnew * scale_log2e;
+      const f32x2 mb2 = {mbs, mbs};
+      f32x2 sum2 = {0.f, 0.f};
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float pe = __builtin_amdgcn_exp2f(S[jq][e] * scale_log2e - mb);
-        sum += pe;
-        P[jq][e >> 3][e & 7] = (half_t)pe;
+      for (int e = 0; e < 16; e += 2) {
+        const f32x2 s2 = {S[jq][e], S[jq][e + 1]};
+        const f32x2 a2 = s2 * sc2 - mb2;  // v_pk_fma_f32
+        const f32x2 p2 = {__builtin_amdgcn_exp2f(a2.x), __builtin_amdgcn_exp2f(a2.y)};
+        sum2 += p2;  // v_pk_add_f32
+        P[jq][e >> 3][e & 7] = (half_t)p2.x;
+        P[jq][e >> 3][(e & 7) + 1] = (half_t)p2.y;
       }
-      lrun[jq] = lrun[jq] * alpha + sum;
+      lrun[jq] = lrun[jq] * alpha + (sum2.x + sum2.y);
       if (!__all(alpha == 1.0f)) {  // wave-uniform: most key blocks do not raise any query's running max
 #pragma unroll
         for (int db = 0; db < 2; ++db) Oa[jq][db] *= alpha;
@@ -256,7 +261,6 @@ __global__ __launch_bounds__(T, 2) void dit_attention_kernel(const half_t* __res
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     }
-    // ---- O^T[d][q] += sum_key V^T[d][key] P[q][key]
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
 #pragma unroll
@@ -271,11 +275,22 @@ __global__ __launch_bounds__(T, 2) void dit_attention_kernel(const half_t* __res
         Oa[1][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, P[1][s], Oa[1][db], 0, 0, 0);
       }
     }
+  };
+  // software pipeline over the key blocks: the S MFMAs of block kb+1 are issued BEFORE the softmax VALU of block kb, so
+  // the matrix pipe works underneath the VALU-heavy part instead of the wave idling on the MFMA -> max -> exp -> MFMA chain
+  f32x16 Sa[2], Sb[2];
+  qk(Sa, 0);
+#pragma unroll 1
+  for (int kb = 0; kb < NKB; kb += 2) {
+    qk(Sb, kb + 1);
+    softmax_pv(Sa, kb);
+    if (kb + 2 < NKB) qk(Sa, kb + 2);
+    softmax_pv(Sb, kb + 1);
   }
   // ---- normalise and store: lane owns query q, d = db*32 + 8g + 4*hsel + r
 #pragma unroll
   for (int jq = 0; jq < 2; ++jq) {
-    const float inv = 1.0f / (lrun[jq] + __shfl_xor(lrun[jq], 32, 64));
+    const float inv = 1.0f / (lrun[jq] + xhalf(lrun[jq]));
     half_t* orow = O + ((long)img * T + q0 + jq * 32 + l31) * D + head * 64;
 #pragma unroll
     for (int db = 0; db < 2; ++db)

@@ -113,6 +113,7 @@ class DiT(nn.Module):
         self.initialize_weights()
         self._packed = None
         self._ws = None
+        self._gen = 0  # bumped whenever device buffers a captured graph may point to are replaced
 
     # ---- init: same distributions as reference DiT.py:193-228 (incl. the adaLN-Zero / zero output layer)
     def initialize_weights(self):
@@ -175,6 +176,7 @@ class DiT(nn.Module):
         }
         w = hip.DitWeights(**{k: v.data_ptr() for k, v in keep.items()})
         self._packed = (w, keep, self.shape_struct())
+        self._gen += 1
         return self._packed
 
     def _workspace(self, batch, device):
@@ -184,6 +186,7 @@ class DiT(nn.Module):
             if nbytes == 0:
                 raise hip.LfmHipError(f"DiT shape not supported by the HIP path: {self.extra_repr()}")
             self._ws = (batch, torch.empty(nbytes, dtype=torch.uint8, device=device))
+            self._gen += 1
         return self._ws[1]
 
     def extra_repr(self):

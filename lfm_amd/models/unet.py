@@ -131,6 +131,7 @@ class UNetModel(nn.Module):
             p.detach().zero_()
         self._packed = None
         self._scratch = None
+        self._gen = 0  # bumped whenever device buffers a captured graph may point to are replaced
 
     # ---- packing ------------------------------------------------------------------------------------------------------
     def _apply(self, fn, *a, **k):
@@ -188,6 +189,7 @@ class UNetModel(nn.Module):
             raise hip.LfmHipError("output conv with more than 4 channels is not built")
         P["conv_out"] = (f16(w4.permute(0, 2, 3, 1).reshape(4, -1)), f32(b4))
         self._packed = P
+        self._gen += 1
         return P
 
     # ---- op helpers (all enqueue on torch's current stream) -------------------------------------------------------------
@@ -196,6 +198,7 @@ class UNetModel(nn.Module):
         need = hip.lib().lfm_groupnorm_scratch_bytes(N, Cch)
         if self._scratch is None or self._scratch.numel() < need or self._scratch.device != x.device:
             self._scratch = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=x.device)
+            self._gen += 1
         hip.check(hip.lib().lfm_groupnorm_f16(hip.ptr(x), hip.ptr(y), hip.ptr(gb[0]), hip.ptr(gb[1]), hip.ptr(film),
                                               film.stride(0) if film is not None else 0, hip.ptr(self._scratch), N, HW, Cch, 1e-5,
                                               1 if silu else 0, hip.stream_ptr(x.device)), "lfm_groupnorm_f16")

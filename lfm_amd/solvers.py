@@ -231,6 +231,7 @@ class GraphedFixedGrid:
         self.ts = self.dts = None
         self.use_graph = graph
         self.graphs = {}
+        self._graph_gen = -1  # model buffer generation the graphs were captured against
 
     def set_grid(self, ts, dts):
         self.ts = ts.to(self.dev, torch.float32).contiguous()
@@ -267,6 +268,10 @@ class GraphedFixedGrid:
         fn = self._euler if kind == "euler" else self._heun
         if not self.use_graph:
             return fn
+        if self._graph_gen != getattr(self.model, "_gen", 0):
+            # weights were re-packed / a workspace was re-allocated (load_state_dict, .to(), bigger batch elsewhere): the
+            # captured graphs hold stale device pointers -> drop them
+            self.graphs.clear()
         if kind not in self.graphs:
             # warm up on a side stream (packs weights, sizes the workspace, sets kernel attributes), then capture
             side = torch.cuda.Stream(self.dev)
@@ -283,6 +288,7 @@ class GraphedFixedGrid:
             self.x.copy_(saved[0])
             self.step.copy_(saved[1])
             self.graphs[kind] = g
+            self._graph_gen = getattr(self.model, "_gen", 0)
         return self.graphs[kind].replay
 
     @torch.no_grad()

@@ -86,3 +86,23 @@ def test_dopri5_on_hip_model_vs_oracle():
     ref = ode_ref.odeint(lambda tt, xx: dit_ref.dit_forward(sd, cfg, tt, xx), x0, t, method="dopri5", rtol=1e-3, atol=1e-3, stats=sb)
     assert rel_l2(got[-1], ref[-1]) < 2e-3
     assert abs(sa["steps"] - sb["steps"]) <= 1
+
+
+def test_captured_graph_follows_weight_reload():
+    """A captured solver graph holds raw device pointers; reloading weights re-packs them, so the graph must be re-captured."""
+    from lfm_amd.solvers import GraphedFixedGrid, torchdiffeq_euler_grid
+
+    dev = torch.device("cuda:0")
+    cfg, sd1, m = _mk("DiT-S/2", dev, num_classes=1, label_dropout=0.0)
+    sd2 = dit_ref.make_dit_state(cfg, seed=77)
+    x0 = torch.randn(2, 4, 32, 32, generator=torch.Generator().manual_seed(9)).to(dev)
+    ts, dts = torchdiffeq_euler_grid(0.5)
+    s = GraphedFixedGrid(m, 2)
+    s.set_grid(ts, dts)
+    a = s.run(x0).clone()
+    m.load_state_dict(sd2, strict=True)
+    b = s.run(x0).clone()  # same solver object, new weights
+    ref = ode_ref.odeint(lambda t, x: dit_ref.dit_forward(sd2, cfg, t, x), x0.cpu(), torch.tensor([1.0, 0.0]), method="euler",
+                         options={"step_size": 0.5})[-1]
+    assert rel_l2(b, ref) < 1e-3
+    assert rel_l2(a, ref) > 1e-2  # and it really was a different model before
