@@ -140,11 +140,13 @@ class DiT(nn.Module):
     # ---- any parameter movement / reload invalidates the packed fp16 operands
     def _apply(self, fn, *a, **k):
         self._packed = None
+        self._gen = getattr(self, "_gen", 0) + 1
         self._ws = None
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
         self._packed = None
+        self._gen = getattr(self, "_gen", 0) + 1
         return super().load_state_dict(*a, **k)
 
     def shape_struct(self):

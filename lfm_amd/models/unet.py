@@ -136,11 +136,13 @@ class UNetModel(nn.Module):
     # ---- packing ------------------------------------------------------------------------------------------------------
     def _apply(self, fn, *a, **k):
         self._packed = None
+        self._gen = getattr(self, "_gen", 0) + 1
         self._scratch = None
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
         self._packed = None
+        self._gen = getattr(self, "_gen", 0) + 1
         return super().load_state_dict(*a, **k)
 
     @torch.no_grad()
