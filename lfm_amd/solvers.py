@@ -228,14 +228,22 @@ class GraphedFixedGrid:
         self.dt = torch.zeros(1, device=dev)
         self.c1 = torch.ones(1, device=dev)
         self.c2 = torch.full((2,), 0.5, device=dev)
-        self.ts = self.dts = None
+        self.max_intervals = 4096
+        self.ts = torch.zeros(self.max_intervals + 1, device=dev)  # persistent: the captured graphs read these addresses
+        self.dts = torch.zeros(self.max_intervals, device=dev)
+        self.n_intervals = 0
         self.use_graph = graph
         self.graphs = {}
         self._graph_gen = -1  # model buffer generation the graphs were captured against
 
     def set_grid(self, ts, dts):
-        self.ts = ts.to(self.dev, torch.float32).contiguous()
-        self.dts = dts.to(self.dev, torch.float32).contiguous()
+        """Copy a time grid (n+1 times, n signed steps) INTO the persistent device buffers the captured graphs point at."""
+        n = dts.numel()
+        if ts.numel() != n + 1 or n < 1 or n > self.max_intervals:
+            raise ValueError(f"grid with {ts.numel()} times / {n} steps (max {self.max_intervals} intervals)")
+        self.ts[: n + 1].copy_(ts.to(torch.float32))
+        self.dts[:n].copy_(dts.to(torch.float32))
+        self.n_intervals = n
 
     def _advance(self):
         hip.check(hip.lib().lfm_grid_advance(hip.ptr(self.ts), hip.ptr(self.dts), hip.ptr(self.step), hip.ptr(self.tcur), hip.ptr(self.tnext),
@@ -295,8 +303,8 @@ class GraphedFixedGrid:
     def run(self, x0, heun_limit=0):
         """Integrate over the whole grid.  heun_limit = number of leading intervals... see karras_sample: the corrector is
         applied on interval i iff i < heun_limit - 1;  heun_limit = 0 means plain Euler."""
-        assert self.ts is not None, "set_grid first"
-        n = self.dts.numel()
+        assert self.n_intervals > 0, "set_grid first"
+        n = self.n_intervals
         self.x.copy_(x0)
         self.step.zero_()
         n_heun = max(0, min(n, heun_limit - 1)) if heun_limit else 0

@@ -106,3 +106,21 @@ def test_captured_graph_follows_weight_reload():
                          options={"step_size": 0.5})[-1]
     assert rel_l2(b, ref) < 1e-3
     assert rel_l2(a, ref) > 1e-2  # and it really was a different model before
+
+
+def test_fused_sampler_survives_repeated_calls_and_grid_changes():
+    """The captured graph reads the time grid from persistent device buffers: repeated calls, other allocations in between and a
+    different grid must all give the eager answer."""
+    from lfm_amd.test_flow_latent import sample_from_model
+
+    dev = torch.device("cuda:0")
+    cfg, sd, m = _mk("DiT-S/2", dev, num_classes=1, label_dropout=0.0)
+    x0 = torch.randn(2, 4, 32, 32, generator=torch.Generator().manual_seed(4)).to(dev)
+    for h in (0.25, 0.25, 0.125, 0.25):
+        junk = [torch.randn(1 << 16, device=dev) for _ in range(8)]  # churn the allocator between calls
+        args = Namespace(method="euler", step_size=h, perturb=False, compute_nfe=False, cfg_scale=1.0, atol=1e-5, rtol=1e-5)
+        fused = sample_from_model(m, x0, {}, args)[-1]
+        args.fused = False
+        eager = sample_from_model(m, x0, {}, args)[-1]
+        assert rel_l2(fused, eager) < 1e-5, h
+        del junk
