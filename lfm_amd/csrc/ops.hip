@@ -142,39 +142,54 @@ extern "C" int lfm_linear_f16(const void* A, long lda, const void* W, long ldw, 
                           EpiResidF16{(half_t*)C, ldc, bias, (const half_t*)resid}, (hipStream_t)stream);
 }
 
-// ------------------------------------------------------------------ first conv: fp32 NCHW (Cin <= 8) -> fp16 NHWC
+// ------------------------------------------------------------------ first conv: fp32 NCHW (Cin <= 16) -> fp16 NHWC
+// Weights are transposed into LDS as [k = (c,ky,kx)][Cout] so the 8 output channels of a thread are two float4 reads per tap;
+// a block walks CI_PIX pixels (threads = Cout/8 channel-octets x pixel rows), input taps are L1-served broadcast loads.
+#define CI_PIX 256
 __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
                                                       half_t* __restrict__ out, int N, int H, int W, int Cin, int Cout) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int c8 = Cout / 8;
-  if (idx >= (long)N * H * W * c8) return;
-  const int co = (int)(idx % c8) * 8;
-  const long pix = idx / c8;
-  const int xx = (int)(pix % W), yy = (int)((pix / W) % H), n = (int)(pix / ((long)H * W));
-  float acc[8];
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // [Cin*9][Cout]
+  const int KK = Cin * 9, c8n = Cout / 8;
+  for (int e = threadIdx.x; e < KK * Cout; e += 256) {
+    const int co = e / KK, k = e - co * KK;  // w is [Cout][Cin][3][3] = [Cout][KK]
+    wl[k * Cout + co] = w[e];
+  }
+  __syncthreads();
+  const int oct = threadIdx.x % c8n, prow = threadIdx.x / c8n, rows = 256 / c8n;
+  if (prow >= rows) return;
+  const int co = oct * 8;
+  const long total = (long)N * H * W;
+  const long p0 = (long)blockIdx.x * CI_PIX;
+  for (long pix = p0 + prow; pix < p0 + CI_PIX && pix < total; pix += rows) {
+    const int xx = (int)(pix % W), yy = (int)((pix / W) % H), n = (int)(pix / ((long)H * W));
+    f32x4 a0 = *(const f32x4*)(b + co), a1 = *(const f32x4*)(b + co + 4);
+    for (int c = 0; c < Cin; ++c)
 #pragma unroll
-  for (int j = 0; j < 8; ++j) acc[j] = b[co + j];
-  for (int ky = 0; ky < 3; ++ky)
-    for (int kx = 0; kx < 3; ++kx) {
-      const int iy = yy + ky - 1, ix = xx + kx - 1;
-      if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) continue;
-      for (int c = 0; c < Cin; ++c) {
+      for (int t = 0; t < 9; ++t) {
+        const int iy = yy + t / 3 - 1, ix = xx + t % 3 - 1;
+        if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) continue;
         const float v = x[(((long)n * Cin + c) * H + iy) * W + ix];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += w[(((long)(co + j) * Cin + c) * 3 + ky) * 3 + kx] * v;
+        const float* wr = wl + (c * 9 + t) * Cout + co;
+        a0 += v * *(const f32x4*)wr;
+        a1 += v * *(const f32x4*)(wr + 4);
       }
-    }
-  half8_t h;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) h[j] = (half_t)acc[j];
-  *(half8_t*)(out + pix * Cout + co) = h;
+    half8_t h = {(half_t)a0.x, (half_t)a0.y, (half_t)a0.z, (half_t)a0.w, (half_t)a1.x, (half_t)a1.y, (half_t)a1.z, (half_t)a1.w};
+    *(half8_t*)(out + pix * Cout + co) = h;
+  }
 }
 
 extern "C" int lfm_conv3x3_in_f32(const float* x_nchw, const float* w, const float* bias, void* out_nhwc, int N, int H, int W, int Cin,
                                   int Cout, lfm_stream_t stream) {
   if (!x_nchw || !w || !bias || !out_nhwc) return LFM_ERR_ARG;
-  if (N <= 0 || Cin <= 0 || Cin > 16 || Cout % 8) return LFM_ERR_SHAPE;
-  hipLaunchKernelGGL(conv_in_kernel, dim3(cdiv((long)N * H * W * (Cout / 8), 256)), dim3(256), 0, (hipStream_t)stream, x_nchw, w, bias,
+  if (N <= 0 || Cin <= 0 || Cin > 16 || Cout % 8 || Cout / 8 > 256) return LFM_ERR_SHAPE;
+  const size_t lds = (size_t)Cin * 9 * Cout * 4;
+  if (lds > 160 * 1024) return LFM_ERR_SHAPE;
+  static bool set = false;
+  if (!set) {
+    if (hipFuncSetAttribute((const void*)conv_in_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return LFM_ERR_LAUNCH;
+    set = true;
+  }
+  hipLaunchKernelGGL(conv_in_kernel, dim3(cdiv((long)N * H * W, CI_PIX)), dim3(256), lds, (hipStream_t)stream, x_nchw, w, bias,
                      (half_t*)out_nhwc, N, H, W, Cin, Cout);
   LFM_CHECK_LAUNCH();
   return LFM_OK;
@@ -221,6 +236,50 @@ __global__ __launch_bounds__(256) void gn_stats_general_kernel(const half_t* __r
   if (threadIdx.x == 0) {
     atomicAdd(&stats[((long)n * 32 + g) * 2], rs[0] + rs[1] + rs[2] + rs[3]);
     atomicAdd(&stats[((long)n * 32 + g) * 2 + 1], rq[0] + rq[1] + rq[2] + rq[3]);
+  }
+}
+
+// fast path (cpg % 4 == 0, C/8 <= 256): a block reads a slab of pixels with FULL rows (coalesced); thread = channel octet x pixel
+// row; per half-octet partial sums are folded through LDS and leave as one atomic pair per half-octet per block.
+__global__ __launch_bounds__(256) void gn_stats_rows_kernel(const half_t* __restrict__ x, float* __restrict__ stats, int HW, int C, int pix_per_block) {
+  __shared__ float red[4][256];
+  const int n = blockIdx.y, c8n = C / 8, tid = threadIdx.x;
+  const int rows = 256 / c8n;
+  const int oct = tid % c8n, prow = tid / c8n;
+  const int p0 = blockIdx.x * pix_per_block;
+  const int p1 = min(p0 + pix_per_block, HW);
+  float s[2] = {0.f, 0.f}, q[2] = {0.f, 0.f};
+  if (prow < rows) {
+    const half_t* base = x + (long)n * HW * C + oct * 8;
+    for (int p = p0 + prow; p < p1; p += rows) {
+      const half8_t v = *(const half8_t*)(base + (long)p * C);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float f = (float)v[j];
+        s[j >> 2] += f;
+        q[j >> 2] += f * f;
+      }
+    }
+  }
+  red[0][tid] = s[0];
+  red[1][tid] = s[1];
+  red[2][tid] = q[0];
+  red[3][tid] = q[1];
+  __syncthreads();
+  if (tid < c8n) {
+    for (int r = 1; r < rows; ++r) {
+      s[0] += red[0][tid + r * c8n];
+      s[1] += red[1][tid + r * c8n];
+      q[0] += red[2][tid + r * c8n];
+      q[1] += red[3][tid + r * c8n];
+    }
+    const int cpg = C / 32;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int g = (tid * 8 + hh * 4) / cpg;
+      atomicAdd(&stats[((long)n * 32 + g) * 2 + 0], s[hh]);
+      atomicAdd(&stats[((long)n * 32 + g) * 2 + 1], q[hh]);
+    }
   }
 }
 
@@ -279,10 +338,15 @@ extern "C" int lfm_groupnorm_f16(const void* x, void* y, const float* gamma, con
   float* ab = (float*)((char*)scratch + (((size_t)N * 64 * 4 + 255) / 256) * 256);
   if (hipMemsetAsync(stats, 0, (size_t)N * 64 * 4, st) != hipSuccess) return LFM_ERR_LAUNCH;
   const int cpg = C / 32;
-  const int ppb = 2048;
-  dim3 grid(32, N, cdiv(HW, ppb));
-  if (cpg % 4 == 0) hipLaunchKernelGGL(gn_stats_general_kernel<4>, grid, dim3(256), 0, st, (const half_t*)x, stats, HW, C, cpg, ppb);
-  else hipLaunchKernelGGL(gn_stats_general_kernel<1>, grid, dim3(256), 0, st, (const half_t*)x, stats, HW, C, cpg, ppb);
+  if (cpg % 4 == 0 && C / 8 <= 256) {
+    const int ppb = HW >= 4096 ? 512 : (HW >= 256 ? 64 : HW);
+    hipLaunchKernelGGL(gn_stats_rows_kernel, dim3(cdiv(HW, ppb), N), dim3(256), 0, st, (const half_t*)x, stats, HW, C, ppb);
+  } else {
+    const int ppb = 2048;
+    dim3 grid(32, N, cdiv(HW, ppb));
+    if (cpg % 4 == 0) hipLaunchKernelGGL(gn_stats_general_kernel<4>, grid, dim3(256), 0, st, (const half_t*)x, stats, HW, C, cpg, ppb);
+    else hipLaunchKernelGGL(gn_stats_general_kernel<1>, grid, dim3(256), 0, st, (const half_t*)x, stats, HW, C, cpg, ppb);
+  }
   LFM_CHECK_LAUNCH();
   hipLaunchKernelGGL(gn_coef_kernel, dim3(cdiv((long)N * C, 256)), dim3(256), 0, st, stats, gamma, beta, film, film_stride, ab, N, C, cpg,
                      (float)HW * (float)cpg, eps);

@@ -131,36 +131,42 @@ struct EpiConvOutNCHW {  // final conv (Cout=3, padded to 4): fp32 NCHW image, t
 // ------------------------------------------------------------------ post_quant_conv (1x1, 4->4) + conv_in (3x3, 4->Cout)
 // z fp32 NCHW [N,4,R,R] -> fp16 NHWC [N,R,R,Cout].  conv_in sees post_quant(z) zero-padded, so the 1x1 is
 // evaluated per tap and skipped (=0) outside the image.  One thread = one pixel x 8 output channels.
+#define VCI_PIX 256
 __global__ __launch_bounds__(256) void vae_conv_in_kernel(const float* __restrict__ z, const float* __restrict__ pq_w,
                                                           const float* __restrict__ pq_b, const float* __restrict__ w,
                                                           const float* __restrict__ b, half_t* __restrict__ out, int N, int R, int Cout) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int c8 = Cout / 8;
-  if (idx >= (long)N * R * R * c8) return;
-  const int co = (int)(idx % c8) * 8;
-  const long pix = idx / c8;
-  const int x = (int)(pix % R), y = (int)((pix / R) % R), n = (int)(pix / ((long)R * R));
-  float acc[8];
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // conv_in weights transposed to [k = (c,ky,kx)][Cout]
+  for (int e = threadIdx.x; e < 36 * Cout; e += 256) {
+    const int co = e / 36, k = e - co * 36;
+    wl[k * Cout + co] = w[e];
+  }
+  __syncthreads();
+  const int c8n = Cout / 8, rows = 256 / c8n;
+  const int oct = threadIdx.x % c8n, prow = threadIdx.x / c8n;
+  if (prow >= rows) return;
+  const int co = oct * 8;
+  const long total = (long)N * R * R, p0 = (long)blockIdx.x * VCI_PIX;
+  for (long pix = p0 + prow; pix < p0 + VCI_PIX && pix < total; pix += rows) {
+    const int x = (int)(pix % R), y = (int)((pix / R) % R), n = (int)(pix / ((long)R * R));
+    f32x4 a0 = *(const f32x4*)(b + co), a1 = *(const f32x4*)(b + co + 4);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) acc[j] = b[co + j];
-  for (int ky = 0; ky < 3; ++ky)
-    for (int kx = 0; kx < 3; ++kx) {
-      const int iy = y + ky - 1, ix = x + kx - 1;
+    for (int t = 0; t < 9; ++t) {
+      const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
       if ((unsigned)iy >= (unsigned)R || (unsigned)ix >= (unsigned)R) continue;
-      float zi[4], pq[4];
+      float zi[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) zi[c] = z[(((long)n * 4 + c) * R + iy) * R + ix];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) pq[c] = pq_b[c] + pq_w[c * 4 + 0] * zi[0] + pq_w[c * 4 + 1] * zi[1] + pq_w[c * 4 + 2] * zi[2] + pq_w[c * 4 + 3] * zi[3];
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[j] += w[(((long)(co + j) * 4 + c) * 3 + ky) * 3 + kx] * pq[c];
+      for (int c = 0; c < 4; ++c) {
+        const float pq = pq_b[c] + pq_w[c * 4 + 0] * zi[0] + pq_w[c * 4 + 1] * zi[1] + pq_w[c * 4 + 2] * zi[2] + pq_w[c * 4 + 3] * zi[3];
+        const float* wr = wl + (c * 9 + t) * Cout + co;
+        a0 += pq * *(const f32x4*)wr;
+        a1 += pq * *(const f32x4*)(wr + 4);
+      }
     }
-  half8_t h;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) h[j] = (half_t)acc[j];
-  *(half8_t*)(out + pix * Cout + co) = h;
+    half8_t h = {(half_t)a0.x, (half_t)a0.y, (half_t)a0.z, (half_t)a0.w, (half_t)a1.x, (half_t)a1.y, (half_t)a1.z, (half_t)a1.w};
+    *(half8_t*)(out + pix * Cout + co) = h;
+  }
 }
 
 // ------------------------------------------------------------------ GroupNorm(32 groups, eps 1e-6) on NHWC fp16
@@ -351,8 +357,16 @@ extern "C" int lfm_vae_decode(const lfm_vae_weights* w, void* workspace, size_t 
   for (int n0 = 0; n0 < N; n0 += chunk) {
     const int n = (N - n0 < chunk) ? N - n0 : chunk;
     half_t *x = ws.b0, *t1 = ws.b1, *t2 = ws.b2, *t3 = ws.b3;
-    hipLaunchKernelGGL(vae_conv_in_kernel, dim3(cdiv((long)n * T * 64, 256)), dim3(256), 0, st, z + (long)n0 * 4 * T, w->pq_w, w->pq_b, w->cin_w,
-                       w->cin_b, x, n, R, 512);
+    {
+      static bool set = false;
+      if (!set) {
+        if (hipFuncSetAttribute((const void*)vae_conv_in_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 36 * 512 * 4) != hipSuccess)
+          return LFM_ERR_LAUNCH;
+        set = true;
+      }
+    }
+    hipLaunchKernelGGL(vae_conv_in_kernel, dim3(cdiv((long)n * T, VCI_PIX)), dim3(256), 36 * 512 * 4, st, z + (long)n0 * 4 * T, w->pq_w, w->pq_b,
+                       w->cin_w, w->cin_b, x, n, R, 512);
     LFM_CHECK_LAUNCH();
     int H = R;
     RC(resnet(&w->mid[0], x, t1, t2, t3, ws, n, H, H, st));
