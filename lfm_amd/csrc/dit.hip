@@ -99,45 +99,56 @@ __global__ __launch_bounds__(320) void patch_embed_kernel(const float* __restric
 // ------------------------------------------------------------------ LayerNorm + modulate -> fp16 (DiT.py:20-21,119,129-130)
 // one wave per token row; the row stays in registers (<= 5 float4 per lane => D <= 1280).
 #define LN_MAXV 5
+#define LN_ROWS 2  // rows per wave: both rows' loads are issued before either reduction, doubling the bytes in flight per wave
 __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restrict__ X, half_t* __restrict__ A, int M, int D, int tokens,
                                                           const float* __restrict__ shift, const float* __restrict__ scale, long mod_stride) {
   const int lane = threadIdx.x & 63;
-  const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (m >= M) return;
+  const long m0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_ROWS;
+  if (m0 >= M) return;
   const int nv = D >> 2;
-  const f32x4* xr = (const f32x4*)(X + m * D);
-  f32x4 v[LN_MAXV];
-  float s = 0.f;
+  f32x4 v[LN_ROWS][LN_MAXV];
+  float s[LN_ROWS];
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nv) {
-      v[i] = xr[c];
-      s += v[i].x + v[i].y + v[i].z + v[i].w;
+  for (int r = 0; r < LN_ROWS; ++r) {
+    const long m = (m0 + r < M) ? m0 + r : M - 1;
+    const f32x4* xr = (const f32x4*)(X + m * D);
+    s[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nv) {
+        v[r][i] = xr[c];
+        s[r] += v[r][i].x + v[r][i].y + v[r][i].z + v[r][i].w;
+      }
     }
   }
-  const float mean = wave_sum(s) / (float)D;
-  float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nv) {
-      v[i] -= mean;
-      q += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+  for (int r = 0; r < LN_ROWS; ++r) {
+    const long m = m0 + r;
+    if (m >= M) break;
+    const float mean = wave_sum(s[r]) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nv) {
+        v[r][i] -= mean;
+        q += v[r][i].x * v[r][i].x + v[r][i].y * v[r][i].y + v[r][i].z * v[r][i].z + v[r][i].w * v[r][i].w;
+      }
     }
-  }
-  const float rstd = rsqrtf(wave_sum(q) / (float)D + 1e-6f);
-  const long mo = (m / tokens) * mod_stride;
-  const f32x4* sh = (const f32x4*)(shift + mo);
-  const f32x4* sc = (const f32x4*)(scale + mo);
-  half4_t* ar = (half4_t*)(A + m * D);
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + 1e-6f);
+    const long mo = (m / tokens) * mod_stride;
+    const f32x4* sh = (const f32x4*)(shift + mo);
+    const f32x4* sc = (const f32x4*)(scale + mo);
+    half4_t* ar = (half4_t*)(A + m * D);
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nv) {
-      const f32x4 o = v[i] * rstd * (1.0f + sc[c]) + sh[c];
-      half4_t h = {(half_t)o.x, (half_t)o.y, (half_t)o.z, (half_t)o.w};
-      ar[c] = h;
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nv) {
+        const f32x4 o = v[r][i] * rstd * (1.0f + sc[c]) + sh[c];
+        half4_t h = {(half_t)o.x, (half_t)o.y, (half_t)o.z, (half_t)o.w};
+        ar[c] = h;
+      }
     }
   }
 }
@@ -544,7 +555,7 @@ extern "C" int lfm_dit_attention(const void* Q, const void* K, const void* Vt, v
 static int ln_modulate_launch(const float* X, half_t* A, int M, int D, int tokens, const float* shift, const float* scale, long stride,
                               hipStream_t st) {
   if (D % 4 || D > 256 * LN_MAXV) return LFM_ERR_SHAPE;
-  hipLaunchKernelGGL(ln_modulate_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, X, A, M, D, tokens, shift, scale, stride);
+  hipLaunchKernelGGL(ln_modulate_kernel, dim3(cdiv(M, 4 * LN_ROWS)), dim3(256), 0, st, X, A, M, D, tokens, shift, scale, stride);
   LFM_CHECK_LAUNCH();
   return LFM_OK;
 }
