@@ -61,12 +61,25 @@ __global__ void cond_kernel(const float* __restrict__ temb, int t_len, const flo
 // X[n*T + tok][j] = b[j] + pos[tok][j] + sum_{c,p,q} W[j][c][p][q] * x[n % xmod][c][hp+p][wp+q]
 // blockDim = D/4 threads, thread = 4 consecutive output channels whose weight rows stay in registers (KK <= 16 here);
 // a block walks PE_TOK tokens, whose KK input values are wave-uniform loads.
-#define PE_TOK 4
+#define PE_TOK 16
 #define PE_MAXK 16
 __global__ __launch_bounds__(320) void patch_embed_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
                                                           const float* __restrict__ pos, float* __restrict__ X, int M, int xmod, int C, int R,
                                                           int p, int D) {
+  __shared__ float xs[PE_TOK][PE_MAXK];
   const int grid = R / p, T = grid * grid, KK = C * p * p;
+  const long m_begin = (long)blockIdx.x * PE_TOK;
+  for (int e = threadIdx.x; e < PE_TOK * PE_MAXK; e += blockDim.x) {  // stage the inputs: the token loop has no dependent global loads
+    const int tt = e / PE_MAXK, k = e % PE_MAXK;
+    const long m = m_begin + tt;
+    float v = 0.f;
+    if (m < M && k < KK) {
+      const int tok = (int)(m % T), n = (int)(m / T) % xmod;
+      const int c = k / (p * p), pp = (k / p) % p, q = k % p;
+      v = x[(((long)n * C + c) * R + (tok / grid) * p + pp) * R + (tok % grid) * p + q];
+    }
+    xs[tt][k] = v;
+  }
   const int j = threadIdx.x * 4;
   float wr[4][PE_MAXK];
 #pragma unroll
@@ -74,23 +87,20 @@ __global__ __launch_bounds__(320) void patch_embed_kernel(const float* __restric
 #pragma unroll
     for (int k = 0; k < PE_MAXK; ++k) wr[i][k] = (k < KK) ? w[(long)(j + i) * KK + k] : 0.f;
   const f32x4 bias = *(const f32x4*)(b + j);
-  const long m_begin = (long)blockIdx.x * PE_TOK;
+  __syncthreads();
+#pragma unroll 4
   for (int tt = 0; tt < PE_TOK; ++tt) {
     const long m = m_begin + tt;
     if (m >= M) break;
-    const int tok = (int)(m % T), n = (int)(m / T) % xmod;
-    const int hp = (tok / grid) * p, wp = (tok % grid) * p;
+    const int tok = (int)(m % T);
     f32x4 acc = bias + *(const f32x4*)(pos + (long)tok * D + j);
 #pragma unroll
     for (int k = 0; k < PE_MAXK; ++k) {
-      if (k < KK) {
-        const int c = k / (p * p), pp = (k / p) % p, q = k % p;
-        const float xv = x[(((long)n * C + c) * R + hp + pp) * R + wp + q];
-        acc.x += wr[0][k] * xv;
-        acc.y += wr[1][k] * xv;
-        acc.z += wr[2][k] * xv;
-        acc.w += wr[3][k] * xv;
-      }
+      const float xv = xs[tt][k];
+      acc.x += wr[0][k] * xv;
+      acc.y += wr[1][k] * xv;
+      acc.z += wr[2][k] * xv;
+      acc.w += wr[3][k] * xv;
     }
     *(f32x4*)(X + m * D + j) = acc;
   }
@@ -316,113 +326,107 @@ __global__ __launch_bounds__(T, 2) void dit_attention_kernel(const half_t* __res
 
 // ------------------------------------------------------------------ final layer + unpatchify + solver update
 // (DiT.py:134-149,230-243,270-271; CFG combine :285-287; Euler update test_flow_latent.py:61-73 via torchdiffeq)
-// one wave per token (pair of tokens under CFG).  out[n][c][hp+p][wp+q] = base + dt * v, v = linear(modulate(LN(x)))[(p*P+q)*C + c]
-#define FIN_MAXO 64
+// out[n][c][hp+p][wp+q] = base + dt * v,  v = linear(modulate(LN(x)))[(p*P+q)*C + c].
+// One wave owns FOUR token rows (under CFG: two conditional tokens and their two unconditional twins), so every row of the
+// output matrix Wf is fetched once per four tokens; the 4 x 16 per-lane partial dot products are then reduced with a 6-step
+// butterfly reduce-scatter (63 exchanges) that leaves lane l with the finished value of (row l>>4, output l&15).
+#define FIN_MAXO 16
 template <bool CFG>
 __global__ __launch_bounds__(256) void final_layer_kernel(const float* __restrict__ X, int M, int D, int tokens, const float* __restrict__ shift,
                                                           const float* __restrict__ scale, long mod_stride, const float* __restrict__ Wf,
                                                           const float* __restrict__ bf, int C, int R, int p, float cfg_scale,
                                                           float* out, const float* base, const float* __restrict__ dt_ptr) {
   const int lane = threadIdx.x & 63;
-  const long mrow = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long wg = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int Mh = CFG ? M / 2 : M;
-  if (mrow >= Mh) return;
+  const long mfirst = CFG ? wg * 2 : wg * 4;
+  if (mfirst >= Mh) return;
   const int nv = D >> 2, NO = p * p * C;
-  float res[2] = {0.f, 0.f};  // lane o < NO holds output o of (cond, uncond)
+  long mrow[4];
 #pragma unroll
-  for (int half = 0; half < (CFG ? 2 : 1); ++half) {
-    const long m = mrow + (long)half * Mh;
-    const f32x4* xr = (const f32x4*)(X + m * D);
-    f32x4 v[LN_MAXV];
-    float s = 0.f;
+  for (int r = 0; r < 4; ++r) {
+    long m = CFG ? mfirst + (r & 1) + (long)(r >> 1) * Mh : mfirst + r;
+    mrow[r] = m < M ? m : M - 1;
+  }
+  f32x4 v[4][LN_MAXV];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const f32x4* xr = (const f32x4*)(X + mrow[r] * D);
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
       const int c = lane + 64 * i;
-      if (c < nv) {
-        v[i] = xr[c];
-        s += v[i].x + v[i].y + v[i].z + v[i].w;
-      }
+      if (c < nv) v[r][i] = xr[c];
     }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i)
+      if (lane + 64 * i < nv) s += v[r][i].x + v[r][i].y + v[r][i].z + v[r][i].w;
     const float mean = wave_sum(s) / (float)D;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      const int c = lane + 64 * i;
-      if (c < nv) {
-        v[i] -= mean;
-        q += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+    for (int i = 0; i < LN_MAXV; ++i)
+      if (lane + 64 * i < nv) {
+        v[r][i] -= mean;
+        q += v[r][i].x * v[r][i].x + v[r][i].y * v[r][i].y + v[r][i].z * v[r][i].z + v[r][i].w * v[r][i].w;
       }
-    }
     const float rstd = rsqrtf(wave_sum(q) / (float)D + 1e-6f);
-    const long mo = (m / tokens) * mod_stride;
+    const long mo = (mrow[r] / tokens) * mod_stride;
     const f32x4* sh = (const f32x4*)(shift + mo);
     const f32x4* sc = (const f32x4*)(scale + mo);
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
       const int c = lane + 64 * i;
-      if (c < nv) v[i] = v[i] * rstd * (1.0f + sc[c]) + sh[c];
-    }
-    // NO (<= 64) dot products of length D: per-lane partials for 16 outputs at a time, then a butterfly that halves the
-    // number of live values per exchange (16 -> 1 in 4 steps) instead of 16 full wave reductions.
-    for (int ob = 0; ob < NO; ob += 16) {
-      float part[16];
-#pragma unroll
-      for (int o = 0; o < 16; ++o) {
-        float a = 0.f;
-        if (ob + o < NO) {
-          const f32x4* wr = (const f32x4*)(Wf + (long)(ob + o) * D);
-#pragma unroll
-          for (int i = 0; i < LN_MAXV; ++i) {
-            const int c = lane + 64 * i;
-            if (c < nv) {
-              const f32x4 w4 = wr[c];
-              a += v[i].x * w4.x + v[i].y * w4.y + v[i].z * w4.z + v[i].w * w4.w;
-            }
-          }
-        }
-        part[o] = a;
-      }
-      // step s exchanges with lane ^ (32 >> s) and keeps the half of the values selected by that lane bit
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int width = 16 >> s, half_w = width >> 1, mask = 32 >> s;
-        const bool upper = (lane & mask) != 0;
-#pragma unroll
-        for (int k = 0; k < half_w; ++k) {
-          const float keep = upper ? part[k + half_w] : part[k];
-          const float send = upper ? part[k] : part[k + half_w];
-          part[k] = keep + __shfl_xor(send, mask, 64);
-        }
-      }
-      // part[0] now holds output index o = (lane>>2)&15 bit-reversed ... summed over 16 lanes groups; finish over the low 2 bits
-      float r = part[0];
-      r += __shfl_xor(r, 2, 64);
-      r += __shfl_xor(r, 1, 64);
-      // which output does this lane hold?  bit (32>>s) of the lane selected the upper half at step s => o = b5*8 + b4*4 + b3*2 + b2
-      const int o_here = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
-      // lane o (< NO) must end up with output o: fetch it from lane src whose o_here == o - ob
-      const int want = lane - ob;
-      const int src = ((want >> 3) & 1) * 32 + ((want >> 2) & 1) * 16 + ((want >> 1) & 1) * 8 + (want & 1) * 4;
-      const float got = __shfl(r, (want >= 0 && want < 16) ? src : lane, 64);
-      if (want >= 0 && want < 16 && lane < NO) res[half] = got + bf[lane];
-      (void)o_here;
+      if (c < nv) v[r][i] = v[r][i] * rstd * (1.0f + sc[c]) + sh[c];
     }
   }
-  if (lane < NO) {
-    float v = CFG ? res[1] + cfg_scale * (res[0] - res[1]) : res[0];
-    const int grid = R / p;
-    const int n = (int)(mrow / tokens), tok = (int)(mrow % tokens);
-    const int pp = lane / (p * C), qq = (lane / C) % p, c = lane % C;
-    const long off = (((long)n * C + c) * R + (tok / grid) * p + pp) * R + (tok % grid) * p + qq;
-    const long hoff = (long)(Mh / tokens) * C * R * R;  // second (uncond) half of the batch
-    if (base) {
-      const float dt = *dt_ptr;
-      out[off] = base[off] + dt * v;
-      if (CFG) out[off + hoff] = base[off + hoff] + dt * v;
-    } else {
-      out[off] = v;
-      if (CFG) out[off + hoff] = v;
+  float part[64];  // [r][o]
+#pragma unroll
+  for (int o = 0; o < 16; ++o) {
+    f32x4 w4[LN_MAXV];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = lane + 64 * i;
+      w4[i] = (o < NO && c < nv) ? ((const f32x4*)(Wf + (long)o * D))[c] : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < LN_MAXV; ++i)
+        if (lane + 64 * i < nv) a += v[r][i].x * w4[i].x + v[r][i].y * w4[i].y + v[r][i].z * w4[i].z + v[r][i].w * w4[i].w;
+      part[r * 16 + o] = a;
+    }
+  }
+  // reduce-scatter: at step s the lane bit (32 >> s) picks the upper/lower half of the remaining index range
+#pragma unroll
+  for (int s = 0; s < 6; ++s) {
+    const int half_w = 32 >> s, mask = 32 >> s;
+    const bool upper = (lane & mask) != 0;
+#pragma unroll
+    for (int k = 0; k < half_w; ++k) {
+      const float keep = upper ? part[k + half_w] : part[k];
+      const float send = upper ? part[k] : part[k + half_w];
+      part[k] = keep + __shfl_xor(send, mask, 64);
+    }
+  }
+  const int r = lane >> 4, o = lane & 15;
+  float val = part[0] + (o < NO ? bf[o] : 0.f);
+  if (CFG) {  // rows 0,1 conditional, rows 2,3 their unconditional twins: lane ^ 32 holds the twin's value
+    const float other = xhalf(val);
+    const float cond = r < 2 ? val : other, uncond = r < 2 ? other : val;
+    val = uncond + cfg_scale * (cond - uncond);
+  }
+  const long m = CFG ? mfirst + (r & 1) + (long)(r >> 1) * Mh : mfirst + r;
+  if (o < NO && m < M && (CFG || m < Mh)) {
+    const int grid = R / p;
+    const int n = (int)(m / tokens), tok = (int)(m % tokens);
+    const int pp = o / (p * C), qq = (o / C) % p, c = o % C;
+    const long off = (((long)n * C + c) * R + (tok / grid) * p + pp) * R + (tok % grid) * p + qq;
+    if (base) out[off] = base[off] + (*dt_ptr) * val;
+    else out[off] = val;
   }
 }
 
@@ -677,10 +681,10 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
   const float* fmod = ws.mod + (long)s->depth * 6 * D;
   const int Mh = cfg ? M / 2 : M;
   if (cfg)
-    hipLaunchKernelGGL(final_layer_kernel<true>, dim3(cdiv(Mh, 4)), dim3(256), 0, st, ws.X, M, D, T, fmod, fmod + D, mstride, w->final_w,
+    hipLaunchKernelGGL(final_layer_kernel<true>, dim3(cdiv(Mh, 8)), dim3(256), 0, st, ws.X, M, D, T, fmod, fmod + D, mstride, w->final_w,
                        w->final_b, s->in_ch, s->res, s->patch, c->cfg_scale, c->out, c->axpy_base, c->axpy_dt);
   else
-    hipLaunchKernelGGL(final_layer_kernel<false>, dim3(cdiv(Mh, 4)), dim3(256), 0, st, ws.X, M, D, T, fmod, fmod + D, mstride, w->final_w,
+    hipLaunchKernelGGL(final_layer_kernel<false>, dim3(cdiv(Mh, 16)), dim3(256), 0, st, ws.X, M, D, T, fmod, fmod + D, mstride, w->final_w,
                        w->final_b, s->in_ch, s->res, s->patch, 1.0f, c->out, c->axpy_base, c->axpy_dt);
   LFM_CHECK_LAUNCH();
   return LFM_OK;
