@@ -79,7 +79,7 @@ class _Decoder(nn.Module):
 class AutoencoderKL(nn.Module):
     """Decoder-only AutoencoderKL of the sd-vae-ft-mse architecture."""
 
-    def __init__(self, decode_chunk=16):
+    def __init__(self, decode_chunk=None):
         super().__init__()
         self.post_quant_conv = nn.Conv2d(4, 4, 1)
         self.decoder = _Decoder()
@@ -210,7 +210,10 @@ class AutoencoderKL(nn.Module):
         w, _ = self._packed or self._pack()
         z = z.contiguous().float()
         N, R = z.shape[0], z.shape[2]
-        chunk = min(self.decode_chunk, N)
+        # images per pass: bigger is faster (57.9 ms vs 65.9 ms per 64 images for 64 vs 16 at 256x256) and bounded by the
+        # 4 ping-pong activation buffers: auto = 64 images at 256x256 (8.6 GB), scaled by resolution (16 at 512x512)
+        chunk = self.decode_chunk or max(1, (64 * 32 * 32) // (R * R))
+        chunk = min(chunk, N)
         L = hip.lib()
         need = L.lfm_vae_workspace_bytes(R, chunk)
         if self._ws is None or self._ws.numel() < need or self._ws.device != z.device:

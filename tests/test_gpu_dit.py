@@ -187,6 +187,8 @@ def test_dit_matches_reference_golden(dev, golden_dir, which):
     ("DiT-B/2", 4, dict(num_classes=1, label_dropout=0.0)),      # BASELINE config 1 shape
     ("DiT-B/2", 6, dict(num_classes=1000, label_dropout=0.1)),   # config 4 shape (class-conditional)
     ("DiT-L/2", 3, dict(num_classes=1, label_dropout=0.0)),      # config 2 shape
+    ("DiT-S/2", 1, dict(num_classes=1, label_dropout=0.0)),      # batch 1 (--measure_time mode): a single 256-row tile
+    ("DiT-S/2", 65, dict(num_classes=10, label_dropout=0.1)),    # ragged everywhere: 65 M-tiles, N = 1152/384 not multiples of 256
 ])
 def test_dit_matches_oracle_fullsize(dev, name, batch, kw):
     from lfm_amd.models import DiT_models
