@@ -201,7 +201,7 @@ extern "C" int lfm_conv3x3_in_f32(const float* x_nchw, const float* w, const flo
 // 3) apply: y = silu?(x*a + b), 8 channels per thread
 template <int VEC>
 __global__ __launch_bounds__(256) void gn_stats_general_kernel(const half_t* __restrict__ x, float* __restrict__ stats, int HW, int C, int cpg,
-                                                               int pix_per_block) {
+                                                               int pix_per_block, int G) {
   const int g = blockIdx.x, n = blockIdx.y;
   const int p0 = blockIdx.z * pix_per_block, p1 = min(p0 + pix_per_block, HW);
   const int vpp = cpg / VEC;  // vectors per pixel in this group
@@ -234,14 +234,15 @@ __global__ __launch_bounds__(256) void gn_stats_general_kernel(const half_t* __r
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    atomicAdd(&stats[((long)n * 32 + g) * 2], rs[0] + rs[1] + rs[2] + rs[3]);
-    atomicAdd(&stats[((long)n * 32 + g) * 2 + 1], rq[0] + rq[1] + rq[2] + rq[3]);
+    atomicAdd(&stats[((long)n * G + g) * 2], rs[0] + rs[1] + rs[2] + rs[3]);
+    atomicAdd(&stats[((long)n * G + g) * 2 + 1], rq[0] + rq[1] + rq[2] + rq[3]);
   }
 }
 
 // fast path (cpg % 4 == 0, C/8 <= 256): a block reads a slab of pixels with FULL rows (coalesced); thread = channel octet x pixel
 // row; per half-octet partial sums are folded through LDS and leave as one atomic pair per half-octet per block.
-__global__ __launch_bounds__(256) void gn_stats_rows_kernel(const half_t* __restrict__ x, float* __restrict__ stats, int HW, int C, int pix_per_block) {
+__global__ __launch_bounds__(256) void gn_stats_rows_kernel(const half_t* __restrict__ x, float* __restrict__ stats, int HW, int C, int pix_per_block,
+                                                            int G) {
   __shared__ float red[4][256];
   const int n = blockIdx.y, c8n = C / 8, tid = threadIdx.x;
   const int rows = 256 / c8n;
@@ -273,24 +274,24 @@ __global__ __launch_bounds__(256) void gn_stats_rows_kernel(const half_t* __rest
       q[0] += red[2][tid + r * c8n];
       q[1] += red[3][tid + r * c8n];
     }
-    const int cpg = C / 32;
+    const int cpg = C / G;
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
       const int g = (tid * 8 + hh * 4) / cpg;
-      atomicAdd(&stats[((long)n * 32 + g) * 2 + 0], s[hh]);
-      atomicAdd(&stats[((long)n * 32 + g) * 2 + 1], q[hh]);
+      atomicAdd(&stats[((long)n * G + g) * 2 + 0], s[hh]);
+      atomicAdd(&stats[((long)n * G + g) * 2 + 1], q[hh]);
     }
   }
 }
 
 __global__ void gn_coef_kernel(const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
                                const float* __restrict__ film, long film_stride, float* __restrict__ ab, int N, int C, int cpg, float cnt,
-                               float eps) {
+                               float eps, int G) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N * C) return;
   const int n = i / C, c = i - n * C, g = c / cpg;
-  const float mean = stats[((long)n * 32 + g) * 2] / cnt;
-  const float var = fmaxf(stats[((long)n * 32 + g) * 2 + 1] / cnt - mean * mean, 0.f);
+  const float mean = stats[((long)n * G + g) * 2] / cnt;
+  const float var = fmaxf(stats[((long)n * G + g) * 2 + 1] / cnt - mean * mean, 0.f);
   const float rstd = rsqrtf(var + eps);
   float a = rstd * gamma[c], b = beta[c] - mean * rstd * gamma[c];
   if (film) {  // h = norm(h) * (1 + scale) + shift   (unet.py:229-232; film row = [scale(C) | shift(C)])
@@ -330,30 +331,76 @@ __global__ __launch_bounds__(256) void gn_affine_kernel(const half_t* __restrict
 extern "C" size_t lfm_groupnorm_scratch_bytes(int N, int C) { return (size_t)N * 64 * 4 + (size_t)N * C * 8 + 256; }
 
 extern "C" int lfm_groupnorm_f16(const void* x, void* y, const float* gamma, const float* beta, const float* film, long film_stride, void* scratch,
-                                 int N, int HW, int C, float eps, int silu, lfm_stream_t stream) {
+                                 int N, int HW, int C, int groups, float eps, int silu, lfm_stream_t stream) {
   if (!x || !y || !gamma || !beta || !scratch) return LFM_ERR_ARG;
-  if (N <= 0 || HW <= 0 || C % 32 || C % 8) return LFM_ERR_SHAPE;
+  if (N <= 0 || HW <= 0 || groups <= 0 || groups > 32 || C % groups || C % 8) return LFM_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   float* stats = (float*)scratch;
   float* ab = (float*)((char*)scratch + (((size_t)N * 64 * 4 + 255) / 256) * 256);
   if (hipMemsetAsync(stats, 0, (size_t)N * 64 * 4, st) != hipSuccess) return LFM_ERR_LAUNCH;
-  const int cpg = C / 32;
+  const int G = groups, cpg = C / G;
   if (cpg % 4 == 0 && C / 8 <= 256) {
     const int ppb = HW >= 4096 ? 512 : (HW >= 256 ? 64 : HW);
-    hipLaunchKernelGGL(gn_stats_rows_kernel, dim3(cdiv(HW, ppb), N), dim3(256), 0, st, (const half_t*)x, stats, HW, C, ppb);
+    hipLaunchKernelGGL(gn_stats_rows_kernel, dim3(cdiv(HW, ppb), N), dim3(256), 0, st, (const half_t*)x, stats, HW, C, ppb, G);
   } else {
     const int ppb = 2048;
-    dim3 grid(32, N, cdiv(HW, ppb));
-    if (cpg % 4 == 0) hipLaunchKernelGGL(gn_stats_general_kernel<4>, grid, dim3(256), 0, st, (const half_t*)x, stats, HW, C, cpg, ppb);
-    else hipLaunchKernelGGL(gn_stats_general_kernel<1>, grid, dim3(256), 0, st, (const half_t*)x, stats, HW, C, cpg, ppb);
+    dim3 grid(G, N, cdiv(HW, ppb));
+    if (cpg % 4 == 0) hipLaunchKernelGGL(gn_stats_general_kernel<4>, grid, dim3(256), 0, st, (const half_t*)x, stats, HW, C, cpg, ppb, G);
+    else hipLaunchKernelGGL(gn_stats_general_kernel<1>, grid, dim3(256), 0, st, (const half_t*)x, stats, HW, C, cpg, ppb, G);
   }
   LFM_CHECK_LAUNCH();
   hipLaunchKernelGGL(gn_coef_kernel, dim3(cdiv((long)N * C, 256)), dim3(256), 0, st, stats, gamma, beta, film, film_stride, ab, N, C, cpg,
-                     (float)HW * (float)cpg, eps);
+                     (float)HW * (float)cpg, eps, G);
   LFM_CHECK_LAUNCH();
   const long total8 = (long)N * HW * C / 8;
   if (silu) hipLaunchKernelGGL(gn_affine_kernel<true>, dim3(cdiv(total8, 256)), dim3(256), 0, st, (const half_t*)x, (half_t*)y, ab, HW, C, total8);
   else hipLaunchKernelGGL(gn_affine_kernel<false>, dim3(cdiv(total8, 256)), dim3(256), 0, st, (const half_t*)x, (half_t*)y, ab, HW, C, total8);
+  LFM_CHECK_LAUNCH();
+  return LFM_OK;
+}
+
+// ------------------------------------------------------------------ 2x2 average pooling, stride 2 (EDM Conv2d(down=True) with
+// resample_filter [1,1]: conv2d with the 2x2 box filter / 4, models/EDM.py:96-98,122-125)
+__global__ void avgpool2_kernel(const half8_t* __restrict__ x, half8_t* __restrict__ y, int Ho, int Wo, int C8, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C8);
+  const long p = i / C8;
+  const int ox = (int)(p % Wo), oy = (int)((p / Wo) % Ho);
+  const long n = p / ((long)Wo * Ho);
+  const long Wi = 2L * Wo;
+  const half8_t* b = x + ((n * 2 * Ho + 2 * oy) * Wi + 2 * ox) * C8 + c;
+  const half8_t a0 = b[0], a1 = b[C8], a2 = b[Wi * C8], a3 = b[Wi * C8 + C8];
+  half8_t o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (half_t)(0.25f * ((float)a0[j] + (float)a1[j] + (float)a2[j] + (float)a3[j]));
+  y[i] = o;
+}
+extern "C" int lfm_avgpool2_f16(const void* x, void* y, int N, int Ho, int Wo, int C, lfm_stream_t stream) {
+  if (!x || !y) return LFM_ERR_ARG;
+  if (N <= 0 || Ho <= 0 || Wo <= 0 || C % 8) return LFM_ERR_SHAPE;
+  const long total = (long)N * Ho * Wo * (C / 8);
+  hipLaunchKernelGGL(avgpool2_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const half8_t*)x, (half8_t*)y, Ho, Wo, C / 8, total);
+  LFM_CHECK_LAUNCH();
+  return LFM_OK;
+}
+
+// ------------------------------------------------------------------ nearest-neighbour 2x upsample (EDM Conv2d(up=True, kernel=0) skip path:
+// conv_transpose2d with the all-ones 2x2 filter, models/EDM.py:117-121)
+__global__ void upsample2_kernel(const half8_t* __restrict__ x, half8_t* __restrict__ y, int Ho, int Wo, int C8, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C8);
+  const long p = i / C8;
+  const int ox = (int)(p % Wo), oy = (int)((p / Wo) % Ho);
+  const long n = p / ((long)Wo * Ho);
+  y[i] = x[((n * (Ho / 2) + oy / 2) * (Wo / 2) + ox / 2) * C8 + c];
+}
+extern "C" int lfm_upsample2_f16(const void* x, void* y, int N, int Ho, int Wo, int C, lfm_stream_t stream) {
+  if (!x || !y) return LFM_ERR_ARG;
+  if (N <= 0 || Ho <= 0 || Wo <= 0 || ((Ho | Wo) & 1) || C % 8) return LFM_ERR_SHAPE;
+  const long total = (long)N * Ho * Wo * (C / 8);
+  hipLaunchKernelGGL(upsample2_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const half8_t*)x, (half8_t*)y, Ho, Wo, C / 8, total);
   LFM_CHECK_LAUNCH();
   return LFM_OK;
 }

@@ -88,7 +88,11 @@ def lib():
     L.lfm_groupnorm_scratch_bytes.restype = C.c_size_t
     L.lfm_groupnorm_scratch_bytes.argtypes = [I, I]
     L.lfm_groupnorm_f16.restype = I
-    L.lfm_groupnorm_f16.argtypes = [V, V, V, V, V, LG, V, I, I, I, F, I, V]
+    L.lfm_groupnorm_f16.argtypes = [V, V, V, V, V, LG, V, I, I, I, I, F, I, V]
+    L.lfm_avgpool2_f16.restype = I
+    L.lfm_avgpool2_f16.argtypes = [V, V, I, I, I, I, V]
+    L.lfm_upsample2_f16.restype = I
+    L.lfm_upsample2_f16.argtypes = [V, V, I, I, I, I, V]
     L.lfm_concat_channels_f16.restype = I
     L.lfm_concat_channels_f16.argtypes = [V, V, V, LG, I, I, V]
     L.lfm_attention_small_f16.restype = I

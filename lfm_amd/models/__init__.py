@@ -5,14 +5,16 @@ from .DiT import DiT, DiT_models
 def create_network(config):
     """``create_network(args) -> nn.Module`` with the reference's dispatch (models/__init__.py:6-17).
 
-    DiT-* model types and ``--use_origin_adm`` (guided-diffusion ``UNetModel``) are built on the HIP path.  The EDM
-    ``adm`` / ``ncsn++`` / ``ddpm++`` and ``--layout`` (UNetModelAttn, out of scope) raise instead of
+    DiT-*, ``--use_origin_adm`` (guided-diffusion ``UNetModel``) and the EDM ``adm`` (``DhariwalUNet``) are built
+    on the HIP path.  ``ncsn++`` / ``ddpm++`` (SongUNet) and ``--layout`` (UNetModelAttn) are out of scope and raise instead of
     silently falling back to anything.
     """
     if getattr(config, "use_origin_adm", False):
         return get_flow_model(config)
     if "DiT" not in config.model_type:
-        raise NotImplementedError(f"model_type {config.model_type!r}: only DiT-* is built on the HIP path (SURVEY.md §8f)")
+        from .EDM import get_edm_network
+
+        return get_edm_network(config)
     return DiT_models[config.model_type](
         img_resolution=config.image_size // config.f,
         in_channels=config.num_in_channels,

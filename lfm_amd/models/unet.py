@@ -202,7 +202,7 @@ class UNetModel(nn.Module):
             self._scratch = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=x.device)
             self._gen += 1
         hip.check(hip.lib().lfm_groupnorm_f16(hip.ptr(x), hip.ptr(y), hip.ptr(gb[0]), hip.ptr(gb[1]), hip.ptr(film),
-                                              film.stride(0) if film is not None else 0, hip.ptr(self._scratch), N, HW, Cch, 1e-5,
+                                              film.stride(0) if film is not None else 0, hip.ptr(self._scratch), N, HW, Cch, 32, 1e-5,
                                               1 if silu else 0, hip.stream_ptr(x.device)), "lfm_groupnorm_f16")
         return y
 

@@ -157,6 +157,32 @@ def golden_unet():
     return out
 
 
+def golden_edm():
+    """DhariwalUNet (models/EDM.py:716-861): plain forward with labels, and forward_with_cfg."""
+    import models.EDM as ref_edm
+
+    g = torch.Generator().manual_seed(21)
+    kw = dict(img_resolution=16, in_channels=4, out_channels=4, label_dim=5, augment_dim=0, model_channels=64, channel_mult=[1, 2],
+              channel_mult_emb=4, num_blocks=1, attn_resolutions=[8], dropout=0.0, label_dropout=0.1)
+    torch.manual_seed(0)
+    m = ref_edm.DhariwalUNet(**kw).eval()
+    _dezero_module(m, 999)
+    sd = m.state_dict()
+    for k in sd:
+        if sd[k].is_floating_point():
+            sd[k].copy_(sd[k].half().float())
+    m.load_state_dict(sd)
+    x = torch.randn(4, 4, 16, 16, generator=g)
+    y = torch.tensor([1, 4, 0, 2])
+    rec = {"cfg": kw, "state_dict": {k: (v.clone().half() if v.is_floating_point() else v.clone()) for k, v in m.state_dict().items()}, "x": x, "y": y}
+    with torch.no_grad():
+        rec["v_t0d"] = m(torch.tensor(0.6), x, y)
+        rec["v_tN"] = m(torch.tensor([0.9, 0.5, 0.3, 0.05]), x, y)
+        rec["v_nolabel"] = m(torch.tensor(0.6), x)
+        rec["v_cfg"] = m.forward_with_cfg(torch.tensor(0.6), x, y, cfg_scale=1.7)
+    return rec
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref_dit, ref_karras, ref_rand = _import_reference()
@@ -164,6 +190,7 @@ def main():
     torch.save(golden_karras(ref_karras, ref_rand), os.path.join(OUT, "karras.pt"))
     torch.save(golden_randgen(ref_rand), os.path.join(OUT, "randgen.pt"))
     torch.save(golden_unet(), os.path.join(OUT, "unet_tiny.pt"))
+    torch.save(golden_edm(), os.path.join(OUT, "edm_tiny.pt"))
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -68,7 +68,7 @@ def test_building_blocks_against_torch():
     scr = torch.empty(L.lfm_groupnorm_scratch_bytes(N, C), dtype=torch.uint8, device=dev)
     gd, bd, fd = gamma.to(dev), beta.to(dev), film.to(dev)
     hip.check(L.lfm_groupnorm_f16(hip.ptr(xin), hip.ptr(y), hip.ptr(gd), hip.ptr(bd), hip.ptr(fd), 2 * C,
-                                  hip.ptr(scr), N, H * W, C, 1e-5, 1, hip.stream_ptr()), "gn")
+                                  hip.ptr(scr), N, H * W, C, 32, 1e-5, 1, hip.stream_ptr()), "gn")
     assert rel_l2(y.permute(0, 3, 1, 2), ref) < 2e-3
     # legacy attention: [N, heads*3*ch, T] with per-head [q|k|v]
     heads, ch, T = 4, 128, 64
