@@ -173,12 +173,12 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
 // MFMA k-slot is the same permutation on both operands, so no shuffle is needed).
 // Keys are consumed in 32-key blocks with an online softmax (running max m, running sum l), which keeps
 // the live state at S 32 + P 16 + O 64 + Q 32 registers (2 waves / SIMD).
-template <int T>
-__global__ __launch_bounds__(T, 2) void dit_attention_kernel(const half_t* __restrict__ Q, const half_t* __restrict__ K,
+template <int T, int JQ>
+__global__ __launch_bounds__((T / (32 * JQ)) * 64, (T / (32 * JQ)) / 2) void dit_attention_kernel(const half_t* __restrict__ Q, const half_t* __restrict__ K,
                                                             const half_t* __restrict__ Vt, half_t* __restrict__ O, int D, int heads,
                                                             float scale_log2e) {
   constexpr int NKB = T / 32;  // 32-key blocks
-  constexpr int NW = T / 64;   // waves
+  constexpr int NW = T / (32 * JQ);  // waves: each owns JQ blocks of 32 queries
   constexpr int VKEY = (T / 8 - 1) < 15 ? (T / 8 - 1) : 15;  // V^T swizzle key mask (stays inside the row)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;             // [T][64] halves, 128-B rows, chunk' = chunk ^ ((row>>1)&7)
@@ -191,18 +191,18 @@ __global__ __launch_bounds__(T, 2) void dit_attention_kernel(const half_t* __res
   // ---- stage K (8 DMAs per thread), fetch this wave's Q fragments, then stage V^T (8 DMAs).  Issue order = completion
   // order for loads, so vmcnt(8) below means "K and Q are here, V^T may still be flying"; V^T is awaited before the first PV.
   constexpr int NPASS = (T * 8) / (NW * 64);
-  static_assert(NPASS == 8, "wait counts below assume 8 DMAs per operand");
+  static_assert(NPASS == 8 || NPASS == 4, "the counted wait below is vmcnt(NPASS)");
 #pragma unroll
   for (int p = 0; p < NPASS; ++p) {
     const int s = p * (NW * 64) + tid;
     const int row = s >> 3, c = (s & 7) ^ ((row >> 1) & 7);
     glds16(Kg + (long)row * D + c * 8, Ks + (p * NW * 64 + wave * 64) * 16);
   }
-  const int q0 = wave * 64;
+  const int q0 = wave * 32 * JQ;
   const int hsel = lane >> 5, l31 = lane & 31;
-  half8_t qf[2][4];
+  half8_t qf[JQ][4];
 #pragma unroll
-  for (int jq = 0; jq < 2; ++jq)
+  for (int jq = 0; jq < JQ; ++jq)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
       qf[jq][ks] = *(const half8_t*)(Q + ((long)img * T + q0 + jq * 32 + l31) * D + head * 64 + ks * 16 + hsel * 8);
@@ -214,16 +214,22 @@ __global__ __launch_bounds__(T, 2) void dit_attention_kernel(const half_t* __res
     glds16(Vg + (long)row * T + c * 8, Vs + (p * NW * 64 + wave * 64) * 16);
   }
 
-  f32x16 Oa[2][2];  // [jq][db]
+  f32x16 Oa[JQ][2];  // [jq][db]
 #pragma unroll
-  for (int jq = 0; jq < 2; ++jq)
+  for (int jq = 0; jq < JQ; ++jq)
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
       for (int e = 0; e < 16; ++e) Oa[jq][db][e] = 0.f;
-  float mrun[2] = {-3.0e38f, -3.0e38f}, lrun[2] = {0.f, 0.f};
+  float mrun[JQ], lrun[JQ];
+#pragma unroll
+  for (int jq = 0; jq < JQ; ++jq) {
+    mrun[jq] = -3.0e38f;
+    lrun[jq] = 0.f;
+  }
 
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  if (NPASS == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // raw barrier: __syncthreads() would drain the in-flight V^T DMAs
   asm volatile("" ::: "memory");
 
@@ -232,24 +238,24 @@ __global__ __launch_bounds__(T, 2) void dit_attention_kernel(const half_t* __res
 #pragma unroll
   for (int e = 0; e < 16; ++e) zero16[e] = 0.f;
   // S^T block kb: 32 keys x 64 queries (the first MFMA takes a shared all-zero C: no per-block accumulator clears)
-  auto qk = [&](f32x16 (&S)[2], int kb) {
+  auto qk = [&](f32x16 (&S)[JQ], int kb) {
     const int row = kb * 32 + l31;
     const int key = (row >> 1) & 7;
     const char* kp = Ks + row * 128;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const half8_t kf = *(const half8_t*)(kp + (((ks * 2 + hsel) ^ key) << 4));
-      S[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[0][ks], ks == 0 ? zero16 : S[0], 0, 0, 0);
-      S[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[1][ks], ks == 0 ? zero16 : S[1], 0, 0, 0);
+#pragma unroll
+      for (int jq = 0; jq < JQ; ++jq) S[jq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[jq][ks], ks == 0 ? zero16 : S[jq], 0, 0, 0);
     }
   };
   // online softmax update for the two queries this lane owns, then O^T[d][q] += sum_key V^T[d][key] P[q][key].
   // VALU diet (the kernel is VALU-bound: ~2.3k VALU per wave vs 128 MFMAs): 3-input max, packed fp32 FMA / ADD on
   // register pairs, one v_permlane32_swap instead of a ds_bpermute round trip for the lane^32 exchange.
-  auto softmax_pv = [&](f32x16 (&S)[2], int kb) {
-    half8_t P[2][2];
+  auto softmax_pv = [&](f32x16 (&S)[JQ], int kb) {
+    half8_t P[JQ][2];
 #pragma unroll
-    for (int jq = 0; jq < 2; ++jq) {
+    for (int jq = 0; jq < JQ; ++jq) {
       float mx = fmaxf(fmaxf(S[jq][0], S[jq][1]), S[jq][2]);
 #pragma unroll
       for (int e = 3; e < 15; e += 2) mx = fmaxf(fmaxf(mx, S[jq][e]), S[jq][e + 1]);
@@ -292,14 +298,14 @@ __global__ __launch_bounds__(T, 2) void dit_attention_kernel(const half_t* __res
         const half4_t lo = *(const half4_t*)(rowp + ((c0 ^ vkey) << 4));
         const half4_t hi = *(const half4_t*)(rowp + (((c0 + 1) ^ vkey) << 4));
         const half8_t vf = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        Oa[0][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, P[0][s], Oa[0][db], 0, 0, 0);
-        Oa[1][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, P[1][s], Oa[1][db], 0, 0, 0);
+#pragma unroll
+        for (int jq = 0; jq < JQ; ++jq) Oa[jq][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, P[jq][s], Oa[jq][db], 0, 0, 0);
       }
     }
   };
   // software pipeline over the key blocks: the S MFMAs of block kb+1 are issued BEFORE the softmax VALU of block kb, so
   // the matrix pipe works underneath the VALU-heavy part instead of the wave idling on the MFMA -> max -> exp -> MFMA chain
-  f32x16 Sa[2], Sb[2];
+  f32x16 Sa[JQ], Sb[JQ];
   qk(Sa, 0);
 #pragma unroll 1
   for (int kb = 0; kb < NKB; kb += 2) {
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(T, 2) void dit_attention_kernel(const half_t* __res
   }
   // ---- normalise and store: lane owns query q, d = db*32 + 8g + 4*hsel + r
 #pragma unroll
-  for (int jq = 0; jq < 2; ++jq) {
+  for (int jq = 0; jq < JQ; ++jq) {
     const float inv = 1.0f / (lrun[jq] + xhalf(lrun[jq]));
     half_t* orow = O + ((long)img * T + q0 + jq * 32 + l31) * D + head * 64;
 #pragma unroll
@@ -524,27 +530,29 @@ extern "C" size_t lfm_dit_workspace_bytes(const lfm_dit_shape* shape, int max_ba
   return carve(shape, max_batch, nullptr).total;
 }
 
+int lfm_gemm_debug_flags();
 static int attention_launch(const half_t* Q, const half_t* K, const half_t* Vt, half_t* O, int batch, int heads, int T, hipStream_t st) {
   const int D = heads * 64;
   const float sl2 = 0.125f * 1.4426950408889634f;  // hd^-0.5 * log2(e)
   const size_t lds = (size_t)T * 256;
   dim3 grid(heads, batch);
-#define ATT_CASE(TT)                                                                                                     \
-  case TT: {                                                                                                             \
-    static bool set = false;                                                                                             \
-    if (!set) {                                                                                                          \
-      (void)hipFuncSetAttribute((const void*)dit_attention_kernel<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, TT * 256);   \
-      set = true;                                                                                                        \
-    }                                                                                                                    \
-    hipLaunchKernelGGL((dit_attention_kernel<TT>), grid, dim3(TT), lds, st, Q, K, Vt, O, D, heads, sl2);                  \
-    break;                                                                                                               \
+  // A/B switch (measurement only): 8 waves x 32 queries (4 waves/SIMD) measured 44.3 us vs 40.2 us for 4 waves x 64 queries --
+  // the kernel moves Q,K,V^T,O = 134 MB per launch (3.4 TB/s): it is HBM-bound, not latency-bound, so more waves do not help
+  const bool narrow = T == 256 && (lfm_gemm_debug_flags() & 256);
+#define ATT_CASE(TT, JQ)                                                                                                          \
+  {                                                                                                                              \
+    static bool set = false;                                                                                                     \
+    if (!set) {                                                                                                                  \
+      (void)hipFuncSetAttribute((const void*)dit_attention_kernel<TT, JQ>, hipFuncAttributeMaxDynamicSharedMemorySize, TT * 256); \
+      set = true;                                                                                                                \
+    }                                                                                                                            \
+    hipLaunchKernelGGL((dit_attention_kernel<TT, JQ>), grid, dim3((TT / (32 * JQ)) * 64), lds, st, Q, K, Vt, O, D, heads, sl2);    \
   }
-  switch (T) {
-    ATT_CASE(64)
-    ATT_CASE(128)
-    ATT_CASE(256)
-    default: return LFM_ERR_SHAPE;
-  }
+  if (T == 64) ATT_CASE(64, 2)
+  else if (T == 128) ATT_CASE(128, 2)
+  else if (T == 256 && narrow) ATT_CASE(256, 1)
+  else if (T == 256) ATT_CASE(256, 2)
+  else return LFM_ERR_SHAPE;
 #undef ATT_CASE
   LFM_CHECK_LAUNCH();
   return LFM_OK;

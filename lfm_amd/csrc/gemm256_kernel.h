@@ -49,10 +49,10 @@ __global__ __launch_bounds__(512) void gemm256_tn_kernel(ASrc asrc, const half_t
   // L2) instead of a 1 x 32 / 2 x 16 strip (33 / 18 panels).
   int bid = blockIdx.x;
   const int nb = gridDim.x;
-  if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
+  if ((nb & 7) == 0 && !(dbg & 128)) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
   int tile_m, tile_n;
   {
-    const int tiles_m = nb / tiles_n, GM = 4;
+    const int tiles_m = nb / tiles_n, GM = (dbg & 32) ? 8 : ((dbg & 64) ? 2 : 4);
     const int grp = bid / (GM * tiles_n), within = bid - grp * (GM * tiles_n);
     const int gm = (tiles_m - grp * GM) < GM ? (tiles_m - grp * GM) : GM;  // last group may be short
     tile_m = grp * GM + within % gm;
@@ -169,8 +169,9 @@ __global__ __launch_bounds__(512) void gemm256_tn_kernel(ASrc asrc, const half_t
 
   if (g == 0) {
     for (int t = 0; t < nk; ++t) {
+      if ((dbg & 16) && t + 3 < nk) issue_tile(t + 3);
       load_frags(t);  // slot 2t: L(t)
-      if (t + 3 < nk) issue_tile(t + 3);
+      if (!(dbg & 16) && t + 3 < nk) issue_tile(t + 3);
       G256_LGKM0();
       G256_BARRIER();
       compute();  // slot 2t+1: C(t)
@@ -180,8 +181,9 @@ __global__ __launch_bounds__(512) void gemm256_tn_kernel(ASrc asrc, const half_t
   } else {
     G256_BARRIER();  // slot 0: group 1 idles, then stays one segment behind
     for (int t = 0; t < nk; ++t) {
+      if ((dbg & 16) && t + 3 < nk) issue_tile(t + 3);
       load_frags(t);  // slot 2t+1: L(t)
-      if (t + 3 < nk) issue_tile(t + 3);
+      if (!(dbg & 16) && t + 3 < nk) issue_tile(t + 3);
       G256_LGKM0();
       if (t + 1 < nk) wait_tile(t + 1);
       G256_BARRIER();

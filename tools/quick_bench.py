@@ -54,8 +54,11 @@ for name, bs in [("DiT-B/2", 64), ("DiT-L/2", 64)]:
 # attention alone (DiT-L shape)
 Bh, heads, T = 64, 16, 256
 Q = torch.randn(Bh * T, heads * 64, device=dev).half(); K = torch.randn_like(Q); Vt = torch.randn(Bh, heads, 64, T, device=dev).half()
-ms = timeit(lambda: hip.dit_attention(Q, K, Vt, Bh, heads, T), n=20)
-print(f"attention b={Bh} h={heads} T={T}: {ms*1e3:.1f} us  {4*Bh*heads*T*T*64/ms/1e9:.0f} TFLOP/s")
+for nm, fl in (("4 waves x 64 q", 0), ("8 waves x 32 q", 256 << 4)):
+    hip.lib().lfm_gemm_select(fl)
+    ms = timeit(lambda: hip.dit_attention(Q, K, Vt, Bh, heads, T), n=20)
+    print(f"attention [{nm}] b={Bh} h={heads} T={T}: {ms*1e3:.1f} us  {4*Bh*heads*T*T*64/ms/1e9:.0f} TFLOP/s")
+hip.lib().lfm_gemm_select(0)
 X = torch.randn(Bh * T, 1024, device=dev); sh = torch.randn(1, 1024, device=dev); sc = torch.randn(1, 1024, device=dev)
 ms = timeit(lambda: hip.ln_modulate(X, sh, sc, T, 0), n=20)
 print(f"ln_modulate M={Bh*T} D=1024: {ms*1e3:.1f} us  {Bh*T*1024*6/ms/1e6:.0f} GB/s")
