@@ -200,3 +200,19 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/lfm_hip.h but not exported"
     lib.lfm_strerror.restype = ctypes.c_char_p
     assert lib.lfm_strerror(0) == b"ok" and lib.lfm_abi_version() >= 1
+
+
+def test_unet_and_edm_state_dict_names_match_reference(golden_dir):
+    """Key-for-key (and shape-for-shape) identity with state dicts produced by the unmodified reference classes."""
+    from lfm_amd.models.EDM import DhariwalUNet
+    from lfm_amd.models.unet import UNetModel
+
+    for which, rec in _load(golden_dir, "unet_tiny.pt").items():
+        m = UNetModel(**rec["cfg"])
+        assert list(m.state_dict().keys()) == list(rec["state_dict"].keys()), which
+        assert all(m.state_dict()[k].shape == v.shape for k, v in rec["state_dict"].items())
+    rec = _load(golden_dir, "edm_tiny.pt")
+    m = DhariwalUNet(**rec["cfg"])
+    assert list(m.state_dict().keys()) == list(rec["state_dict"].keys())
+    assert all(m.state_dict()[k].shape == v.shape for k, v in rec["state_dict"].items())
+    assert any(k.endswith("resample_filter") for k in rec["state_dict"])  # the up/down convolutions' buffers are mirrored too
