@@ -199,7 +199,7 @@ def main():
         res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
                            "traffic": traffic, "traffic_unit": "bytes/launch (HBM, rocprofv3 PMC, separate passes)",
                            "algorithmic_bytes": 2.0 * (M * D + H * D + M * H), "algorithmic_flop": 2.0 * M * H * D,
-                           "kernel": "gemm256_tn_kernel<ASrcRowMajor,EpiBiasGeluF16> (DiT fc1 + GELU)",
+                           "kernel": "gemm256q_tn_kernel<ASrcRowMajor,EpiBiasGeluF16> (DiT fc1 + GELU)",
                            "shape": {"M": M, "N": H, "K": D}, "avg_launch_us": dur * 1e6, "launches_timed": len(durs)}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(a.model, a.nfe)

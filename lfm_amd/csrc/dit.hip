@@ -1,14 +1,14 @@
 // DiT velocity field on gfx950: the kernels around the MFMA GEMMs and the per-call driver.
 // Reference behaviour: /root/reference/models/DiT.py (cited per kernel).
 #include "../../include/lfm_hip.h"
-#include "gemm256_kernel.h"
+#include "gemm256q_kernel.h"
 
 static int g_gemm_sel = 0;
 int lfm_gemm_selected() { return g_gemm_sel; }
 static int g_gemm_dbg = 0;
 int lfm_gemm_debug_flags() { return g_gemm_dbg; }
-extern "C" int lfm_gemm_select(int which) {  // low 2 bits: kernel choice; bits 4,5: ablation flags (measurement only)
-  if ((which & 15) > 2 || which < 0) return LFM_ERR_ARG;
+extern "C" int lfm_gemm_select(int which) {  // low 4 bits: kernel choice (0 auto, 1..3); bits 4+: ablation flags (measurement only)
+  if ((which & 15) > 3 || which < 0) return LFM_ERR_ARG;
   g_gemm_sel = which & 15;
   g_gemm_dbg = which >> 4;
   return LFM_OK;

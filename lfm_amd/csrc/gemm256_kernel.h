@@ -36,6 +36,80 @@ int lfm_gemm_debug_flags();  // ablation switches, measurement only
 #define G256_STAGE_BYTES (2 * G256_TILE_BYTES)  // A + W, 32 KiB
 #define G256_LDS_BYTES (G256_NSTAGE * G256_STAGE_BYTES)  // 128 KiB (the epilogue scratch reuses it)
 
+// Tile order.  Block b runs on XCD b%8: give each XCD a contiguous range of tile ids, and inside a range walk groups of
+// GM = 4 M-panels column-major, so the ~32 tiles an XCD runs concurrently form a 4 x 8 patch (12 operand panels in its
+// L2) instead of a 1 x 32 / 2 x 16 strip (33 / 18 panels).
+__device__ __forceinline__ void g256_tile_order(int bid, int nb, int tiles_n, int dbg, int& tile_m, int& tile_n) {
+  if ((nb & 7) == 0 && !(dbg & 128)) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
+  const int tiles_m = nb / tiles_n, GM = (dbg & 32) ? 8 : ((dbg & 64) ? 2 : 4);
+  const int grp = bid / (GM * tiles_n), within = bid - grp * (GM * tiles_n);
+  const int gm = (tiles_m - grp * GM) < GM ? (tiles_m - grp * GM) : GM;  // last group may be short
+  tile_m = grp * GM + within % gm;
+  tile_n = within / gm;
+}
+
+// Shared epilogue of the 256x256 kernels (wave (g, wn) owns rows g*128.., columns wn*64.., acc[i][j] = 32x32 block i, j).
+template <class Epi>
+__device__ __forceinline__ void g256_epilogue(f32x16 (&acc)[4][2], char* smem, Epi& epi, int m0, int n0, int M, int N, int g, int wn, int lane,
+                                              int wave, int bz, long bsC, int dbg) {
+  const int chalf = lane >> 5;
+  // ---- epilogue.  The MFMA leaves lane (m = lane&31, h = lane>>5) with 4 consecutive n per register group: storing that
+  // directly makes every store instruction touch 32 different 128-B lines with 16-32 B each (measured: ~12 us per tile,
+  // L2-request-bound).  Instead each wave transposes its block through a PRIVATE 32 x 64 fp32 LDS scratch (row stride
+  // 272 B: conflict-free ds_write_b128) and re-reads it row-major: 16 lanes cover one 256-B row, so a global access
+  // instruction touches 4 rows x full lines.  Epilogues that want the fragment layout (V^T scatter) opt out.
+  epi_batch(epi, bz, bsC, 0);
+  if (dbg & 4) return;  // ablation: no epilogue
+  if (epi_direct(epi, n0, 0)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + g * 128 + i * 32 + (lane & 31);
+      if (m >= M) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = n0 + wn * 64 + j * 32 + 8 * q + 4 * chalf;
+          if (n + 3 < N) {
+            f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+            epi.store(m, n, v, epi.load(m, n));
+          }
+        }
+    }
+    return;
+  }
+  char* scr = smem + wave * (32 * 272);
+  const bool interior = (m0 + G256_BM <= M) && (n0 + G256_BN <= N);
+  const int rrow = lane >> 4, rcol = lane & 15;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        *(f32x4*)(scr + (lane & 31) * 272 + (j * 32 + 8 * q + 4 * chalf) * 4) = v;
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    f32x4 v[8];
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) v[ps] = *(const f32x4*)(scr + (ps * 4 + rrow) * 272 + rcol * 16);
+    const int mb = m0 + g * 128 + i * 32 + rrow, n = n0 + wn * 64 + rcol * 4;
+    if (interior) {
+      typename Epi::Aux aux[8];
+#pragma unroll
+      for (int ps = 0; ps < 8; ++ps) aux[ps] = epi.load(mb + ps * 4, n);
+#pragma unroll
+      for (int ps = 0; ps < 8; ++ps) epi.store(mb + ps * 4, n, v[ps], aux[ps]);
+    } else if (n + 3 < N) {
+#pragma unroll
+      for (int ps = 0; ps < 8; ++ps)
+        if (mb + ps * 4 < M) epi.store(mb + ps * 4, n, v[ps], epi.load(mb + ps * 4, n));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
 template <class ASrc, class Epi>
 __global__ __launch_bounds__(512) void gemm256_tn_kernel(ASrc asrc, const half_t* __restrict__ W, long ldw, int M, int N, int K,
                                                           int tiles_n, Epi epi, long bsA, long bsW, long bsC, int dbg) {
@@ -44,20 +118,8 @@ __global__ __launch_bounds__(512) void gemm256_tn_kernel(ASrc asrc, const half_t
   const int g = wave >> 2, wn = wave & 3;
   const bool dbg_noload = dbg & 1, dbg_nomfma = dbg & 2;  // ablation switches (measurement only)
 
-  // Tile order.  Block b runs on XCD b%8: give each XCD a contiguous range of tile ids, and inside a range walk groups of
-  // GM = 4 M-panels column-major, so the ~32 tiles an XCD runs concurrently form a 4 x 8 patch (12 operand panels in its
-  // L2) instead of a 1 x 32 / 2 x 16 strip (33 / 18 panels).
-  int bid = blockIdx.x;
-  const int nb = gridDim.x;
-  if ((nb & 7) == 0 && !(dbg & 128)) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
   int tile_m, tile_n;
-  {
-    const int tiles_m = nb / tiles_n, GM = (dbg & 32) ? 8 : ((dbg & 64) ? 2 : 4);
-    const int grp = bid / (GM * tiles_n), within = bid - grp * (GM * tiles_n);
-    const int gm = (tiles_m - grp * GM) < GM ? (tiles_m - grp * GM) : GM;  // last group may be short
-    tile_m = grp * GM + within % gm;
-    tile_n = within / gm;
-  }
+  g256_tile_order(blockIdx.x, gridDim.x, tiles_n, dbg, tile_m, tile_n);
   const int m0 = tile_m * G256_BM, n0 = tile_n * G256_BN;
   const int bz = blockIdx.y;
   asrc.init(bz, bsA);
@@ -192,61 +254,7 @@ __global__ __launch_bounds__(512) void gemm256_tn_kernel(ASrc asrc, const half_t
     }
   }
 
-  // ---- epilogue.  The MFMA leaves lane (m = lane&31, h = lane>>5) with 4 consecutive n per register group: storing that
-  // directly makes every store instruction touch 32 different 128-B lines with 16-32 B each (measured: ~12 us per tile,
-  // L2-request-bound).  Instead each wave transposes its block through a PRIVATE 32 x 64 fp32 LDS scratch (row stride
-  // 272 B: conflict-free ds_write_b128) and re-reads it row-major: 16 lanes cover one 256-B row, so a global access
-  // instruction touches 4 rows x full lines.  Epilogues that want the fragment layout (V^T scatter) opt out.
-  epi_batch(epi, bz, bsC, 0);
-  if (dbg & 4) return;  // ablation: no epilogue
-  if (epi_direct(epi, n0, 0)) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = m0 + g * 128 + i * 32 + (lane & 31);
-      if (m >= M) continue;
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int n = n0 + wn * 64 + j * 32 + 8 * q + 4 * chalf;
-          if (n + 3 < N) {
-            f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-            epi.store(m, n, v, epi.load(m, n));
-          }
-        }
-    }
-    return;
-  }
-  char* scr = smem + wave * (32 * 272);
-  const bool interior = (m0 + G256_BM <= M) && (n0 + G256_BN <= N);
-  const int rrow = lane >> 4, rcol = lane & 15;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-        *(f32x4*)(scr + (lane & 31) * 272 + (j * 32 + 8 * q + 4 * chalf) * 4) = v;
-      }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    f32x4 v[8];
-#pragma unroll
-    for (int ps = 0; ps < 8; ++ps) v[ps] = *(const f32x4*)(scr + (ps * 4 + rrow) * 272 + rcol * 16);
-    const int mb = m0 + g * 128 + i * 32 + rrow, n = n0 + wn * 64 + rcol * 4;
-    if (interior) {
-      typename Epi::Aux aux[8];
-#pragma unroll
-      for (int ps = 0; ps < 8; ++ps) aux[ps] = epi.load(mb + ps * 4, n);
-#pragma unroll
-      for (int ps = 0; ps < 8; ++ps) epi.store(mb + ps * 4, n, v[ps], aux[ps]);
-    } else if (n + 3 < N) {
-#pragma unroll
-      for (int ps = 0; ps < 8; ++ps)
-        if (mb + ps * 4 < M) epi.store(mb + ps * 4, n, v[ps], epi.load(mb + ps * 4, n));
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  }
+  g256_epilogue(acc, smem, epi, m0, n0, M, N, g, wn, lane, wave, bz, bsC, dbg);
 }
 
 template <class ASrc, class Epi>
@@ -265,15 +273,4 @@ static inline int launch_gemm256_tn(const ASrc& asrc, const half_t* W, long ldw,
                      bsA, bsW, bsC, lfm_gemm_debug_flags());
   LFM_CHECK_LAUNCH();
   return LFM_OK;
-}
-
-// Dispatcher: the ping-pong kernel when the problem fills the chip with 256x256 tiles, v1 otherwise.
-// lfm_gemm_select() (0 auto, 1 force v1, 2 force v2) exists for A/B measurements and parity tests of both kernels.
-template <class ASrc, class Epi>
-static inline int launch_gemm_auto(const ASrc& asrc, const half_t* W, long ldw, int M, int N, int K, const Epi& epi, hipStream_t stream,
-                                   int batch = 1, long bsA = 0, long bsW = 0, long bsC = 0) {
-  const long tiles256 = (long)cdiv(M, 256) * cdiv(N, 256) * batch;
-  const int sel = lfm_gemm_selected();
-  if (sel == 2 || (sel == 0 && tiles256 >= 192 && N >= 256 && M >= 256)) return launch_gemm256_tn(asrc, W, ldw, M, N, K, epi, stream, batch, bsA, bsW, bsC);
-  return launch_gemm_tn(asrc, W, ldw, M, N, K, epi, stream, batch, bsA, bsW, bsC);
 }

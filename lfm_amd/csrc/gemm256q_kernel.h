@@ -1,0 +1,233 @@
+// 256x256 "quadrant-phased" MFMA GEMM for gfx950 (v3):  C[m][n] = sum_k A[m][k] * W[n][k]  (+ fused epilogue).
+// Same operand / epilogue / A-source interfaces and the same wave -> output mapping as gemm256_kernel.h (v2), so the
+// epilogue code is shared.  What changed, and why (measured on v2):
+//
+//  * v2 stages 32-deep K-tiles, i.e. 64-B rows: one LDS-DMA instruction then touches 16 rows x HALF a cache line, and the
+//    DMA issue cost (not the MFMAs, not the LDS reads) bounded the loop: 1.4 PFLOP/s with the DMAs ablated, 1.07 with.
+//    v3 stages 64-deep K-tiles = full 128-B lines (8 rows per DMA instruction), half the requests per byte.
+//  * A K-tile is consumed in FOUR phases, one 64x32 output quadrant each (8 MFMAs = 256 matrix-pipe cycles), and is
+//    staged in four 16-KiB PIECES cut along the same lines:  A.sub0 / A.sub1 = rows {0..63} / {64..127} of both
+//    groups' 128-row halves,  B.sub0 / B.sub1 = columns {0..31} / {32..63} of every wave's 64-column block.  A piece is
+//    last read in a known phase, so it can be re-staged two phases later: every phase issues exactly one piece
+//    (2 DMAs per thread) and ends its load part with the same counted wait, vmcnt(8) = "all but my newest four pieces
+//    have landed" -- four pieces (64 KiB per CU) are always in flight and each has >= 4 phases to land.
+//
+//      phase       reads (ds_read_b128)          MFMAs (acc rows x cols)    stages piece        of K-tile
+//      P1(t)       A.sub0 (8) + B.sub0 (4)       sub0 x sub0                B.sub1              t+1
+//      P2(t)       B.sub1 (4)                    sub0 x sub1                A.sub1              t+1
+//      P3(t)       A.sub1 (8)                    sub1 x sub1                A.sub0              t+2
+//      P4(t)       -                             sub1 x sub0                B.sub0              t+2
+//
+//    phase = [reads, DMA, vmcnt] s_barrier [lgkmcnt(0), 8 MFMAs] s_barrier.  The two wave groups (rows 0..127 /
+//    128..255 of the tile, one wave per SIMD each) run this program shifted by ONE barrier, so a SIMD's two waves
+//    alternate "load part" and "MFMA part".  Hazards (interval = time between two barriers; group 0 loads in interval
+//    2p and computes in 2p+1, group 1 one later):
+//      RAW  a piece waited for in phase p (both groups, before their first barrier of p) is read in phase p+1 or later;
+//      WAR  a piece read in phase p (reads retired right after the first barrier of p) is re-staged in phase p+2 or later.
+//    LDS = 2 K-tiles x 4 pieces x 16 KiB = 128 KiB; rows are 128 B, chunk c of row r sits at c ^ ((r>>1)&7) (v1's key).
+#pragma once
+#include "gemm256_kernel.h"
+
+#define G256Q_BK 64
+#define G256Q_PIECE 16384
+#define G256Q_SLOT_A0 0
+#define G256Q_SLOT_B0 (1 * G256Q_PIECE)
+#define G256Q_SLOT_B1 (2 * G256Q_PIECE)
+#define G256Q_SLOT_A1 (3 * G256Q_PIECE)
+#define G256Q_BUF_BYTES (4 * G256Q_PIECE)
+#define G256Q_LDS_BYTES (2 * G256Q_BUF_BYTES)
+
+template <int V>
+struct g256q_ic {
+  static constexpr int value = V;
+};
+
+template <class ASrc, class Epi>
+__global__ __launch_bounds__(512) void gemm256q_tn_kernel(ASrc asrc, const half_t* __restrict__ W, long ldw, int M, int N, int K,
+                                                           int tiles_n, Epi epi, long bsA, long bsW, long bsC, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> SGPR
+  const int g = wave >> 2, wn = wave & 3;
+
+  int tile_m, tile_n;
+  g256_tile_order(blockIdx.x, gridDim.x, tiles_n, dbg, tile_m, tile_n);
+  const int m0 = tile_m * G256_BM, n0 = tile_n * G256_BN;
+  const int bz = blockIdx.y;
+  asrc.init(bz, bsA);
+  W += (long)bz * bsW;
+
+  // ---- DMA sources.  A piece is 128 local rows x 128 B = 1024 chunks of 16 B: thread tid stages chunks tid and 512 + tid,
+  // i.e. local rows (tid>>3) and 64 + (tid>>3), physical chunk tid&7, which holds logical chunk (tid&7) ^ key(row).
+  //   A.sub_s local row lr -> tile row (lr>>6)*128 + s*64 + (lr&63)         (group = lr>>6)
+  //   B.sub_s local row lr -> tile col (lr>>5)*64  + s*32 + (lr&31)         (wave column = lr>>5)
+  typename ASrc::Row arow[2][2];  // [sub][pass]
+  const half_t* wrow[2][2];
+  const int cswz = ((tid & 7) ^ ((tid >> 4) & 7)) * 8;  // key(lr) = (lr>>1)&7 = (tid>>4)&7 for both passes
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      arow[s][p] = asrc.row(m0 + p * 128 + s * 64 + (tid >> 3));
+      const int n = n0 + (p * 2 + (tid >> 8)) * 64 + s * 32 + ((tid >> 3) & 31);
+      wrow[s][p] = W + (long)(n < N ? n : N - 1) * ldw + cswz;
+    }
+  const int nk = K / G256Q_BK;
+  const int dma_off = wave * 1024;  // wave-uniform destination; the hardware adds lane*16
+
+  auto issue_a = [&](int s, char* slot) {  // the A-source's current K-tile (begin_tile) applies
+    glds16(asrc.ptr(arow[s][0], cswz), slot + dma_off);
+    glds16(asrc.ptr(arow[s][1], cswz), slot + 8192 + dma_off);
+  };
+  auto issue_b = [&](int s, int kt, char* slot) {
+    glds16(wrow[s][0] + kt * G256Q_BK, slot + dma_off);
+    glds16(wrow[s][1] + kt * G256Q_BK, slot + 8192 + dma_off);
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // fragment reads: lane (r = lane&31, h = lane>>5) reads logical chunk 2*ks + h of local row base + r
+  const int rkey = ((lane & 31) >> 1) & 7, chalf = lane >> 5;
+  const int a_rd = (g * 64 + (lane & 31)) * 128;   // + i2 * 4096
+  const int w_rd = (wn * 32 + (lane & 31)) * 128;
+  half8_t af[2][4], wf[2][4];  // A: [32-row block][k16 step] of the current sub;  W: [sub][k16 step]
+
+  auto read_a = [&](const char* slot) {
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) af[i2][ks] = *(const half8_t*)(slot + a_rd + i2 * 4096 + (((ks * 2 + chalf) ^ rkey) << 4));
+  };
+  auto read_w = [&](int s, const char* slot) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) wf[s][ks] = *(const half8_t*)(slot + w_rd + (((ks * 2 + chalf) ^ rkey) << 4));
+  };
+
+#define G256Q_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+  // One phase of K-tile t.  PH 0..3, BUF = K-tile parity.  s1 / s2: K-tiles t+1 / t+2 exist (wave-uniform).
+  auto phase = [&](auto PHC, auto BUFC, int t, bool s1, bool s2) {
+    constexpr int PH = decltype(PHC)::value, BUF = decltype(BUFC)::value;
+    char* cur = smem + BUF * G256Q_BUF_BYTES;
+    char* oth = smem + (BUF ^ 1) * G256Q_BUF_BYTES;
+    if constexpr (PH == 0) {
+      read_w(0, cur + G256Q_SLOT_B0);
+      __builtin_amdgcn_sched_barrier(0);
+      read_a(cur + G256Q_SLOT_A0);
+    } else if constexpr (PH == 1) {
+      read_w(1, cur + G256Q_SLOT_B1);
+    } else if constexpr (PH == 2) {
+      read_a(cur + G256Q_SLOT_A1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int I0 = (PH >= 2) ? 2 : 0, J = (PH == 1 || PH == 2) ? 1 : 0;
+    // stage one piece, then wait until everything the NEXT phase reads has landed: with the piece order of the header
+    // that is "all but my newest four pieces" in steady state, fewer once the stream of pieces has ended
+    if constexpr (PH == 0) {
+      if (s1) issue_b(1, t + 1, oth + G256Q_SLOT_B1);
+      if (s1) G256Q_VMCNT(8);
+      else G256Q_VMCNT(2);
+    } else if constexpr (PH == 1) {
+      if (s1) issue_a(1, oth + G256Q_SLOT_A1);  // A-source state = K-tile t+1 (set in P3(t-1) / the prologue)
+      if (s1) G256Q_VMCNT(8);
+      else G256Q_VMCNT(0);
+    } else if constexpr (PH == 2) {
+      if (s2) {
+        asrc.begin_tile(t + 2, G256Q_BK);
+        issue_a(0, cur + G256Q_SLOT_A0);
+        G256Q_VMCNT(8);
+      } else if (s1) G256Q_VMCNT(6);
+      else G256Q_VMCNT(0);
+    } else {
+      if (s2) {
+        issue_b(0, t + 2, cur + G256Q_SLOT_B0);
+        G256Q_VMCNT(8);
+      } else if (s1) G256Q_VMCNT(4);
+      // last K-tile: nothing left to wait for
+    }
+    G256_BARRIER();
+    G256_LGKM0();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2)
+        acc[I0 + i2][J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[J][ks], af[i2][ks], acc[I0 + i2][J], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    if (PH < 3 || s1 || g == 0) G256_BARRIER();  // group 1 ran one extra barrier up front: it skips the very last one
+  };
+  auto tile = [&](auto BUFC, int t) {
+    const bool s1 = t + 1 < nk, s2 = t + 2 < nk;
+    phase(g256q_ic<0>{}, BUFC, t, s1, s2);
+    phase(g256q_ic<1>{}, BUFC, t, s1, s2);
+    phase(g256q_ic<2>{}, BUFC, t, s1, s2);
+    phase(g256q_ic<3>{}, BUFC, t, s1, s2);
+  };
+
+  // ---- prologue: pieces A0(0) B0(0) B1(0) A1(0) [A0(1) B0(1)]; the first two must have landed before P1(0)
+  asrc.begin_tile(0, G256Q_BK);
+  issue_a(0, smem + G256Q_SLOT_A0);
+  issue_b(0, 0, smem + G256Q_SLOT_B0);
+  issue_b(1, 0, smem + G256Q_SLOT_B1);
+  issue_a(1, smem + G256Q_SLOT_A1);
+  if (nk > 1) {
+    asrc.begin_tile(1, G256Q_BK);
+    issue_a(0, smem + G256Q_BUF_BYTES + G256Q_SLOT_A0);
+    issue_b(0, 1, smem + G256Q_BUF_BYTES + G256Q_SLOT_B0);
+    G256Q_VMCNT(8);
+  } else {
+    G256Q_VMCNT(4);
+  }
+  G256_BARRIER();
+  if (g == 1) G256_BARRIER();  // group 1 stays one barrier behind from here on
+
+  {
+    int t = 0;
+    for (; t + 1 < nk; t += 2) {
+      tile(g256q_ic<0>{}, t);
+      tile(g256q_ic<1>{}, t + 1);
+    }
+    if (t < nk) tile(g256q_ic<0>{}, t);
+  }
+#undef G256Q_VMCNT
+
+  // group 0's last barrier is group 1's first barrier of its last phase (P4: no reads), every earlier read has been
+  // retired and every piece has landed: the LDS is free for the epilogue scratch
+  g256_epilogue(acc, smem, epi, m0, n0, M, N, g, wn, lane, wave, bz, bsC, dbg);
+}
+
+template <class ASrc, class Epi>
+static inline int launch_gemm256q_tn(const ASrc& asrc, const half_t* W, long ldw, int M, int N, int K, const Epi& epi, hipStream_t stream,
+                                     int batch = 1, long bsA = 0, long bsW = 0, long bsC = 0) {
+  if (M <= 0 || N <= 0 || K <= 0 || (K % G256Q_BK) != 0 || (N % 4) != 0) return LFM_ERR_SHAPE;
+  if ((ldw % 8) != 0 || ((uintptr_t)W & 15)) return LFM_ERR_ALIGN;
+  const int tm = cdiv(M, G256_BM), tn = cdiv(N, G256_BN);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm256q_tn_kernel<ASrc, Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, G256Q_LDS_BYTES) != hipSuccess)
+      return LFM_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm256q_tn_kernel<ASrc, Epi>), dim3(tm * tn, batch), dim3(512), G256Q_LDS_BYTES, stream, asrc, W, ldw, M, N, K, tn, epi,
+                     bsA, bsW, bsC, lfm_gemm_debug_flags());
+  LFM_CHECK_LAUNCH();
+  return LFM_OK;
+}
+
+// Dispatcher: a 256x256 kernel when the problem fills the chip with such tiles, v1 otherwise.
+// lfm_gemm_select() (0 auto, 1 force v1, 2 force v2, 3 force v3 -- v2 when K % 64 != 0) exists for A/B measurements and parity tests of all kernels.
+template <class ASrc, class Epi>
+static inline int launch_gemm_auto(const ASrc& asrc, const half_t* W, long ldw, int M, int N, int K, const Epi& epi, hipStream_t stream,
+                                   int batch = 1, long bsA = 0, long bsW = 0, long bsC = 0) {
+  const long tiles256 = (long)cdiv(M, 256) * cdiv(N, 256) * batch;
+  const int sel = lfm_gemm_selected();
+  const bool big = tiles256 >= 192 && N >= 256 && M >= 256;
+  if ((sel == 3 || (sel == 0 && big)) && (K % G256Q_BK) == 0) return launch_gemm256q_tn(asrc, W, ldw, M, N, K, epi, stream, batch, bsA, bsW, bsC);
+  if (sel == 2 || sel == 3 || (sel == 0 && big)) return launch_gemm256_tn(asrc, W, ldw, M, N, K, epi, stream, batch, bsA, bsW, bsC);
+  return launch_gemm_tn(asrc, W, ldw, M, N, K, epi, stream, batch, bsA, bsW, bsC);
+}

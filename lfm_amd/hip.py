@@ -123,6 +123,12 @@ def require_gpu(t, what):
 
 
 # ----------------------------------------------------------------------------- thin op wrappers (used by tests)
+def gemm_select(which):
+    """Force a GEMM kernel (0 auto, 1 128x128, 2 ping-pong, 3 quadrant-phased) | ablation flags << 4; A/B measurements
+    and parity tests only.  Raises on a value the library rejects (a silently ignored selection invalidates an A/B)."""
+    check(lib().lfm_gemm_select(int(which)), "lfm_gemm_select")
+
+
 def gemm_f16(A, W, bias=None, epilogue=0, out=None, gate=None, gate_stride=0, tokens=1):
     require_gpu(A, "gemm_f16")
     M, K = A.shape

@@ -55,10 +55,13 @@ def test_gemm_epilogues(dev, M, N, K, epi):
     assert rel_l2(got, ref) < (2e-3 if epi in (0, 1) else 2e-4)
 
 
-@pytest.mark.parametrize("M,N,K", [(512, 512, 128), (1024, 768, 1024), (300, 260, 64), (4096, 1024, 4096), (8192, 3072, 1024)])
+@pytest.mark.parametrize("M,N,K", [(512, 512, 128), (1024, 768, 1024), (300, 260, 64), (4096, 1024, 4096), (8192, 3072, 1024),
+                                   (512, 256, 192), (256, 512, 320), (768, 512, 576)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
-def test_gemm256_pingpong_kernel(dev, M, N, K, epi):
-    """Same checks with the 256x256 ping-pong kernel forced (lfm_gemm_select(2)); repeated launches screen for races."""
+@pytest.mark.parametrize("kernel", [2, 3])
+def test_gemm256_kernels(dev, M, N, K, epi, kernel):
+    """Same checks with a 256x256 kernel forced (lfm_gemm_select: 2 = ping-pong, 3 = quadrant-phased; K covers 1, 2, 3, odd and
+    even numbers of 64-deep K-tiles, i.e. every prologue / tail path); repeated launches screen for races."""
     from lfm_amd import hip
 
     g = torch.Generator().manual_seed(M + N * 3 + K + epi)
@@ -75,7 +78,7 @@ def test_gemm256_pingpong_kernel(dev, M, N, K, epi):
         gate = torch.randn(M // tokens, N, generator=g)
         ref = X + gate.repeat_interleave(tokens, 0) * ref
         gate = gate.to(dev)
-    hip.lib().lfm_gemm_select(2)
+    hip.gemm_select(kernel)
     try:
         Ad, Wd, bd = A.to(dev), W.to(dev), bias.to(dev)
         outs = []
@@ -84,22 +87,23 @@ def test_gemm256_pingpong_kernel(dev, M, N, K, epi):
             outs.append(hip.gemm_f16(Ad, Wd, bd, epilogue=epi, out=out, gate=gate, gate_stride=N, tokens=tokens))
         torch.cuda.synchronize()
     finally:
-        hip.lib().lfm_gemm_select(0)
+        hip.gemm_select(0)
     assert rel_l2(outs[0], ref) < (2e-3 if epi in (0, 1) else 2e-4)
     for o in outs[1:]:
         assert torch.equal(o, outs[0])  # deterministic across launches (no data race on the LDS stages)
 
 
-def test_gemm256_detects_transpose(dev):
+@pytest.mark.parametrize("kernel", [2, 3])
+def test_gemm256_detects_transpose(dev, kernel):
     from lfm_amd import hip
 
     A = torch.eye(256, 256).half()
     W = (torch.arange(512 * 256).reshape(512, 256) % 97).half()
-    hip.lib().lfm_gemm_select(2)
+    hip.gemm_select(kernel)
     try:
         got = hip.gemm_f16(A.to(dev), W.to(dev), None, epilogue=2)
     finally:
-        hip.lib().lfm_gemm_select(0)
+        hip.gemm_select(0)
     assert torch.equal(got.cpu(), W.float().t())
 
 
