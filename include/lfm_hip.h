@@ -111,6 +111,9 @@ int lfm_gemm_select(int which);
 /* Measurement only: when enabled, every eager lfm_dit_forward records a HIP event pair around each block's fc1 GEMM (the
  * dominant kernel); lfm_profile_fc1_read synchronises and returns the per-launch durations in ms (bench.py roofline row). */
 int lfm_profile_fc1(int enable);
+/* Measurement only: s_memtime stamps written by the quadrant-phased GEMM (select flag 2) after every barrier of block 0,
+ * wave groups 0 and 1; host_out receives 2 x n_per_group values. */
+int lfm_gemm_trace_read(unsigned long long* host_out, int n_per_group);
 int lfm_profile_fc1_read(float* host_ms_out, int max_n);
 
 /* A fp16 [M,D] = LayerNorm(X fp32 [M,D], eps 1e-6, no affine) * (1 + scale[img]) + shift[img]

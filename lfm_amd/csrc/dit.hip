@@ -586,7 +586,10 @@ extern "C" int lfm_gemm_f16(const void* A, long lda, const void* W, long ldw, vo
   hipStream_t st = (hipStream_t)stream;
   ASrcRowMajor a{(const half_t*)A, lda, M, 0};
   switch (epilogue) {
-    case 0: return launch_gemm_auto(a, (const half_t*)W, ldw, M, N, K, EpiBiasF16{(half_t*)C, ldc, bias}, st);
+    case 0:
+      if (g_gemm_sel == 3 && (g_gemm_dbg & 2) && K % G256Q_BK == 0)  // measurement: the time-stamped build of the quadrant-phased kernel
+        return launch_gemm256q_tn<ASrcRowMajor, EpiBiasF16, true>(a, (const half_t*)W, ldw, M, N, K, EpiBiasF16{(half_t*)C, ldc, bias}, st);
+      return launch_gemm_auto(a, (const half_t*)W, ldw, M, N, K, EpiBiasF16{(half_t*)C, ldc, bias}, st);
     case 1:
       if (!bias) return LFM_ERR_ARG;
       return launch_gemm_auto(a, (const half_t*)W, ldw, M, N, K, EpiBiasGeluF16{(half_t*)C, ldc, bias}, st);
@@ -623,6 +626,16 @@ extern "C" int lfm_profile_fc1_read(float* ms_out, int max_n) {  // synchronises
     if (hipEventElapsedTime(&ms_out[i], g_prof_ev[2 * i], g_prof_ev[2 * i + 1]) != hipSuccess) return LFM_ERR_LAUNCH;
   }
   return n;
+}
+
+extern "C" int lfm_gemm_trace_read(unsigned long long* host_out, int n_per_group) {  // 2 x n stamps (group 0, group 1)
+  if (!host_out || n_per_group <= 0 || n_per_group > G256Q_TRACE_MAX) return LFM_ERR_ARG;
+  if (hipDeviceSynchronize() != hipSuccess) return LFM_ERR_LAUNCH;
+  for (int g = 0; g < 2; ++g)
+    if (hipMemcpyFromSymbol(host_out + (size_t)g * n_per_group, HIP_SYMBOL(g256q_trace), sizeof(unsigned long long) * n_per_group,
+                            sizeof(unsigned long long) * G256Q_TRACE_MAX * g, hipMemcpyDeviceToHost) != hipSuccess)
+      return LFM_ERR_LAUNCH;
+  return LFM_OK;
 }
 
 extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w, void* workspace, size_t workspace_bytes,

@@ -37,12 +37,19 @@
 #define G256Q_BUF_BYTES (4 * G256Q_PIECE)
 #define G256Q_LDS_BYTES (2 * G256Q_BUF_BYTES)
 
+// Measurement only (lfm_gemm_select flag 2): waves 0 and 4 of block 0 take SIX s_memtime stamps per phase (phase start, reads
+// issued, DMAs issued, vmcnt wait done, first barrier passed, MFMAs issued) into SGPRs, wait for them once at the end of the
+// phase (when the LDS queue is empty anyway) and park them in the 32 KiB of LDS above the operand ring; they are copied out
+// after the K loop.  lfm_gemm_trace_read() / tools/phase_trace.py.  One copy per translation unit; dit.hip's is read back.
+#define G256Q_TRACE_MAX 2048
+static __device__ unsigned long long g256q_trace[2][G256Q_TRACE_MAX];
+
 template <int V>
 struct g256q_ic {
   static constexpr int value = V;
 };
 
-template <class ASrc, class Epi>
+template <class ASrc, class Epi, bool TRACE>
 __global__ __launch_bounds__(512) void gemm256q_tn_kernel(ASrc asrc, const half_t* __restrict__ W, long ldw, int M, int N, int K,
                                                            int tiles_n, Epi epi, long bsA, long bsW, long bsC, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -97,35 +104,74 @@ __global__ __launch_bounds__(512) void gemm256q_tn_kernel(ASrc asrc, const half_
   const int w_rd = (wn * 32 + (lane & 31)) * 128;
   half8_t af[2][4], wf[2][4];  // A: [32-row block][k16 step] of the current sub;  W: [sub][k16 step]
 
-  auto read_a = [&](const char* slot) {
+  // The reads are inline asm (invisible to the compiler's wait insertion, which otherwise puts a full lgkmcnt(0) in front of
+  // the first MFMA of a phase), issued in the order the MFMAs consume them (k16-step major), and every pair of MFMAs is preceded
+  // by a COUNTED lgkmcnt: the first MFMAs start as soon as their own fragments are there while the later reads are in flight.
+  // per-k16-step read addresses (the swizzle term depends on ks and on the lane, the rest is a compile-time offset)
+  int a_addr[4], w_addr[4];
 #pragma unroll
-    for (int i2 = 0; i2 < 2; ++i2)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) af[i2][ks] = *(const half8_t*)(slot + a_rd + i2 * 4096 + (((ks * 2 + chalf) ^ rkey) << 4));
+  for (int ks = 0; ks < 4; ++ks) {
+    a_addr[ks] = a_rd + (((ks * 2 + chalf) ^ rkey) << 4);
+    w_addr[ks] = w_rd + (((ks * 2 + chalf) ^ rkey) << 4);
+  }
+  auto lds_read = [&](half8_t& dst, int addr, auto OFFC) {  // OFF < 65536 (ds offset field); the caller folds the rest into addr
+    constexpr int OFF = decltype(OFFC)::value;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
   };
-  auto read_w = [&](int s, const char* slot) {
+  auto read_a = [&](auto BUFC, auto SLOTC) {
+    constexpr int HI = decltype(BUFC)::value * G256Q_BUF_BYTES, SLOT = decltype(SLOTC)::value;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) wf[s][ks] = *(const half8_t*)(slot + w_rd + (((ks * 2 + chalf) ^ rkey) << 4));
+    for (int ks = 0; ks < 4; ++ks) {
+      lds_read(af[0][ks], a_addr[ks] + HI, g256q_ic<SLOT>{});
+      lds_read(af[1][ks], a_addr[ks] + HI, g256q_ic<SLOT + 4096>{});
+    }
+  };
+  auto read_w = [&](int s, auto BUFC, auto SLOTC) {
+    constexpr int HI = decltype(BUFC)::value * G256Q_BUF_BYTES, SLOT = decltype(SLOTC)::value;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) lds_read(wf[s][ks], w_addr[ks] + HI, g256q_ic<SLOT>{});
   };
 
-#define G256Q_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define G256Q_VMCNT(n)                                       \
+  do {                                                       \
+    stamp(2);                                                \
+    asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory");    \
+  } while (0)
+  int trace_n = 0;
+  unsigned long long tstamp[6];
+  auto stamp = [&](int i) {
+    if constexpr (TRACE) asm volatile("s_memtime %0" : "=s"(tstamp[i])::"memory");
+  };
+  auto stamp_flush = [&]() {
+    if constexpr (TRACE) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (wn == 0 && lane == 0 && trace_n + 6 <= G256Q_TRACE_MAX) {
+        unsigned long long* dst = (unsigned long long*)(smem + G256Q_LDS_BYTES + g * 16384) + trace_n;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) dst[i] = tstamp[i];
+      }
+      trace_n += 6;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  };
 
   // One phase of K-tile t.  PH 0..3, BUF = K-tile parity.  s1 / s2: K-tiles t+1 / t+2 exist (wave-uniform).
   auto phase = [&](auto PHC, auto BUFC, int t, bool s1, bool s2) {
     constexpr int PH = decltype(PHC)::value, BUF = decltype(BUFC)::value;
     char* cur = smem + BUF * G256Q_BUF_BYTES;
     char* oth = smem + (BUF ^ 1) * G256Q_BUF_BYTES;
-    if constexpr (PH == 0) {
-      read_w(0, cur + G256Q_SLOT_B0);
-      __builtin_amdgcn_sched_barrier(0);
-      read_a(cur + G256Q_SLOT_A0);
-    } else if constexpr (PH == 1) {
-      read_w(1, cur + G256Q_SLOT_B1);
-    } else if constexpr (PH == 2) {
-      read_a(cur + G256Q_SLOT_A1);
-    }
-    __builtin_amdgcn_sched_barrier(0);
     constexpr int I0 = (PH >= 2) ? 2 : 0, J = (PH == 1 || PH == 2) ? 1 : 0;
+    stamp(0);
+    if constexpr (PH == 0) {
+      read_w(0, BUFC, g256q_ic<G256Q_SLOT_B0>{});
+      read_a(BUFC, g256q_ic<G256Q_SLOT_A0>{});
+    } else if constexpr (PH == 1) {
+      read_w(1, BUFC, g256q_ic<G256Q_SLOT_B1>{});
+    } else if constexpr (PH == 2) {
+      read_a(BUFC, g256q_ic<G256Q_SLOT_A1>{});
+    }
+    stamp(1);
+    __builtin_amdgcn_sched_barrier(0);
     // stage one piece, then wait until everything the NEXT phase reads has landed: with the piece order of the header
     // that is "all but my newest four pieces" in steady state, fewer once the stream of pieces has ended
     if constexpr (PH == 0) {
@@ -150,15 +196,35 @@ __global__ __launch_bounds__(512) void gemm256q_tn_kernel(ASrc asrc, const half_
       } else if (s1) G256Q_VMCNT(4);
       // last K-tile: nothing left to wait for
     }
+    stamp(3);
     G256_BARRIER();
-    G256_LGKM0();
-    __builtin_amdgcn_s_setprio(1);
+    stamp(4);
+    if (!(dbg & 8)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+    for (int ks = 0; ks < 4; ++ks) {
+      if constexpr (PH < 3) {
+        // reads still allowed in flight before k16 step ks:  P1 (4 W + 8 A, ks-major): 6,4,2,0;  P2 (4 W): 3,2,1,0;  P3 (8 A): 6,4,2,0
+        if constexpr (PH == 1) {
+          if (ks == 0) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+          else if (ks == 1) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+          else if (ks == 2) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+          else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
+          if (ks == 0) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+          else if (ks == 1) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+          else if (ks == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+          else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int i2 = 0; i2 < 2; ++i2)
         acc[I0 + i2][J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[J][ks], af[i2][ks], acc[I0 + i2][J], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     __builtin_amdgcn_s_setprio(0);
+    stamp(5);
+    stamp_flush();
     if (PH < 3 || s1 || g == 0) G256_BARRIER();  // group 1 ran one extra barrier up front: it skips the very last one
   };
   auto tile = [&](auto BUFC, int t) {
@@ -198,23 +264,32 @@ __global__ __launch_bounds__(512) void gemm256q_tn_kernel(ASrc asrc, const half_
 
   // group 0's last barrier is group 1's first barrier of its last phase (P4: no reads), every earlier read has been
   // retired and every piece has landed: the LDS is free for the epilogue scratch
+  if constexpr (TRACE) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && wn == 0) {
+      const unsigned long long* src = (const unsigned long long*)(smem + G256Q_LDS_BYTES + g * 16384);
+      const int n = trace_n < G256Q_TRACE_MAX ? trace_n : G256Q_TRACE_MAX;
+      for (int i = lane; i < n; i += 64) g256q_trace[g][i] = src[i];
+    }
+    __syncthreads();
+  }
   g256_epilogue(acc, smem, epi, m0, n0, M, N, g, wn, lane, wave, bz, bsC, dbg);
 }
 
-template <class ASrc, class Epi>
+template <class ASrc, class Epi, bool TRACE = false>
 static inline int launch_gemm256q_tn(const ASrc& asrc, const half_t* W, long ldw, int M, int N, int K, const Epi& epi, hipStream_t stream,
                                      int batch = 1, long bsA = 0, long bsW = 0, long bsC = 0) {
   if (M <= 0 || N <= 0 || K <= 0 || (K % G256Q_BK) != 0 || (N % 4) != 0) return LFM_ERR_SHAPE;
   if ((ldw % 8) != 0 || ((uintptr_t)W & 15)) return LFM_ERR_ALIGN;
   const int tm = cdiv(M, G256_BM), tn = cdiv(N, G256_BN);
+  constexpr int lds = G256Q_LDS_BYTES + (TRACE ? 32768 : 0);  // the trace parks its stamps above the operand ring
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm256q_tn_kernel<ASrc, Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, G256Q_LDS_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemm256q_tn_kernel<ASrc, Epi, TRACE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return LFM_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm256q_tn_kernel<ASrc, Epi>), dim3(tm * tn, batch), dim3(512), G256Q_LDS_BYTES, stream, asrc, W, ldw, M, N, K, tn, epi,
-                     bsA, bsW, bsC, lfm_gemm_debug_flags());
+  hipLaunchKernelGGL((gemm256q_tn_kernel<ASrc, Epi, TRACE>), dim3(tm * tn, batch), dim3(512), lds, stream, asrc, W, ldw, M, N, K, tn, epi, bsA,
+                     bsW, bsC, lfm_gemm_debug_flags());
   LFM_CHECK_LAUNCH();
   return LFM_OK;
 }

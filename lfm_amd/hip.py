@@ -58,6 +58,8 @@ def lib():
                                C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.c_int, C.c_void_p]
     L.lfm_gemm_select.restype = C.c_int
     L.lfm_gemm_select.argtypes = [C.c_int]
+    L.lfm_gemm_trace_read.restype = C.c_int
+    L.lfm_gemm_trace_read.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
     L.lfm_profile_fc1.restype = C.c_int
     L.lfm_profile_fc1.argtypes = [C.c_int]
     L.lfm_profile_fc1_read.restype = C.c_int
