@@ -588,7 +588,8 @@ extern "C" int lfm_gemm_f16(const void* A, long lda, const void* W, long ldw, vo
   switch (epilogue) {
     case 0:
       if (g_gemm_sel == 3 && (g_gemm_dbg & 2) && K % G256Q_BK == 0)  // measurement: the time-stamped build of the quadrant-phased kernel
-        return launch_gemm256q_tn<ASrcRowMajor, EpiBiasF16, true>(a, (const half_t*)W, ldw, M, N, K, EpiBiasF16{(half_t*)C, ldc, bias}, st);
+        return (g_gemm_dbg & 1) ? launch_gemm256q_tn<ASrcRowMajor, EpiBiasF16, true, 0>(a, (const half_t*)W, ldw, M, N, K, EpiBiasF16{(half_t*)C, ldc, bias}, st)
+                                : launch_gemm256q_tn<ASrcRowMajor, EpiBiasF16, true, 1>(a, (const half_t*)W, ldw, M, N, K, EpiBiasF16{(half_t*)C, ldc, bias}, st);
       return launch_gemm_auto(a, (const half_t*)W, ldw, M, N, K, EpiBiasF16{(half_t*)C, ldc, bias}, st);
     case 1:
       if (!bias) return LFM_ERR_ARG;

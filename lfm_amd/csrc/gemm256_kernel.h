@@ -270,7 +270,7 @@ static inline int launch_gemm256_tn(const ASrc& asrc, const half_t* W, long ldw,
     attr_set = true;
   }
   hipLaunchKernelGGL((gemm256_tn_kernel<ASrc, Epi>), dim3(tm * tn, batch), dim3(512), G256_LDS_BYTES, stream, asrc, W, ldw, M, N, K, tn, epi,
-                     bsA, bsW, bsC, lfm_gemm_debug_flags());
+                     bsA, bsW, bsC, lfm_gemm_selected() == 2 ? lfm_gemm_debug_flags() : (lfm_gemm_debug_flags() & 4));  // other flags belong to v3
   LFM_CHECK_LAUNCH();
   return LFM_OK;
 }

@@ -49,7 +49,7 @@ struct g256q_ic {
   static constexpr int value = V;
 };
 
-template <class ASrc, class Epi, bool TRACE>
+template <class ASrc, class Epi, bool TRACE, int SCHED>
 __global__ __launch_bounds__(512) void gemm256q_tn_kernel(ASrc asrc, const half_t* __restrict__ W, long ldw, int M, int N, int K,
                                                            int tiles_n, Epi epi, long bsA, long bsW, long bsC, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -155,12 +155,13 @@ __global__ __launch_bounds__(512) void gemm256q_tn_kernel(ASrc asrc, const half_
     }
   };
 
-  // One phase of K-tile t.  PH 0..3, BUF = K-tile parity.  s1 / s2: K-tiles t+1 / t+2 exist (wave-uniform).
-  auto phase = [&](auto PHC, auto BUFC, int t, bool s1, bool s2) {
+  // LOAD part of phase PH of K-tile t (BUF = K-tile parity; s1 / s2: K-tiles t+1 / t+2 exist, wave-uniform): the phase's fragment
+  // reads, one piece staged, and the counted wait.  SCHED 0 waits for what the NEXT phase reads (four pieces stay in flight),
+  // SCHED 1 for what the phase after the next reads (three pieces).
+  auto load_part = [&](auto PHC, auto BUFC, int t, bool s1, bool s2) {
     constexpr int PH = decltype(PHC)::value, BUF = decltype(BUFC)::value;
     char* cur = smem + BUF * G256Q_BUF_BYTES;
     char* oth = smem + (BUF ^ 1) * G256Q_BUF_BYTES;
-    constexpr int I0 = (PH >= 2) ? 2 : 0, J = (PH == 1 || PH == 2) ? 1 : 0;
     stamp(0);
     if constexpr (PH == 0) {
       read_w(0, BUFC, g256q_ic<G256Q_SLOT_B0>{});
@@ -172,32 +173,42 @@ __global__ __launch_bounds__(512) void gemm256q_tn_kernel(ASrc asrc, const half_
     }
     stamp(1);
     __builtin_amdgcn_sched_barrier(0);
-    // stage one piece, then wait until everything the NEXT phase reads has landed: with the piece order of the header
-    // that is "all but my newest four pieces" in steady state, fewer once the stream of pieces has ended
     if constexpr (PH == 0) {
       if (s1) issue_b(1, t + 1, oth + G256Q_SLOT_B1);
-      if (s1) G256Q_VMCNT(8);
-      else G256Q_VMCNT(2);
     } else if constexpr (PH == 1) {
       if (s1) issue_a(1, oth + G256Q_SLOT_A1);  // A-source state = K-tile t+1 (set in P3(t-1) / the prologue)
-      if (s1) G256Q_VMCNT(8);
-      else G256Q_VMCNT(0);
     } else if constexpr (PH == 2) {
       if (s2) {
         asrc.begin_tile(t + 2, G256Q_BK);
         issue_a(0, cur + G256Q_SLOT_A0);
-        G256Q_VMCNT(8);
-      } else if (s1) G256Q_VMCNT(6);
-      else G256Q_VMCNT(0);
+      }
     } else {
-      if (s2) {
-        issue_b(0, t + 2, cur + G256Q_SLOT_B0);
-        G256Q_VMCNT(8);
-      } else if (s1) G256Q_VMCNT(4);
-      // last K-tile: nothing left to wait for
+      if (s2) issue_b(0, t + 2, cur + G256Q_SLOT_B0);
+    }
+    if constexpr (SCHED == 0) {  // pieces allowed in flight: 4 4 4 4 | second-to-last tile 4 4 3 2 | last tile 1 0 0 -
+      if (s2) G256Q_VMCNT(8);
+      else if (s1) {
+        if constexpr (PH < 2) G256Q_VMCNT(8);
+        else if constexpr (PH == 2) G256Q_VMCNT(6);
+        else G256Q_VMCNT(4);
+      } else {
+        if constexpr (PH == 0) G256Q_VMCNT(2);
+        else if constexpr (PH < 3) G256Q_VMCNT(0);
+      }
+    } else {  // 3 3 3 3 | 3 3 2 1 | 0 0 0 0
+      if (s2) G256Q_VMCNT(6);
+      else if (s1) {
+        if constexpr (PH < 2) G256Q_VMCNT(6);
+        else if constexpr (PH == 2) G256Q_VMCNT(4);
+        else G256Q_VMCNT(2);
+      } else G256Q_VMCNT(0);
     }
     stamp(3);
-    G256_BARRIER();
+  };
+  // MFMA part of phase PH: one 64x32 quadrant x K = 64, every pair of MFMAs behind a counted lgkmcnt
+  auto mfma_part = [&](auto PHC) {
+    constexpr int PH = decltype(PHC)::value;
+    constexpr int I0 = (PH >= 2) ? 2 : 0, J = (PH == 1 || PH == 2) ? 1 : 0;
     stamp(4);
     if (!(dbg & 8)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -224,18 +235,9 @@ __global__ __launch_bounds__(512) void gemm256q_tn_kernel(ASrc asrc, const half_
     }
     __builtin_amdgcn_s_setprio(0);
     stamp(5);
-    stamp_flush();
-    if (PH < 3 || s1 || g == 0) G256_BARRIER();  // group 1 ran one extra barrier up front: it skips the very last one
-  };
-  auto tile = [&](auto BUFC, int t) {
-    const bool s1 = t + 1 < nk, s2 = t + 2 < nk;
-    phase(g256q_ic<0>{}, BUFC, t, s1, s2);
-    phase(g256q_ic<1>{}, BUFC, t, s1, s2);
-    phase(g256q_ic<2>{}, BUFC, t, s1, s2);
-    phase(g256q_ic<3>{}, BUFC, t, s1, s2);
   };
 
-  // ---- prologue: pieces A0(0) B0(0) B1(0) A1(0) [A0(1) B0(1)]; the first two must have landed before P1(0)
+  // ---- prologue: pieces A0(0) B0(0) B1(0) A1(0) [A0(1) B0(1)]
   asrc.begin_tile(0, G256Q_BK);
   issue_a(0, smem + G256Q_SLOT_A0);
   issue_b(0, 0, smem + G256Q_SLOT_B0);
@@ -245,20 +247,78 @@ __global__ __launch_bounds__(512) void gemm256q_tn_kernel(ASrc asrc, const half_
     asrc.begin_tile(1, G256Q_BK);
     issue_a(0, smem + G256Q_BUF_BYTES + G256Q_SLOT_A0);
     issue_b(0, 1, smem + G256Q_BUF_BYTES + G256Q_SLOT_B0);
-    G256Q_VMCNT(8);
-  } else {
-    G256Q_VMCNT(4);
   }
-  G256_BARRIER();
-  if (g == 1) G256_BARRIER();  // group 1 stays one barrier behind from here on
-
-  {
+  if constexpr (SCHED == 0) {
+    // phase = [LOAD part] barrier [MFMA part] barrier, group 1 one barrier behind: see the header.  P1(0) reads pieces 0, 1.
+    if (nk > 1) G256Q_VMCNT(8);
+    else G256Q_VMCNT(4);
+    G256_BARRIER();
+    if (g == 1) G256_BARRIER();
+    auto tile = [&](auto BUFC, int t) {
+      const bool s1 = t + 1 < nk, s2 = t + 2 < nk;
+      auto phase = [&](auto PHC) {
+        load_part(PHC, BUFC, t, s1, s2);
+        G256_BARRIER();
+        mfma_part(PHC);
+        stamp_flush();
+        if (decltype(PHC)::value < 3 || s1 || g == 0) G256_BARRIER();  // group 1 skips the very last barrier
+      };
+      phase(g256q_ic<0>{});
+      phase(g256q_ic<1>{});
+      phase(g256q_ic<2>{});
+      phase(g256q_ic<3>{});
+    };
     int t = 0;
     for (; t + 1 < nk; t += 2) {
       tile(g256q_ic<0>{}, t);
       tile(g256q_ic<1>{}, t + 1);
     }
     if (t < nk) tile(g256q_ic<0>{}, t);
+  } else {
+    // SCHED 1: ONE barrier per phase.  Between two barriers group 0 runs  MFMA(p), LOAD(p+1)  and group 1 runs  LOAD(p), MFMA(p):
+    // still "one wave of a SIMD computes while the other loads", but the hand-over inside the interval is not a barrier (the
+    // second wave's MFMAs simply queue behind the first wave's), so a K-tile costs 4 barrier round trips instead of 8.
+    //   RAW  the wait in LOAD(p) covers the pieces read in phase p+2: for either group a barrier lies between every wave's
+    //        wait and the first read (group 0 reads them in LOAD(p+2) one interval later, group 1 two intervals later);
+    //   WAR  a piece read in phase r is retired by the counted waits of MFMA(r), before the barrier that ends the interval of
+    //        group 1's MFMA(r); it is re-staged in LOAD(r+2) or later, which for either group starts after that barrier.
+    if (nk > 1) G256Q_VMCNT(6);  // phases 0 and 1 read pieces 0, 1, 2
+    else G256Q_VMCNT(2);
+    G256_BARRIER();
+    auto run = [&](auto GC) {  // one copy of the loop per group (a per-phase branch on g made the register allocator spill)
+      constexpr int G = decltype(GC)::value;
+      if constexpr (G == 0) load_part(g256q_ic<0>{}, g256q_ic<0>{}, 0, 1 < nk, 2 < nk);
+      G256_BARRIER();
+      auto tile = [&](auto BUFC, int t) {
+        constexpr int BUF = decltype(BUFC)::value;
+        const bool s1 = t + 1 < nk, s2 = t + 2 < nk, s3 = t + 3 < nk;
+        auto phase = [&](auto PHC) {
+          constexpr int PH = decltype(PHC)::value;
+          if constexpr (G == 0) {
+            mfma_part(PHC);
+            if constexpr (PH < 3) load_part(g256q_ic<PH + 1>{}, BUFC, t, s1, s2);
+            else if (s1) load_part(g256q_ic<0>{}, g256q_ic<(BUF ^ 1)>{}, t + 1, s2, s3);
+          } else {
+            load_part(PHC, BUFC, t, s1, s2);
+            mfma_part(PHC);
+          }
+          stamp_flush();
+          G256_BARRIER();
+        };
+        phase(g256q_ic<0>{});
+        phase(g256q_ic<1>{});
+        phase(g256q_ic<2>{});
+        phase(g256q_ic<3>{});
+      };
+      int t = 0;
+      for (; t + 1 < nk; t += 2) {
+        tile(g256q_ic<0>{}, t);
+        tile(g256q_ic<1>{}, t + 1);
+      }
+      if (t < nk) tile(g256q_ic<0>{}, t);
+    };
+    if (g == 0) run(g256q_ic<0>{});
+    else run(g256q_ic<1>{});
   }
 #undef G256Q_VMCNT
 
@@ -275,7 +335,7 @@ __global__ __launch_bounds__(512) void gemm256q_tn_kernel(ASrc asrc, const half_
   g256_epilogue(acc, smem, epi, m0, n0, M, N, g, wn, lane, wave, bz, bsC, dbg);
 }
 
-template <class ASrc, class Epi, bool TRACE = false>
+template <class ASrc, class Epi, bool TRACE = false, int SCHED = 1>
 static inline int launch_gemm256q_tn(const ASrc& asrc, const half_t* W, long ldw, int M, int N, int K, const Epi& epi, hipStream_t stream,
                                      int batch = 1, long bsA = 0, long bsW = 0, long bsC = 0) {
   if (M <= 0 || N <= 0 || K <= 0 || (K % G256Q_BK) != 0 || (N % 4) != 0) return LFM_ERR_SHAPE;
@@ -284,11 +344,11 @@ static inline int launch_gemm256q_tn(const ASrc& asrc, const half_t* W, long ldw
   constexpr int lds = G256Q_LDS_BYTES + (TRACE ? 32768 : 0);  // the trace parks its stamps above the operand ring
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm256q_tn_kernel<ASrc, Epi, TRACE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemm256q_tn_kernel<ASrc, Epi, TRACE, SCHED>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return LFM_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm256q_tn_kernel<ASrc, Epi, TRACE>), dim3(tm * tn, batch), dim3(512), lds, stream, asrc, W, ldw, M, N, K, tn, epi, bsA,
+  hipLaunchKernelGGL((gemm256q_tn_kernel<ASrc, Epi, TRACE, SCHED>), dim3(tm * tn, batch), dim3(512), lds, stream, asrc, W, ldw, M, N, K, tn, epi, bsA,
                      bsW, bsC, lfm_gemm_debug_flags());
   LFM_CHECK_LAUNCH();
   return LFM_OK;
@@ -302,7 +362,11 @@ static inline int launch_gemm_auto(const ASrc& asrc, const half_t* W, long ldw, 
   const long tiles256 = (long)cdiv(M, 256) * cdiv(N, 256) * batch;
   const int sel = lfm_gemm_selected();
   const bool big = tiles256 >= 192 && N >= 256 && M >= 256;
-  if ((sel == 3 || (sel == 0 && big)) && (K % G256Q_BK) == 0) return launch_gemm256q_tn(asrc, W, ldw, M, N, K, epi, stream, batch, bsA, bsW, bsC);
+  if ((sel == 3 || (sel == 0 && big)) && (K % G256Q_BK) == 0) {
+    if (lfm_gemm_debug_flags() & 1)  // A/B switch: the two-barriers-per-phase schedule
+      return launch_gemm256q_tn<ASrc, Epi, false, 0>(asrc, W, ldw, M, N, K, epi, stream, batch, bsA, bsW, bsC);
+    return launch_gemm256q_tn(asrc, W, ldw, M, N, K, epi, stream, batch, bsA, bsW, bsC);
+  }
   if (sel == 2 || sel == 3 || (sel == 0 && big)) return launch_gemm256_tn(asrc, W, ldw, M, N, K, epi, stream, batch, bsA, bsW, bsC);
   return launch_gemm_tn(asrc, W, ldw, M, N, K, epi, stream, batch, bsA, bsW, bsC);
 }

@@ -58,9 +58,9 @@ def test_gemm_epilogues(dev, M, N, K, epi):
 @pytest.mark.parametrize("M,N,K", [(512, 512, 128), (1024, 768, 1024), (300, 260, 64), (4096, 1024, 4096), (8192, 3072, 1024),
                                    (512, 256, 192), (256, 512, 320), (768, 512, 576)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
-@pytest.mark.parametrize("kernel", [2, 3])
+@pytest.mark.parametrize("kernel", [2, 3, 3 | (1 << 4)])
 def test_gemm256_kernels(dev, M, N, K, epi, kernel):
-    """Same checks with a 256x256 kernel forced (lfm_gemm_select: 2 = ping-pong, 3 = quadrant-phased; K covers 1, 2, 3, odd and
+    """Same checks with a 256x256 kernel forced (lfm_gemm_select: 2 = ping-pong, 3 = quadrant-phased, 3 | 1<<4 = its two-barrier schedule; K covers 1, 2, 3, odd and
     even numbers of 64-deep K-tiles, i.e. every prologue / tail path); repeated launches screen for races."""
     from lfm_amd import hip
 
