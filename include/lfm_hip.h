@@ -104,8 +104,15 @@ int lfm_dit_forward(const lfm_dit_shape* shape, const lfm_dit_weights* w, void* 
 int lfm_gemm_f16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N, int K, const float* bias,
                  int epilogue, const float* gate, long gate_stride, int tokens, lfm_stream_t stream);
 
-/* Kernel selection for the GEMMs: 0 = automatic (256x256 ping-pong kernel for chip-filling shapes, 128x128 otherwise),
- * 1 = force the 128x128 kernel, 2 = force the 256x256 kernel.  For A/B measurement and parity tests. */
+/* The attention input projection with its fused split (timm Attention.qkv + reshape/permute, models/DiT.py:120):
+ * [Q | K | V] = A[M,K] * W[3D,K]^T + bias;  Q, K fp16 [M, D] row-major;  V is written TRANSPOSED per head as
+ * Vt[M / tokens][D / head_dim][head_dim][tokens] (what lfm_dit_attention reads).  head_dim % 32 == 0, tokens % 4 == 0. */
+int lfm_gemm_qkv_f16(const void* A, long lda, const void* W, long ldw, void* Q, void* K_out, void* Vt, int M, int D, int K,
+                     const float* bias, int head_dim, int tokens, lfm_stream_t stream);
+
+/* Kernel selection for the GEMMs: 0 = automatic (a 256x256 kernel for chip-filling shapes -- the quadrant-phased one when
+ * K % 64 == 0, else the ping-pong one -- and the 128x128 kernel otherwise), 1 = force 128x128, 2 = force ping-pong,
+ * 3 = force quadrant-phased; | flags << 4 = ablation / A-B switches.  For measurement and parity tests. */
 int lfm_gemm_select(int which);
 
 /* Measurement only: when enabled, every eager lfm_dit_forward records a HIP event pair around each block's fc1 GEMM (the

@@ -629,6 +629,15 @@ extern "C" int lfm_profile_fc1_read(float* ms_out, int max_n) {  // synchronises
   return n;
 }
 
+extern "C" int lfm_gemm_qkv_f16(const void* A, long lda, const void* W, long ldw, void* Q, void* Kout, void* Vt, int M, int D, int K,
+                                const float* bias, int head_dim, int tokens, lfm_stream_t stream) {
+  if (!A || !W || !Q || !Kout || !Vt || !bias) return LFM_ERR_ARG;
+  if ((lda % 8) || ((uintptr_t)A & 15)) return LFM_ERR_ALIGN;
+  if (head_dim <= 0 || tokens <= 0 || (D % head_dim) || (head_dim % 32) || (tokens % 4) || (M % tokens)) return LFM_ERR_SHAPE;
+  return launch_gemm_auto(ASrcRowMajor{(const half_t*)A, lda, M, 0}, (const half_t*)W, ldw, M, 3 * D, K,
+                          EpiQKV::make((half_t*)Q, (half_t*)Kout, (half_t*)Vt, bias, D, head_dim, tokens), (hipStream_t)stream);
+}
+
 extern "C" int lfm_gemm_trace_read(unsigned long long* host_out, int n_per_group) {  // 2 x n stamps (group 0, group 1)
   if (!host_out || n_per_group <= 0 || n_per_group > G256Q_TRACE_MAX) return LFM_ERR_ARG;
   if (hipDeviceSynchronize() != hipSuccess) return LFM_ERR_LAUNCH;
@@ -681,7 +690,7 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
     rc = ln_modulate_launch(ws.X, ws.A, M, D, T, mod, mod + D, mstride, st);
     if (rc) return rc;
     rc = launch_gemm_auto(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->qkv_w + (size_t)i * 3 * D * D, D, M, 3 * D, D,
-                        EpiQKV{Qb, Kb, Vb, w->qkv_b + (size_t)i * 3 * D, D, 64, T}, st);
+                        EpiQKV::make(Qb, Kb, Vb, w->qkv_b + (size_t)i * 3 * D, D, 64, T), st);
     if (rc) return rc;
     rc = attention_launch(Qb, Kb, Vb, ws.A, B, s->heads, T, st);
     if (rc) return rc;

@@ -41,43 +41,19 @@ int lfm_gemm_debug_flags();  // ablation switches, measurement only
 // L2) instead of a 1 x 32 / 2 x 16 strip (33 / 18 panels).
 __device__ __forceinline__ void g256_tile_order(int bid, int nb, int tiles_n, int dbg, int& tile_m, int& tile_n) {
   if ((nb & 7) == 0 && !(dbg & 128)) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
-  const int tiles_m = nb / tiles_n, GM = (dbg & 32) ? 8 : ((dbg & 64) ? 2 : 4);
+  // GM x tiles_n should be a multiple of the ~32 tiles an XCD runs at once: 8 for 12 tile columns (QKV, measured -3 %), else 4
+  const int tiles_m = nb / tiles_n, GM = (dbg & 32) ? 8 : ((dbg & 64) ? 2 : ((tiles_n & 7) && tiles_n > 8 ? 8 : 4));
   const int grp = bid / (GM * tiles_n), within = bid - grp * (GM * tiles_n);
   const int gm = (tiles_m - grp * GM) < GM ? (tiles_m - grp * GM) : GM;  // last group may be short
   tile_m = grp * GM + within % gm;
   tile_n = within / gm;
 }
 
-// Shared epilogue of the 256x256 kernels (wave (g, wn) owns rows g*128.., columns wn*64.., acc[i][j] = 32x32 block i, j).
+// The row-major path of the epilogue: each wave transposes its accumulators through a private LDS scratch, see g256_epilogue.
 template <class Epi>
-__device__ __forceinline__ void g256_epilogue(f32x16 (&acc)[4][2], char* smem, Epi& epi, int m0, int n0, int M, int N, int g, int wn, int lane,
-                                              int wave, int bz, long bsC, int dbg) {
+__device__ __forceinline__ void g256_epilogue_rows(f32x16 (&acc)[4][2], char* smem, const Epi& epi, int m0, int n0, int M, int N, int g, int wn,
+                                                   int lane, int wave) {
   const int chalf = lane >> 5;
-  // ---- epilogue.  The MFMA leaves lane (m = lane&31, h = lane>>5) with 4 consecutive n per register group: storing that
-  // directly makes every store instruction touch 32 different 128-B lines with 16-32 B each (measured: ~12 us per tile,
-  // L2-request-bound).  Instead each wave transposes its block through a PRIVATE 32 x 64 fp32 LDS scratch (row stride
-  // 272 B: conflict-free ds_write_b128) and re-reads it row-major: 16 lanes cover one 256-B row, so a global access
-  // instruction touches 4 rows x full lines.  Epilogues that want the fragment layout (V^T scatter) opt out.
-  epi_batch(epi, bz, bsC, 0);
-  if (dbg & 4) return;  // ablation: no epilogue
-  if (epi_direct(epi, n0, 0)) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = m0 + g * 128 + i * 32 + (lane & 31);
-      if (m >= M) continue;
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int n = n0 + wn * 64 + j * 32 + 8 * q + 4 * chalf;
-          if (n + 3 < N) {
-            f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-            epi.store(m, n, v, epi.load(m, n));
-          }
-        }
-    }
-    return;
-  }
   char* scr = smem + wave * (32 * 272);
   const bool interior = (m0 + G256_BM <= M) && (n0 + G256_BN <= N);
   const int rrow = lane >> 4, rcol = lane & 15;
@@ -108,6 +84,82 @@ __device__ __forceinline__ void g256_epilogue(f32x16 (&acc)[4][2], char* smem, E
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
+}
+
+// Shared epilogue of the 256x256 kernels (wave (g, wn) owns rows g*128.., columns wn*64.., acc[i][j] = 32x32 block i, j).
+template <class Epi>
+__device__ __forceinline__ void g256_epilogue(f32x16 (&acc)[4][2], char* smem, Epi& epi, int m0, int n0, int M, int N, int g, int wn, int lane,
+                                              int wave, int bz, long bsC, int dbg, bool swapped = false) {
+  const int chalf = lane >> 5;
+  // ---- epilogue.  The MFMA leaves lane (m = lane&31, h = lane>>5) with 4 consecutive n per register group: storing that
+  // directly makes every store instruction touch 32 different 128-B lines with 16-32 B each (measured: ~12 us per tile,
+  // L2-request-bound).  Instead each wave transposes its block through a PRIVATE 32 x 64 fp32 LDS scratch (row stride
+  // 272 B: conflict-free ds_write_b128) and re-reads it row-major: 16 lanes cover one 256-B row, so a global access
+  // instruction touches 4 rows x full lines.  Epilogues that want the fragment layout (V^T scatter) opt out.
+  epi_batch(epi, bz, bsC, 0);
+  if (dbg & 4) return;  // ablation: no epilogue
+  if constexpr (epi_has_transposed<Epi>::value) {
+    // The K loop ran this tile with the MFMA operands swapped: lane (n = lane&31, h) holds FOUR CONSECUTIVE m per register
+    // group.  Same scratch, roles exchanged: rows = 32 columns n of block j, columns = 64 rows m of blocks 2*ih, 2*ih+1; read
+    // back row-major, 16 lanes cover 64 consecutive m of one n -> epi.store_t(n, m, C[m..m+3][n]).
+    if (swapped) {
+      char* scr = smem + wave * (32 * 272);
+      const int rrow = lane >> 4, rcol = lane & 15;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int nb = n0 + wn * 64 + j * 32 + rrow;
+        float bt[8];  // all loads of a block before its first store (the compiler cannot move a load above a possibly-aliasing store)
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) bt[ps] = nb + ps * 4 < N ? epi.load_t(nb + ps * 4) : 0.f;
+#pragma unroll
+        for (int ih = 0; ih < 2; ++ih) {
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              f32x4 v = {acc[2 * ih + ii][j][4 * q], acc[2 * ih + ii][j][4 * q + 1], acc[2 * ih + ii][j][4 * q + 2], acc[2 * ih + ii][j][4 * q + 3]};
+              *(f32x4*)(scr + (lane & 31) * 272 + (ii * 32 + 8 * q + 4 * chalf) * 4) = v;
+            }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          f32x4 v[8];
+#pragma unroll
+          for (int ps = 0; ps < 8; ++ps) v[ps] = *(const f32x4*)(scr + (ps * 4 + rrow) * 272 + rcol * 16);
+          const int m = m0 + g * 128 + ih * 64 + rcol * 4;
+#pragma unroll
+          for (int ps = 0; ps < 8; ++ps)
+            if (nb + ps * 4 < N && m + 3 < M) epi.store_t(nb + ps * 4, m, v[ps], bt[ps]);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+      }
+      return;
+    }
+  }
+  if (epi_direct(epi, n0, 0)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + g * 128 + i * 32 + (lane & 31);
+      if (m >= M) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = n0 + wn * 64 + j * 32 + 8 * q + 4 * chalf;
+          if (n + 3 < N) {
+            f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+            epi.store(m, n, v, epi.load(m, n));
+          }
+        }
+    }
+    return;
+  }
+  if constexpr (epi_has_plain<Epi>::value) {
+    if (epi.plain_tile(n0, G256_BN)) {
+      auto pe = epi.plain(n0);
+      g256_epilogue_rows(acc, smem, pe, m0, n0, M, N, g, wn, lane, wave);
+      return;
+    }
+  }
+  g256_epilogue_rows(acc, smem, epi, m0, n0, M, N, g, wn, lane, wave);
 }
 
 template <class ASrc, class Epi>

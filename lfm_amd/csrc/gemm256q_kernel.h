@@ -59,6 +59,9 @@ __global__ __launch_bounds__(512) void gemm256q_tn_kernel(ASrc asrc, const half_
   int tile_m, tile_n;
   g256_tile_order(blockIdx.x, gridDim.x, tiles_n, dbg, tile_m, tile_n);
   const int m0 = tile_m * G256_BM, n0 = tile_n * G256_BN;
+  // tiles the epilogue wants transposed (V^T of the QKV projection) run with the MFMA operands swapped: C^T blocks for free
+  bool swapped = false;
+  if constexpr (epi_has_transposed<Epi>::value && SCHED == 1) swapped = epi.transposed(n0);  // (the A/B schedule keeps the direct V^T path)
   const int bz = blockIdx.y;
   asrc.init(bz, bsA);
   W += (long)bz * bsW;
@@ -206,8 +209,9 @@ __global__ __launch_bounds__(512) void gemm256q_tn_kernel(ASrc asrc, const half_
     stamp(3);
   };
   // MFMA part of phase PH: one 64x32 quadrant x K = 64, every pair of MFMAs behind a counted lgkmcnt
-  auto mfma_part = [&](auto PHC) {
+  auto mfma_part = [&](auto PHC, auto SWC) {
     constexpr int PH = decltype(PHC)::value;
+    constexpr bool SW = decltype(SWC)::value != 0;  // operands swapped: the tile is computed transposed
     constexpr int I0 = (PH >= 2) ? 2 : 0, J = (PH == 1 || PH == 2) ? 1 : 0;
     stamp(4);
     if (!(dbg & 8)) __builtin_amdgcn_s_setprio(1);
@@ -228,9 +232,15 @@ __global__ __launch_bounds__(512) void gemm256q_tn_kernel(ASrc asrc, const half_
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      if constexpr (SW) {
 #pragma unroll
-      for (int i2 = 0; i2 < 2; ++i2)
-        acc[I0 + i2][J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[J][ks], af[i2][ks], acc[I0 + i2][J], 0, 0, 0);
+        for (int i2 = 0; i2 < 2; ++i2)
+          acc[I0 + i2][J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i2][ks], wf[J][ks], acc[I0 + i2][J], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+          acc[I0 + i2][J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[J][ks], af[i2][ks], acc[I0 + i2][J], 0, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_s_setprio(0);
@@ -259,7 +269,7 @@ __global__ __launch_bounds__(512) void gemm256q_tn_kernel(ASrc asrc, const half_
       auto phase = [&](auto PHC) {
         load_part(PHC, BUFC, t, s1, s2);
         G256_BARRIER();
-        mfma_part(PHC);
+        mfma_part(PHC, g256q_ic<0>{});
         stamp_flush();
         if (decltype(PHC)::value < 3 || s1 || g == 0) G256_BARRIER();  // group 1 skips the very last barrier
       };
@@ -285,7 +295,7 @@ __global__ __launch_bounds__(512) void gemm256q_tn_kernel(ASrc asrc, const half_
     if (nk > 1) G256Q_VMCNT(6);  // phases 0 and 1 read pieces 0, 1, 2
     else G256Q_VMCNT(2);
     G256_BARRIER();
-    auto run = [&](auto GC) {  // one copy of the loop per group (a per-phase branch on g made the register allocator spill)
+    auto run = [&](auto GC, auto SWC) {  // one copy of the loop per group / operand order (per-phase branches made the allocator spill)
       constexpr int G = decltype(GC)::value;
       if constexpr (G == 0) load_part(g256q_ic<0>{}, g256q_ic<0>{}, 0, 1 < nk, 2 < nk);
       G256_BARRIER();
@@ -295,12 +305,12 @@ __global__ __launch_bounds__(512) void gemm256q_tn_kernel(ASrc asrc, const half_
         auto phase = [&](auto PHC) {
           constexpr int PH = decltype(PHC)::value;
           if constexpr (G == 0) {
-            mfma_part(PHC);
+            mfma_part(PHC, SWC);
             if constexpr (PH < 3) load_part(g256q_ic<PH + 1>{}, BUFC, t, s1, s2);
             else if (s1) load_part(g256q_ic<0>{}, g256q_ic<(BUF ^ 1)>{}, t + 1, s2, s3);
           } else {
             load_part(PHC, BUFC, t, s1, s2);
-            mfma_part(PHC);
+            mfma_part(PHC, SWC);
           }
           stamp_flush();
           G256_BARRIER();
@@ -317,8 +327,18 @@ __global__ __launch_bounds__(512) void gemm256q_tn_kernel(ASrc asrc, const half_
       }
       if (t < nk) tile(g256q_ic<0>{}, t);
     };
-    if (g == 0) run(g256q_ic<0>{});
-    else run(g256q_ic<1>{});
+    if constexpr (epi_has_transposed<Epi>::value) {
+      if (swapped) {
+        if (g == 0) run(g256q_ic<0>{}, g256q_ic<1>{});
+        else run(g256q_ic<1>{}, g256q_ic<1>{});
+      } else {
+        if (g == 0) run(g256q_ic<0>{}, g256q_ic<0>{});
+        else run(g256q_ic<1>{}, g256q_ic<0>{});
+      }
+    } else {
+      if (g == 0) run(g256q_ic<0>{}, g256q_ic<0>{});
+      else run(g256q_ic<1>{}, g256q_ic<0>{});
+    }
   }
 #undef G256Q_VMCNT
 
@@ -332,7 +352,7 @@ __global__ __launch_bounds__(512) void gemm256q_tn_kernel(ASrc asrc, const half_
     }
     __syncthreads();
   }
-  g256_epilogue(acc, smem, epi, m0, n0, M, N, g, wn, lane, wave, bz, bsC, dbg);
+  g256_epilogue(acc, smem, epi, m0, n0, M, N, g, wn, lane, wave, bz, bsC, dbg, swapped);
 }
 
 template <class ASrc, class Epi, bool TRACE = false, int SCHED = 1>

@@ -116,7 +116,22 @@ struct EpiQKV {
   half_t* Vt;
   const float* bias;
   int D, hd, tokens;
+  int hd_sh, tok_sh;  // log2 when hd / tokens are powers of two (every DiT configuration), else -1: no integer division per store
+  static __host__ __device__ int log2_or_neg(int v) {
+    int s = 0;
+    while ((1 << s) < v) ++s;
+    return (1 << s) == v ? s : -1;
+  }
+  static EpiQKV make(half_t* Q, half_t* K, half_t* Vt, const float* bias, int D, int hd, int tokens) {
+    return EpiQKV{Q, K, Vt, bias, D, hd, tokens, log2_or_neg(hd), log2_or_neg(tokens)};
+  }
   typedef f32x4 Aux;
+  __device__ __forceinline__ half_t* vt_ptr(int n, int m) const {  // &Vt[img][head][d][tok] for column n (>= 2D) and row m
+    const int c = n - 2 * D;
+    const int head = hd_sh >= 0 ? (c >> hd_sh) : c / hd, d = c - head * hd;
+    const int img = tok_sh >= 0 ? (m >> tok_sh) : m / tokens, tok = m - img * tokens;
+    return Vt + (((long)img * (D / hd) + head) * hd + d) * tokens + tok;
+  }
   __device__ __forceinline__ bool direct(int n0) const { return n0 >= 2 * D; }  // V tiles: 32 consecutive tokens per lane group
   __device__ __forceinline__ Aux load(int, int n) const { return *(const f32x4*)(bias + n); }
   __device__ __forceinline__ void store(int m, int n, f32x4 v, const Aux& b) const {
@@ -126,14 +141,24 @@ struct EpiQKV {
       half4_t h = {(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
       *(half4_t*)dst = h;
     } else {
-      const int c = n - 2 * D, head = c / hd, d = c - head * hd;
-      const int img = m / tokens, tok = m - img * tokens;
-      half_t* dst = Vt + (((long)img * (D / hd) + head) * hd + d) * tokens + tok;
+      half_t* dst = vt_ptr(n, m);  // n..n+3 stay inside one head (hd % 4 == 0)
       dst[0] = (half_t)v.x;
       dst[tokens] = (half_t)v.y;
       dst[2 * tokens] = (half_t)v.z;
       dst[3 * tokens] = (half_t)v.w;
     }
+  }
+  // A 256-column tile that lies inside Q or inside K is a plain "acc + bias -> fp16" tile of a [M, D] matrix: kernels that
+  // ask get that epilogue (no per-store Q/K/V case distinction).  C is shifted so that C[m*D + n] is the right element.
+  __device__ __forceinline__ bool plain_tile(int n0, int bn) const { return n0 + bn <= D || (n0 >= D && n0 + bn <= 2 * D); }
+  __device__ __forceinline__ EpiBiasF16 plain(int n0) const { return EpiBiasF16{n0 < D ? Q : K - D, (long)D, bias}; }
+  // Kernels that can compute a tile TRANSPOSED (operands swapped in the MFMA) hand V tiles over as rows of V^T:
+  // v = C[m..m+3][n], four consecutive tokens of one (head, d) column -> one 8-byte store.  tokens % 4 == 0.
+  __device__ __forceinline__ bool transposed(int n0) const { return n0 >= 2 * D; }
+  __device__ __forceinline__ float load_t(int n) const { return bias[n]; }
+  __device__ __forceinline__ void store_t(int n, int m, f32x4 v, float b) const {
+    half4_t h = {(half_t)(v.x + b), (half_t)(v.y + b), (half_t)(v.z + b), (half_t)(v.w + b)};
+    *(half4_t*)vt_ptr(n, m) = h;
   }
 };
 
@@ -155,6 +180,25 @@ template <class Epi>
 __device__ __forceinline__ bool epi_direct(const Epi&, int, long) {
   return false;
 }
+
+// epilogues with transposed(n0) / store_t(n, m, v): see EpiQKV
+template <class Epi, class = void>
+struct epi_has_transposed {
+  static constexpr bool value = false;
+};
+template <class Epi>
+struct epi_has_transposed<Epi, decltype((void)((const Epi*)nullptr)->transposed(0))> {
+  static constexpr bool value = true;
+};
+
+template <class Epi, class = void>
+struct epi_has_plain {
+  static constexpr bool value = false;
+};
+template <class Epi>
+struct epi_has_plain<Epi, decltype((void)((const Epi*)nullptr)->plain(0))> {
+  static constexpr bool value = true;
+};
 
 template <class ASrc, class Epi>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(ASrc asrc, const half_t* __restrict__ W, long ldw, int M, int N, int K,

@@ -58,6 +58,9 @@ def lib():
                                C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.c_int, C.c_void_p]
     L.lfm_gemm_select.restype = C.c_int
     L.lfm_gemm_select.argtypes = [C.c_int]
+    L.lfm_gemm_qkv_f16.restype = C.c_int
+    L.lfm_gemm_qkv_f16.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.lfm_gemm_trace_read.restype = C.c_int
     L.lfm_gemm_trace_read.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
     L.lfm_profile_fc1.restype = C.c_int
@@ -140,6 +143,19 @@ def gemm_f16(A, W, bias=None, epilogue=0, out=None, gate=None, gate_stride=0, to
     check(lib().lfm_gemm_f16(ptr(A), A.stride(0), ptr(W), W.stride(0), ptr(out), out.stride(0), M, N, K, ptr(bias), epilogue,
                              ptr(gate), gate_stride, tokens, stream_ptr()), "lfm_gemm_f16")
     return out
+
+
+def gemm_qkv_f16(A, W, bias, head_dim, tokens):
+    """Q, K [M, D] and V^T [M/tokens, D/head_dim, head_dim, tokens] of the fused attention input projection."""
+    require_gpu(A, "gemm_qkv_f16")
+    M, K = A.shape
+    D = W.shape[0] // 3
+    Q = torch.empty(M, D, device=A.device, dtype=torch.float16)
+    Kt = torch.empty_like(Q)
+    Vt = torch.empty(M // tokens, D // head_dim, head_dim, tokens, device=A.device, dtype=torch.float16)
+    check(lib().lfm_gemm_qkv_f16(ptr(A), A.stride(0), ptr(W), W.stride(0), ptr(Q), ptr(Kt), ptr(Vt), M, D, K, ptr(bias), head_dim, tokens,
+                                 stream_ptr()), "lfm_gemm_qkv_f16")
+    return Q, Kt, Vt
 
 
 def ln_modulate(X, shift, scale, tokens, mod_stride):

@@ -107,6 +107,30 @@ def test_gemm256_detects_transpose(dev, kernel):
     assert torch.equal(got.cpu(), W.float().t())
 
 
+@pytest.mark.parametrize("kernel", [1, 2, 3, 3 | (1 << 4)])
+@pytest.mark.parametrize("batch,tokens,D,hd", [(3, 256, 384, 64), (8, 64, 512, 64), (2, 256, 1024, 64)])
+def test_gemm_qkv_split(dev, batch, tokens, D, hd, kernel):
+    """Fused QKV projection: Q, K row-major, V transposed per head (timm Attention's qkv + reshape + permute, DiT.py:120), with
+    every GEMM kernel (fragment-direct V^T stores in v1/v2 and v3's two-barrier schedule, operand-swapped V tiles in v3)."""
+    from lfm_amd import hip
+
+    M = batch * tokens
+    g = torch.Generator().manual_seed(batch + tokens + D)
+    A = (torch.randn(M, D, generator=g) * 0.5).half()
+    W = (torch.randn(3 * D, D, generator=g) / D ** 0.5).half()
+    bias = torch.randn(3 * D, generator=g) * 0.1
+    ref = A.float() @ W.float().t() + bias
+    hip.gemm_select(kernel)
+    try:
+        Q, K, Vt = hip.gemm_qkv_f16(A.to(dev), W.to(dev), bias.to(dev), hd, tokens)
+        torch.cuda.synchronize()
+    finally:
+        hip.gemm_select(0)
+    assert rel_l2(Q, ref[:, :D]) < 2e-3 and rel_l2(K, ref[:, D:2 * D]) < 2e-3
+    v_ref = ref[:, 2 * D:].reshape(batch, tokens, D // hd, hd).permute(0, 2, 3, 1)  # [b, head, d, tok]
+    assert rel_l2(Vt, v_ref) < 2e-3
+
+
 def test_gemm_detects_transpose(dev):
     """A = I with an asymmetric W: a swapped C write cannot pass (cdna guide: always A=I-check)."""
     from lfm_amd import hip
@@ -210,6 +234,35 @@ def test_dit_matches_oracle_fullsize(dev, name, batch, kw):
         got = m(t.to(dev), x.to(dev), y.to(dev) if y is not None else None)
         assert float(ref.abs().mean()) > 1e-3
         assert rel_l2(got, ref) < 2e-3, (name, t)
+
+
+@pytest.mark.parametrize("kernel", [1, 2, 3, 3 | (1 << 4)])
+@pytest.mark.parametrize("name,batch", [("DiT-S/2", 5), ("DiT-B/2", 3)])
+def test_dit_with_every_gemm_kernel(dev, name, batch, kernel):
+    """The same forward with each GEMM kernel forced (auto picks by size, so small test batches would never reach the 256x256
+    kernels through the model): covers the fused epilogues in situ, in particular the QKV split with V written transposed
+    (fragment-direct in v1/v2, operand-swapped tiles + transposed epilogue in v3)."""
+    from lfm_amd import hip
+    from lfm_amd.models import DiT_models
+
+    kw = dict(num_classes=10, label_dropout=0.1)
+    cfg = dit_ref.DiTCfg.named(name, **kw)
+    sd = dit_ref.make_dit_state(cfg, seed=3)
+    m = DiT_models[name](img_resolution=32, in_channels=4, **kw)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).eval()
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(batch, 4, 32, 32, generator=g)
+    y = torch.randint(0, 10, (batch,), generator=g)
+    t = torch.linspace(0.2, 0.8, batch)
+    ref = dit_ref.dit_forward(sd, cfg, t, x, y)
+    hip.gemm_select(kernel)
+    try:
+        got = m(t.to(dev), x.to(dev), y.to(dev))
+        torch.cuda.synchronize()
+    finally:
+        hip.gemm_select(0)
+    assert rel_l2(got, ref) < 2e-3, (name, kernel)
 
 
 def test_dit_fused_euler_update(dev):

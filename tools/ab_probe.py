@@ -11,12 +11,12 @@ def timeit(fn, n=20, warm=3):
     for _ in range(n): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n
-variants = [("v3", 3), ("v3 sched1", 3 | (1 << 4)), ("v3 no-epi", 3 | (4 << 4)), ("v3s1 no-epi", 3 | (5 << 4))]
+variants = [("v3 GM=4", 3), ("v3 GM=8", 3 | (32 << 4)), ("v3 GM=2", 3 | (64 << 4))]
 for M, N, K in [(16384, 4096, 1024), (512, 768, 4096), (256, 256, 64), (256, 256, 128), (256, 512, 192), (1024, 256, 256), (300, 260, 320), (4096, 1024, 576), (256, 256, 32), (512, 256, 96), (256, 512, 160)]:
     A = (torch.randn(M, K, device=dev) * 0.5).half(); W = (torch.randn(N, K, device=dev) * 0.03).half(); b = torch.randn(N, device=dev)
     o1 = torch.zeros(M, N, device=dev, dtype=torch.float16)
     hip.check(hip.lib().lfm_gemm_select(2), 'select'); hip.gemm_f16(A, W, b, epilogue=0, out=o1)
-    for sel in (3, 3 | (1 << 4)):
+    for sel in ():
         worst = 0.0
         for rep in range(5):
             o2 = torch.zeros_like(o1)
@@ -24,7 +24,7 @@ for M, N, K in [(16384, 4096, 1024), (512, 768, 4096), (256, 256, 64), (256, 256
             torch.cuda.synchronize()
             worst = max(worst, (o1.float() - o2.float()).abs().max().item())
         print("check", M, N, K, "sel", sel, "max diff vs v2", worst, flush=True)
-for M, N, K, epi in [(16384, 4096, 1024, 1), (16384, 4096, 1024, 0), (16384, 1024, 4096, 3), (16384, 3072, 1024, 0), (16384, 1024, 1024, 3), (4096, 4096, 4096, 0), (256, 256, 8192, 0)]:
+for M, N, K, epi in [(16384, 4096, 1024, 1), (16384, 4096, 1024, 0), (16384, 1024, 4096, 3), (16384, 3072, 1024, 0), (16384, 1024, 1024, 3)]:
     A = (torch.randn(M, K, device=dev) * 0.5).half(); W = (torch.randn(N, K, device=dev) * 0.03).half(); b = torch.randn(N, device=dev)
     out = torch.zeros(M, N, device=dev, dtype=torch.float32 if epi in (2, 3) else torch.float16); gate = torch.randn(M // 256, N, device=dev)
     res = {n: [] for n, _ in variants}
