@@ -174,7 +174,7 @@ def main():
     res["split_ms"] = {"solver": ev[0].elapsed_time(ev[1]), "vae_decode_u8": ev[1].elapsed_time(ev[2])}
 
     if rank == 0 and not a.no_roofline:
-        # dominant kernel: the fc1 MFMA GEMM + GELU epilogue (gemm256_tn_kernel<ASrcRowMajor, EpiBiasGeluF16>, 24 % of the step).
+        # dominant kernel: the fc1 MFMA GEMM + GELU epilogue (gemm256q_tn_kernel<ASrcRowMajor, EpiBiasGeluF16>, 25 % of the step).
         # Timed LIVE and IN SITU: eager forwards of the real model on the solver's latents with one HIP event pair recorded
         # around every block's fc1 launch on the launching stream (lfm_profile_fc1; a captured graph cannot be bracketed).
         import ctypes as C
@@ -193,9 +193,10 @@ def main():
         L.lfm_profile_fc1(0)
         dur = sum(durs) / len(durs) * 1e-3
         ach = 2.0 * M * H * D / dur / 1e12
-        # HBM traffic per launch from PMC (profiles/r01_b_fc1_gemm_hbm_pmc.json): FETCH_SIZE 98.58 MB raw -> x2 (gfx950
-        # correction of MI355X_MICROARCH.md) + WRITE_SIZE 134.22 MB; measured at this shape on the shipped kernel.
-        traffic = (2 * 98576.7 + 131072.0) * 1024 if (M, H, D) == (16384, 4096, 1024) else None
+        # HBM traffic per launch from PMC (profiles/r01_e_gemm_pmc.txt, separate FETCH_SIZE / WRITE_SIZE passes): FETCH_SIZE
+        # 100694.4 KB raw -> x2 (gfx950 correction of MI355X_MICROARCH.md for 16-B-per-lane streams) + WRITE_SIZE 135168 KB;
+        # measured at this shape on the shipped kernel.
+        traffic = (2 * 100694.4 + 135168.0) * 1024 if (M, H, D) == (16384, 4096, 1024) else None
         res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
                            "traffic": traffic, "traffic_unit": "bytes/launch (HBM, rocprofv3 PMC, separate passes)",
                            "algorithmic_bytes": 2.0 * (M * D + H * D + M * H), "algorithmic_flop": 2.0 * M * H * D,

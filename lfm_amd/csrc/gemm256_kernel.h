@@ -42,7 +42,7 @@ int lfm_gemm_debug_flags();  // ablation switches, measurement only
 __device__ __forceinline__ void g256_tile_order(int bid, int nb, int tiles_n, int dbg, int& tile_m, int& tile_n) {
   if ((nb & 7) == 0 && !(dbg & 128)) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
   // GM x tiles_n should be a multiple of the ~32 tiles an XCD runs at once: 8 for 12 tile columns (QKV, measured -3 %), else 4
-  const int tiles_m = nb / tiles_n, GM = (dbg & 32) ? 8 : ((dbg & 64) ? 2 : ((tiles_n & 7) && tiles_n > 8 ? 8 : 4));
+  const int tiles_m = nb / tiles_n, GM = (dbg & 32) ? 8 : ((dbg & 64) ? 2 : ((dbg & 256) ? 4 : ((tiles_n & 7) && tiles_n > 8 ? 8 : 4)));
   const int grp = bid / (GM * tiles_n), within = bid - grp * (GM * tiles_n);
   const int gm = (tiles_m - grp * GM) < GM ? (tiles_m - grp * GM) : GM;  // last group may be short
   tile_m = grp * GM + within % gm;
