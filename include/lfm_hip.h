@@ -167,6 +167,9 @@ int lfm_vae_decode(const lfm_vae_weights* w, void* workspace, size_t workspace_b
 
 /* u8 NHWC = trunc(clamp((x+1)/2, 0, 1) * 255) of fp32 NCHW images (test_flow_latent_ddp.py:131-135). */
 int lfm_images_to_uint8(const float* x, uint8_t* out, int N, int H, int W, lfm_stream_t stream);
+/* Same with rounding != 0: trunc(clamp((x+1)/2, 0, 1) * 255 + 0.5), the conversion of torchvision.utils.save_image that the
+ * single-process script applies (test_flow_latent.py:264-269,297). */
+int lfm_images_to_uint8_mode(const float* x, uint8_t* out, int N, int H, int W, int rounding, lfm_stream_t stream);
 
 /* ------------------------------------------------------------------ NHWC-fp16 building blocks (origin-ADM UNet)
  * The guided-diffusion UNet (models/guided_diffusion/unet.py:376-655) has a data-dependent layer list, so its forward is

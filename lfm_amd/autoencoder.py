@@ -227,11 +227,13 @@ class AutoencoderKL(nn.Module):
         return self.decode(z).sample
 
 
-def images_to_uint8(x):
-    """u8 NHWC = trunc(clamp((x+1)/2,0,1)*255) on the GPU (reference test_flow_latent_ddp.py:131-135)."""
+def images_to_uint8(x, rounding=False):
+    """u8 NHWC = trunc(clamp((x+1)/2,0,1)*255) on the GPU (reference test_flow_latent_ddp.py:131-135); ``rounding=True`` adds the 0.5 of
+    torchvision.utils.save_image, the single-process script's writer (test_flow_latent.py:264-269,297)."""
     hip.require_gpu(x, "images_to_uint8")
     x = x.contiguous().float()
     N, _, H, W = x.shape
     out = torch.empty(N, H, W, 3, dtype=torch.uint8, device=x.device)
-    hip.check(hip.lib().lfm_images_to_uint8(hip.ptr(x), hip.ptr(out), N, H, W, hip.stream_ptr(x.device)), "lfm_images_to_uint8")
+    hip.check(hip.lib().lfm_images_to_uint8_mode(hip.ptr(x), hip.ptr(out), N, H, W, int(bool(rounding)), hip.stream_ptr(x.device)),
+              "lfm_images_to_uint8_mode")
     return out

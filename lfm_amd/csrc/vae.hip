@@ -411,7 +411,9 @@ extern "C" int lfm_vae_decode(const lfm_vae_weights* w, void* workspace, size_t 
   return LFM_OK;
 }
 
-// images: u8 NHWC = trunc(clamp((x + 1) / 2, 0, 1) * 255)   (test_flow_latent_ddp.py:131-135)
+// images: u8 NHWC = trunc(clamp((x + 1) / 2, 0, 1) * 255)   (test_flow_latent_ddp.py:131-135), or with ROUND the single-process
+// script's torchvision.utils.save_image conversion  trunc(clamp(.., 0, 1) * 255 + 0.5)  (test_flow_latent.py:264-269,297)
+template <bool ROUND>
 __global__ void to_uint8_nhwc_kernel(const float* __restrict__ x, uint8_t* __restrict__ o, int HW, long total) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over N*HW pixels
   if (i >= total) return;
@@ -420,14 +422,20 @@ __global__ void to_uint8_nhwc_kernel(const float* __restrict__ x, uint8_t* __res
   for (int c = 0; c < 3; ++c) {
     float v = (x[(n * 3 + c) * HW + p] + 1.0f) * 0.5f;
     v = fminf(fmaxf(v, 0.f), 1.f) * 255.0f;
+    if (ROUND) v = fminf(v + 0.5f, 255.0f);
     o[i * 3 + c] = (uint8_t)v;
   }
 }
 
-extern "C" int lfm_images_to_uint8(const float* x, uint8_t* out, int N, int H, int W, lfm_stream_t stream) {
+extern "C" int lfm_images_to_uint8_mode(const float* x, uint8_t* out, int N, int H, int W, int rounding, lfm_stream_t stream) {
   if (!x || !out) return LFM_ERR_ARG;
+  if (N <= 0 || H <= 0 || W <= 0) return LFM_ERR_SHAPE;
   const long total = (long)N * H * W;
-  hipLaunchKernelGGL(to_uint8_nhwc_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, out, H * W, total);
+  if (rounding) hipLaunchKernelGGL(to_uint8_nhwc_kernel<true>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, out, H * W, total);
+  else hipLaunchKernelGGL(to_uint8_nhwc_kernel<false>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, out, H * W, total);
   LFM_CHECK_LAUNCH();
   return LFM_OK;
+}
+extern "C" int lfm_images_to_uint8(const float* x, uint8_t* out, int N, int H, int W, lfm_stream_t stream) {
+  return lfm_images_to_uint8_mode(x, out, N, H, W, 0, stream);
 }

@@ -81,6 +81,8 @@ def lib():
     L.lfm_vae_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.lfm_images_to_uint8.restype = C.c_int
     L.lfm_images_to_uint8.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.lfm_images_to_uint8_mode.restype = C.c_int
+    L.lfm_images_to_uint8_mode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     V, I, LG, F = C.c_void_p, C.c_int, C.c_long, C.c_float
     L.lfm_conv3x3_f16.restype = I
     L.lfm_conv3x3_f16.argtypes = [V, V, V, V, V, I, I, I, I, I, I, V]

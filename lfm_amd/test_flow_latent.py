@@ -124,10 +124,11 @@ def run_sampling(model, first_stage_model, args, num_samples, generator, device,
 
 
 def load_checkpoint(model, path, device):
-    """Flat state_dict saved from an accelerate/DDP-wrapped model (train_flow_latent.py:211-214): strip ``module.`` when present."""
-    ckpt = torch.load(path, map_location=device)
-    ckpt = {(k[7:] if k.startswith("module.") else k): v for k, v in ckpt.items()}
-    model.load_state_dict(ckpt, strict=True)
+    """``model_{epoch}.pth`` (flat state_dict of an accelerate/DDP-wrapped model, train_flow_latent.py:211-214: ``module.`` stripped when
+    present) or ``content.pth`` (train_flow_latent.py:196-203: the weights sit under ``model_dict``)."""
+    from .io_formats import load_state_dict_file
+
+    model.load_state_dict(load_state_dict_file(path, map_location=device), strict=True)
 
 
 def build_parser():
@@ -216,12 +217,10 @@ def build_models(args, device):
 
 
 def save_images_uint8(img_u8, save_dir, start_index, stride=1, offset=0):
-    from PIL import Image
+    """One JPEG per image, named by the reference's global index j * world + rank + total (test_flow_latent.py:268, _ddp:138)."""
+    from .io_formats import save_indexed_jpegs
 
-    os.makedirs(save_dir, exist_ok=True)
-    arr = img_u8.cpu().numpy()
-    for j, a in enumerate(arr):
-        Image.fromarray(a).save(os.path.join(save_dir, f"{j * stride + offset + start_index}.jpg"))
+    save_indexed_jpegs(img_u8.cpu(), save_dir, start_index, world_size=stride, rank=offset)
 
 
 def main(argv=None):
@@ -266,13 +265,28 @@ def main(argv=None):
         t0 = time.time()
         for i in range(total_samples // n):
             img = run_sampling(model, vae, args, n, generator, device)
-            save_images_uint8(images_to_uint8(img), save_dir, i * n)
+            # the single-process script writes through torchvision.utils.save_image: ROUNDING uint8 conversion (:264-269)
+            save_images_uint8(images_to_uint8(img, rounding=True), save_dir, i * n)
         print(f"wrote {total_samples} images to {save_dir} in {time.time() - t0:.1f}s; FID needs pytorch_fid + Inception weights "
-              "(not available offline): run the reference's pytorch_fid on that directory")
+              "(not available offline): run the reference's pytorch_fid on that directory (lfm_amd.io_formats has the statistics "
+              "reader and the Frechet distance)")
         return
     img = run_sampling(model, vae, args, args.batch_size, generator, device)
-    save_images_uint8(images_to_uint8(img), save_dir, 0)
-    print("Samples are saved under '{}'".format(save_dir))
+    # default mode: ONE sample sheet, nrow=8, padding=0, named as the reference names it (test_flow_latent.py:288-298)
+    from .io_formats import make_grid_nhwc, save_jpeg
+
+    if not args.use_karras_samplers:
+        save_path = "./samples_{}_{}_{}_{}".format(args.dataset, args.method, args.atol, args.rtol)
+    else:
+        save_path = "./samples_{}_{}_{}".format(args.dataset, args.method, args.num_steps)
+    if args.num_classes is not None and args.num_classes > 1:
+        save_path += "_cfg{}".format(args.cfg_scale)
+    save_path = os.path.join(args.save_dir, os.path.basename(save_path)) if args.save_dir else save_path
+    save_path += ".jpg"
+    if os.path.dirname(save_path):
+        os.makedirs(os.path.dirname(save_path), exist_ok=True)
+    save_jpeg(make_grid_nhwc(images_to_uint8(img, rounding=True).cpu(), nrow=8, padding=0), save_path)
+    print("Samples are save at '{}".format(save_path))
 
 
 if __name__ == "__main__":

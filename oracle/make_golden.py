@@ -8,6 +8,7 @@ What is imported from the reference, as-is:
   * models/DiT.py           (behind oracle/timm_shim.py -- timm is not installed)
   * models/guided_diffusion/unet.py  (UNetModel)
   * sampler/karras_sample.py, sampler/random_util.py
+  * pytorch_fid/fid_score.py::calculate_frechet_distance (loaded from its source file, torchvision / Inception imports stubbed)
 Every fixture stores the reference state_dict (tiny configs, so the files stay small), the
 seeded inputs and the reference outputs.  torchdiffeq / diffusers have no fixture: they are not
 installable here (parity unpinned, see oracle/__init__.py).
@@ -183,6 +184,34 @@ def golden_edm():
     return rec
 
 
+def golden_fid():
+    """pytorch_fid/fid_score.py::calculate_frechet_distance (pure numpy/scipy) on seeded statistics, incl. a rank-deficient pair.
+    The module imports torchvision / the Inception wrapper at import time; neither is installed, so the function is loaded from its
+    source file with those two imports stubbed (nothing of them is used by the function)."""
+    import importlib.util
+    import types
+
+    import numpy as np
+
+    for name in ("torchvision", "torchvision.transforms", "inception"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    sys.modules["inception"].InceptionV3 = type("InceptionV3", (), {"BLOCK_INDEX_BY_DIM": {64: 0, 192: 1, 768: 2, 2048: 3}})
+    spec = importlib.util.spec_from_file_location("ref_fid_score", os.path.join(REF, "pytorch_fid", "fid_score.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rng = np.random.default_rng(7)
+    out = {"cases": []}
+    for dims, n1, n2 in [(16, 60, 50), (64, 150, 130), (48, 30, 40)]:  # the last pair is rank-deficient (n < dims)
+        a1 = rng.normal(size=(n1, dims)) * rng.uniform(0.5, 2.0, size=dims) + rng.normal(size=dims)
+        a2 = rng.normal(size=(n2, dims)) * rng.uniform(0.5, 2.0, size=dims)
+        m1, s1 = np.mean(a1, axis=0), np.cov(a1, rowvar=False)
+        m2, s2 = np.mean(a2, axis=0), np.cov(a2, rowvar=False)
+        out["cases"].append({"act1": torch.from_numpy(a1), "act2": torch.from_numpy(a2), "mu1": torch.from_numpy(m1), "sigma1": torch.from_numpy(s1),
+                             "mu2": torch.from_numpy(m2), "sigma2": torch.from_numpy(s2), "fid": float(mod.calculate_frechet_distance(m1, s1, m2, s2))})
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref_dit, ref_karras, ref_rand = _import_reference()
@@ -191,9 +220,11 @@ def main():
     torch.save(golden_randgen(ref_rand), os.path.join(OUT, "randgen.pt"))
     torch.save(golden_unet(), os.path.join(OUT, "unet_tiny.pt"))
     torch.save(golden_edm(), os.path.join(OUT, "edm_tiny.pt"))
+    torch.save(golden_fid(), os.path.join(OUT, "fid.pt"))
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
 
 if __name__ == "__main__":
     main()
+

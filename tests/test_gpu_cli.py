@@ -23,11 +23,19 @@ def _run(cmd, **kw):
 def test_single_process_driver_euler_and_karras_heun(tmp_path):
     out = _run([sys.executable, "-m", "lfm_amd.test_flow_latent", "--model_type", "DiT-S/2", "--num_classes", "1", "--label_dropout", "0.",
                 "--method", "euler", "--step_size", "0.25", "--save_dir", str(tmp_path / "a"), *COMMON])
-    assert "Samples are saved" in out
-    assert sorted(os.listdir(tmp_path / "a")) == ["0.jpg", "1.jpg"]
+    # default mode = one sample sheet named as the reference names it (test_flow_latent.py:288-298): 2 images of 256x256, nrow 8
+    assert "Samples are save at" in out
+    assert os.listdir(tmp_path / "a") == ["samples_cifar10_euler_1e-05_1e-05.jpg"]
+    from PIL import Image
+
+    assert Image.open(tmp_path / "a" / "samples_cifar10_euler_1e-05_1e-05.jpg").size == (512, 256)
     out = _run([sys.executable, "-m", "lfm_amd.test_flow_latent", "--model_type", "DiT-S/2", "--num_classes", "10", "--label_dropout", "0.1",
                 "--cfg_scale", "1.5", "--use_karras_samplers", "--method", "heun", "--num_steps", "5", "--save_dir", str(tmp_path / "b"), *COMMON])
-    assert "Samples are saved" in out and len(os.listdir(tmp_path / "b")) == 2
+    assert "Samples are save at" in out and os.listdir(tmp_path / "b") == ["samples_cifar10_heun_5_cfg1.5.jpg"]
+    # single-process --compute_fid: per-image JPEGs named by global index, written through the ROUNDING conversion
+    out = _run([sys.executable, "-m", "lfm_amd.test_flow_latent", "--model_type", "DiT-S/2", "--num_classes", "1", "--label_dropout", "0.",
+                "--method", "euler", "--step_size", "0.5", "--compute_fid", "--save_dir", str(tmp_path / "d"), *COMMON])
+    assert sorted(os.listdir(tmp_path / "d"), key=lambda s: int(s.split(".")[0])) == ["0.jpg", "1.jpg", "2.jpg", "3.jpg"]
 
 
 def test_ddp_driver_one_rank_rccl(tmp_path):

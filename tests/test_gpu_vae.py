@@ -37,3 +37,11 @@ def test_images_to_uint8():
     ref = (torch.clamp((x + 1) / 2, 0, 1) * 255).permute(0, 2, 3, 1).to(torch.uint8)
     got = images_to_uint8(x.cuda()).cpu()
     assert torch.equal(got, ref)
+    # rounding mode = the single-process script's torchvision.utils.save_image conversion, bit-exact against the host restatement
+    from lfm_amd.io_formats import to_uint8_rounding, to_uint8_truncating
+
+    assert torch.equal(ref, to_uint8_truncating(x))
+    x01 = torch.clamp((x + 1) / 2, 0, 1)
+    assert torch.equal(images_to_uint8(x.cuda(), rounding=True).cpu(), to_uint8_rounding(x01))
+    edge = torch.tensor([-1.0, 1.0, 2 * 100.5 / 255 - 1, 2 * 254.5 / 255 - 1, 0.0, 5.0, -5.0, 2 * 0.5 / 255 - 1]).reshape(1, 1, 1, 8).expand(1, 3, 1, 8).contiguous()
+    assert torch.equal(images_to_uint8(edge.cuda(), rounding=True).cpu(), to_uint8_rounding(torch.clamp((edge + 1) / 2, 0, 1)))
