@@ -15,7 +15,7 @@ for M, N, K in [(256, 256, 8192), (4096, 2048, 8192), (4096, 4096, 8192)]:
     A = (torch.randn(M, K, device=dev) * 0.5).half(); W = (torch.randn(N, K, device=dev) * 0.03).half()
     b = torch.zeros(N, device=dev); out = torch.zeros(M, N, device=dev, dtype=torch.float16)
     for name, sel in [("v2 full", 2), ("v2 no DMA (reads+MFMA)", 2 | (1 << 4)), ("v2 no MFMA (DMA+reads)", 2 | (2 << 4)), ("v2 neither (reads+barriers)", 2 | (3 << 4)),
-                      ("v3 quadrant-phased", 3), ("v3 shadow", 3 | (1 << 4)), ("v4 free-running", 4), ("v1 128x128", 1)]:
+                      ("v3 quadrant-phased", 3), ("v3 two-barrier schedule", 3 | (1 << 4)), ("v1 128x128", 1)]:
         hip.check(hip.lib().lfm_gemm_select(sel), 'select')
         ms = statistics.median(timeit(lambda: hip.gemm_f16(A, W, b, epilogue=0, out=out)) for _ in range(3))
         nkt = K // 64
