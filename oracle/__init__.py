@@ -12,6 +12,10 @@ Pinning status (see DESIGN.md "Oracle"):
   ``oracle/make_golden.py`` produced by importing the unmodified reference
   classes from ``/root/reference`` (behind the three-class ``timm`` shim in
   ``oracle/timm_shim.py``).
+* The EDM ``DhariwalUNet`` and the FID back half have no separate restatement:
+  the goldens ``edm_tiny.pt`` (unmodified ``models/EDM.py``) and ``fid.pt``
+  (``pytorch_fid/fid_score.py::calculate_frechet_distance``) pin the product's
+  ``lfm_amd/models/EDM.py`` and ``lfm_amd/io_formats.py`` directly.
 * ``ode_ref`` (torchdiffeq) and ``vae_ref`` (diffusers ``AutoencoderKL``
   decoder) restate third-party packages that are neither vendored in the
   reference nor installed here (requirements.txt:2-3, no versions):
