@@ -7,6 +7,7 @@ static int g_gemm_sel = 0;
 int lfm_gemm_selected() { return g_gemm_sel; }
 static int g_gemm_dbg = 0;
 int lfm_gemm_debug_flags() { return g_gemm_dbg; }
+int lfm_gemm_selected_v1_ok() { return g_gemm_sel < 2 && !(g_gemm_dbg & 512); }  // flag 512: split-K off (A/B)
 extern "C" int lfm_gemm_select(int which) {  // low 4 bits: kernel choice (0 auto, 1..3); bits 4+: ablation flags (measurement only)
   if ((which & 15) > 3 || which < 0) return LFM_ERR_ARG;
   g_gemm_sel = which & 15;
@@ -473,6 +474,8 @@ struct DitWs {
   float* temb_h;  // [B, D] hidden layer of the t-MLP
   half_t* c_half; // [B, D]
   float* mod;     // [B, J]
+  float* slab;    // split-K partial tiles (small M only, else null)
+  size_t slab_bytes;
   size_t total;
 };
 
@@ -495,6 +498,10 @@ static DitWs carve(const lfm_dit_shape* s, int B, void* ws) {
   w.temb_h = (float*)take((size_t)B * D * 4);
   w.c_half = (half_t*)take((size_t)B * D * 2);
   w.mod = (float*)take((size_t)B * J * 4);
+  // latency mode: room for up to 4 K slices of the widest GEMM output (fc1), when the token count is small
+  w.slab_bytes = M <= 1024 ? 4 * M * (H > 3 * D ? H : 3 * D) * 4 : 0;
+  w.slab = w.slab_bytes ? (float*)take(w.slab_bytes) : nullptr;
+  if (!base) w.slab = nullptr;
   w.total = off;
   return w;
 }
@@ -689,24 +696,28 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
     const float* mod = ws.mod + (long)i * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
     rc = ln_modulate_launch(ws.X, ws.A, M, D, T, mod, mod + D, mstride, st);
     if (rc) return rc;
-    rc = launch_gemm_auto(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->qkv_w + (size_t)i * 3 * D * D, D, M, 3 * D, D,
-                        EpiQKV::make(Qb, Kb, Vb, w->qkv_b + (size_t)i * 3 * D, D, 64, T), st);
+    const EpiQKV e_qkv = EpiQKV::make(Qb, Kb, Vb, w->qkv_b + (size_t)i * 3 * D, D, 64, T);
+    rc = launch_gemm_splitk(ws.A, D, (const half_t*)w->qkv_w + (size_t)i * 3 * D * D, D, M, 3 * D, D, e_qkv, ws.slab, ws.slab_bytes, st);
+    if (rc == 1) rc = launch_gemm_auto(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->qkv_w + (size_t)i * 3 * D * D, D, M, 3 * D, D, e_qkv, st);
     if (rc) return rc;
     rc = attention_launch(Qb, Kb, Vb, ws.A, B, s->heads, T, st);
     if (rc) return rc;
-    rc = launch_gemm_auto(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D,
-                        EpiGateResidF32{ws.X, D, w->proj_b + (size_t)i * D, mod + 2 * D, mstride, T}, st);
+    const EpiGateResidF32 e_proj{ws.X, D, w->proj_b + (size_t)i * D, mod + 2 * D, mstride, T};
+    rc = launch_gemm_splitk(ws.A, D, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D, e_proj, ws.slab, ws.slab_bytes, st);
+    if (rc == 1) rc = launch_gemm_auto(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D, e_proj, st);
     if (rc) return rc;
     rc = ln_modulate_launch(ws.X, ws.A, M, D, T, mod + 3 * D, mod + 4 * D, mstride, st);
     if (rc) return rc;
     const bool prof = g_prof_on && g_prof_count < LFM_PROF_MAX;
     if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_count], st);
-    rc = launch_gemm_auto(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->fc1_w + (size_t)i * H * D, D, M, H, D,
-                        EpiBiasGeluF16{ws.QKVH, H, w->fc1_b + (size_t)i * H}, st);
+    const EpiBiasGeluF16 e_fc1{ws.QKVH, H, w->fc1_b + (size_t)i * H};
+    rc = launch_gemm_splitk(ws.A, D, (const half_t*)w->fc1_w + (size_t)i * H * D, D, M, H, D, e_fc1, ws.slab, ws.slab_bytes, st);
+    if (rc == 1) rc = launch_gemm_auto(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->fc1_w + (size_t)i * H * D, D, M, H, D, e_fc1, st);
     if (rc) return rc;
     if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_count++ + 1], st);
-    rc = launch_gemm_auto(ASrcRowMajor{ws.QKVH, H, M, 0}, (const half_t*)w->fc2_w + (size_t)i * D * H, H, M, D, H,
-                        EpiGateResidF32{ws.X, D, w->fc2_b + (size_t)i * D, mod + 5 * D, mstride, T}, st);
+    const EpiGateResidF32 e_fc2{ws.X, D, w->fc2_b + (size_t)i * D, mod + 5 * D, mstride, T};
+    rc = launch_gemm_splitk(ws.QKVH, H, (const half_t*)w->fc2_w + (size_t)i * D * H, H, M, D, H, e_fc2, ws.slab, ws.slab_bytes, st);
+    if (rc == 1) rc = launch_gemm_auto(ASrcRowMajor{ws.QKVH, H, M, 0}, (const half_t*)w->fc2_w + (size_t)i * D * H, H, M, D, H, e_fc2, st);
     if (rc) return rc;
   }
   const float* fmod = ws.mod + (long)s->depth * 6 * D;

@@ -19,6 +19,8 @@
 #pragma once
 #include "common.h"
 
+int lfm_gemm_selected_v1_ok();  // 1 unless a 256x256 kernel is being forced (lfm_gemm_select 2 / 3): split-K runs on the 128x128 kernel
+
 #define GEMM_BM 128
 #define GEMM_BN 128
 #define GEMM_BK 64
@@ -105,6 +107,16 @@ struct EpiGateResidF32 {
   __device__ __forceinline__ void store(int m, int n, f32x4 v, const Aux& a) const {
     *(f32x4*)(X + (long)m * ldx + n) = a.x + a.g * (v + a.b);
   }
+};
+
+// Split-K partial tile: slice bz of the K range writes its fp32 partial product to slab[bz][M][N] (see launch_gemm_splitk).
+struct EpiSlabF32 {
+  float* slab;
+  long ldn, slice_stride;
+  typedef int Aux;
+  __device__ __forceinline__ void batch(int bz, long) { slab += (long)bz * slice_stride; }
+  __device__ __forceinline__ Aux load(int, int) const { return 0; }
+  __device__ __forceinline__ void store(int m, int n, f32x4 v, const Aux&) const { *(f32x4*)(slab + (long)m * ldn + n) = v; }
 };
 
 // QKV projection of timm Attention (DiT.py:120): columns [q | k | v], each [head][hd].
@@ -354,6 +366,50 @@ static inline int launch_gemm_tn(const ASrc& asrc, const half_t* W, long ldw, in
   }
   hipLaunchKernelGGL((gemm_tn_kernel<ASrc, Epi>), dim3(tm * tn, batch), dim3(256), GEMM_LDS_BYTES, stream, asrc, W, ldw, M, N, K, tn,
                      epi, bsA, bsW, bsC);
+  LFM_CHECK_LAUNCH();
+  return LFM_OK;
+}
+
+// ------------------------------------------------------------------ split-K for small M (latency mode)
+// --measure_time runs ONE latent: M = 256 rows, so a DiT GEMM has 16-64 tiles of 128x128 on 256 CUs and up to 64 K-tiles in
+// sequence per tile (fc2) -- 3.07 ms per DiT-L/2 evaluation, 0.3 TB/s of weight streaming.  Split the K range over blockIdx.y:
+// every slice writes an fp32 partial tile to a slab in the caller's workspace, and a second small kernel sums the slabs in a
+// FIXED order and applies the real epilogue (deterministic, unlike atomics -- which were also measured 1.7x slower: device-scope
+// atomics from 8 XCDs serialise at the memory side).
+template <class Epi>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ slabs, int S, long slice_stride, int M, int N, Epi epi) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int n4 = N >> 2;
+  if (idx >= (long)M * n4) return;
+  const int m = (int)(idx / n4), n = (int)(idx - (long)m * n4) * 4;
+  const float* p = slabs + (long)m * N + n;
+  f32x4 v = *(const f32x4*)p;
+  for (int s = 1; s < S; ++s) v += *(const f32x4*)(p + (long)s * slice_stride);
+  epi.store(m, n, v, epi.load(m, n));
+}
+
+// slices for a GEMM of this size: only when the 128x128 tiling leaves most of the chip idle; slices >= 128 deep; slabs fit
+static inline int splitk_slices(int M, int N, int K, size_t slab_bytes) {
+  const long tiles = (long)cdiv(M, 128) * cdiv(N, 128);
+  if (tiles > 64 || (K % 128) != 0 || (N % 4) != 0) return 1;
+  int s = 1;
+  while (tiles * (s * 2) <= 256 && K / (s * 2) >= 128 && (K / (s * 2)) % 64 == 0 && (size_t)(s * 2) * M * N * 4 <= slab_bytes) s *= 2;
+  return s;
+}
+
+// returns LFM_OK after launching both kernels, or 1 if split-K does not apply (the caller then takes the ordinary path)
+template <class Epi>
+static inline int launch_gemm_splitk(const half_t* A, long lda, const half_t* W, long ldw, int M, int N, int K, const Epi& epi, float* slab,
+                                     size_t slab_bytes, hipStream_t stream) {
+  if (!slab || lfm_gemm_selected_v1_ok() == 0) return 1;
+  const int S = splitk_slices(M, N, K, slab_bytes);
+  if (S < 2) return 1;
+  const int ks = K / S;
+  const long stride = (long)M * N;
+  int rc = launch_gemm_tn(ASrcRowMajor{A, lda, M, 0}, W, ldw, M, N, ks, EpiSlabF32{slab, (long)N, stride}, stream, S, ks, ks, 0);
+  if (rc) return rc;
+  const long work = (long)M * (N >> 2);
+  hipLaunchKernelGGL((splitk_finish_kernel<Epi>), dim3((unsigned)cdiv(work, 256)), dim3(256), 0, stream, slab, S, stride, M, N, epi);
   LFM_CHECK_LAUNCH();
   return LFM_OK;
 }
