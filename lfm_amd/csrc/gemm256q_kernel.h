@@ -1,29 +1,34 @@
 // 256x256 "quadrant-phased" MFMA GEMM for gfx950 (v3):  C[m][n] = sum_k A[m][k] * W[n][k]  (+ fused epilogue).
 // Same operand / epilogue / A-source interfaces and the same wave -> output mapping as gemm256_kernel.h (v2), so the
-// epilogue code is shared.  What changed, and why (measured on v2):
+// epilogue code is shared.  What changed, and why (measurements in DESIGN.md section 3):
 //
-//  * v2 stages 32-deep K-tiles, i.e. 64-B rows: one LDS-DMA instruction then touches 16 rows x HALF a cache line, and the
-//    DMA issue cost (not the MFMAs, not the LDS reads) bounded the loop: 1.4 PFLOP/s with the DMAs ablated, 1.07 with.
-//    v3 stages 64-deep K-tiles = full 128-B lines (8 rows per DMA instruction), half the requests per byte.
+//  * v2 stages 32-deep K-tiles, i.e. 64-B rows: one LDS-DMA instruction then touches 16 rows x HALF a cache line.
+//    v3 stages 64-deep K-tiles = full 128-B lines (8 rows per DMA instruction), half the L2 requests per byte: -7 % cycles,
+//    and -- the GEMMs run under the board power cap on real data -- the same in time.
 //  * A K-tile is consumed in FOUR phases, one 64x32 output quadrant each (8 MFMAs = 256 matrix-pipe cycles), and is
 //    staged in four 16-KiB PIECES cut along the same lines:  A.sub0 / A.sub1 = rows {0..63} / {64..127} of both
 //    groups' 128-row halves,  B.sub0 / B.sub1 = columns {0..31} / {32..63} of every wave's 64-column block.  A piece is
 //    last read in a known phase, so it can be re-staged two phases later: every phase issues exactly one piece
-//    (2 DMAs per thread) and ends its load part with the same counted wait, vmcnt(8) = "all but my newest four pieces
-//    have landed" -- four pieces (64 KiB per CU) are always in flight and each has >= 4 phases to land.
+//    (2 DMAs per thread) and ends its LOAD part with the same counted vmcnt wait.
 //
 //      phase       reads (ds_read_b128)          MFMAs (acc rows x cols)    stages piece        of K-tile
-//      P1(t)       A.sub0 (8) + B.sub0 (4)       sub0 x sub0                B.sub1              t+1
+//      P1(t)       B.sub0 (4) + A.sub0 (8)       sub0 x sub0                B.sub1              t+1
 //      P2(t)       B.sub1 (4)                    sub0 x sub1                A.sub1              t+1
 //      P3(t)       A.sub1 (8)                    sub1 x sub1                A.sub0              t+2
 //      P4(t)       -                             sub1 x sub0                B.sub0              t+2
 //
-//    phase = [reads, DMA, vmcnt] s_barrier [lgkmcnt(0), 8 MFMAs] s_barrier.  The two wave groups (rows 0..127 /
-//    128..255 of the tile, one wave per SIMD each) run this program shifted by ONE barrier, so a SIMD's two waves
-//    alternate "load part" and "MFMA part".  Hazards (interval = time between two barriers; group 0 loads in interval
-//    2p and computes in 2p+1, group 1 one later):
-//      RAW  a piece waited for in phase p (both groups, before their first barrier of p) is read in phase p+1 or later;
-//      WAR  a piece read in phase p (reads retired right after the first barrier of p) is re-staged in phase p+2 or later.
+//    The two wave groups (rows 0..127 / 128..255 of the tile, one wave per SIMD each) alternate "LOAD part" and "MFMA part"
+//    so that a SIMD's matrix pipe always has a wave feeding it.  Two schedules (template SCHED):
+//      SCHED 1 (default): ONE barrier per phase.  Between two barriers group 0 runs MFMA(p), LOAD(p+1) and group 1 runs
+//              LOAD(p), MFMA(p); the hand-over inside the interval is the matrix pipe's own queueing.  The wait in LOAD(p)
+//              covers the pieces of phase p+2 (three pieces = 48 KiB per CU stay in flight).
+//      SCHED 0 (A/B switch, flag 1): phase = [LOAD] barrier [MFMA] barrier, group 1 one barrier behind; the wait covers the
+//              pieces of phase p+1 (four pieces in flight).
+//    Hazards, both schedules: a piece is read only after every wave's wait for it AND a barrier; a piece read in phase r is
+//    retired by the counted lgkmcnt waits of MFMA(r) and re-staged in LOAD(r+2) or later, behind a barrier (see the comments
+//    at the two schedules below).
+//  * Fragment reads are inline asm in the order the MFMAs consume them, every MFMA pair behind its own counted lgkmcnt.
+//  * Tiles an epilogue wants transposed (EpiQKV: the V third) run with the MFMA operands swapped (template copy of the loop).
 //    LDS = 2 K-tiles x 4 pieces x 16 KiB = 128 KiB; rows are 128 B, chunk c of row r sits at c ^ ((r>>1)&7) (v1's key).
 #pragma once
 #include "gemm256_kernel.h"
