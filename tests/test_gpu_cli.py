@@ -44,3 +44,13 @@ def test_ddp_driver_one_rank_rccl(tmp_path):
                 "--label_dropout", "0.", "--method", "euler", "--step_size", "0.5", "--compute_fid", "--save_dir", str(tmp_path / "c"), *COMMON])
     assert "sampled 4 images on 1 GPUs" in out
     assert sorted(os.listdir(tmp_path / "c"), key=lambda s: int(s.split(".")[0])) == ["0.jpg", "1.jpg", "2.jpg", "3.jpg"]
+
+
+def test_launcher_with_a_reference_args_file(tmp_path):
+    """python -m lfm_amd.run_test <test_args file>: the reference's run_test.sh expansion, solver overridden after '--' to keep it short."""
+    f = tmp_path / "celeb256_dit.txt"
+    f.write_text("MODEL_TYPE=DiT-L/2\nEPOCH_ID=475\nDATASET=celeba_256\nEXP=celeb_f8_dit\nMETHOD=dopri5\nSTEPS=0\nUSE_ORIGIN_ADM=false\nIMG_SIZE=256")
+    out = _run([sys.executable, "-m", "lfm_amd.run_test", str(f), "--", "--random_weights", "--generator", "device", "--batch_size", "2",
+                "--method", "euler", "--step_size", "0.5", "--save_dir", str(tmp_path / "e")])
+    assert "Argument file:" in out and "Samples are save at" in out
+    assert os.listdir(tmp_path / "e") == ["samples_celeba_256_euler_1e-05_1e-05.jpg"]
