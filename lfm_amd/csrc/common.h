@@ -62,3 +62,17 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
 }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Zero a small device buffer with a KERNEL instead of hipMemsetAsync: inside a captured hipGraph a memset becomes a memset node, and
+// graphs of the host-sequenced UNets (GroupNorm statistics are zeroed before every accumulation) produced NaN on the first replay
+// after the device had gone idle -- the accumulation kernel ran against a scratch that was not zero yet.  Kernel nodes only.
+static __global__ void lfm_zero_u32_kernel(unsigned int* __restrict__ p, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+static inline int lfm_zero_async(void* p, size_t bytes, hipStream_t st) {  // bytes % 4 == 0
+  const long n = (long)(bytes / 4);
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(lfm_zero_u32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (unsigned int*)p, n);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}

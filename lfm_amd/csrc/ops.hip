@@ -337,7 +337,7 @@ extern "C" int lfm_groupnorm_f16(const void* x, void* y, const float* gamma, con
   hipStream_t st = (hipStream_t)stream;
   float* stats = (float*)scratch;
   float* ab = (float*)((char*)scratch + (((size_t)N * 64 * 4 + 255) / 256) * 256);
-  if (hipMemsetAsync(stats, 0, (size_t)N * 64 * 4, st) != hipSuccess) return LFM_ERR_LAUNCH;
+  if (lfm_zero_async(stats, (size_t)N * 64 * 4, st)) return LFM_ERR_LAUNCH;
   const int G = groups, cpg = C / G;
   if (cpg % 4 == 0 && C / 8 <= 256) {
     const int ppb = HW >= 4096 ? 512 : (HW >= 256 ? 64 : HW);

@@ -306,7 +306,7 @@ extern "C" size_t lfm_vae_workspace_bytes(int R, int chunk) {
 
 static int gn(const half_t* x, half_t* y, float* stats, const float* g, const float* b, int n, int HW, int C, bool silu, hipStream_t st) {
   if (C % 128 || 256 % (C / 8)) return LFM_ERR_SHAPE;  // groups of >= 4 channels, octet-per-thread mapping
-  if (hipMemsetAsync(stats, 0, (size_t)n * 64 * 4, st) != hipSuccess) return LFM_ERR_LAUNCH;
+  if (lfm_zero_async(stats, (size_t)n * 64 * 4, st)) return LFM_ERR_LAUNCH;
   const int ppb = 1024;
   hipLaunchKernelGGL(gn_stats_kernel, dim3(cdiv(HW, ppb), n), dim3(256), 0, st, x, stats, HW, C, ppb);
   LFM_CHECK_LAUNCH();
@@ -352,7 +352,7 @@ extern "C" int lfm_vae_decode(const lfm_vae_weights* w, void* workspace, size_t 
   if (ws.total > workspace_bytes) return LFM_ERR_WORKSPACE;
   if ((uintptr_t)workspace & 255) return LFM_ERR_ALIGN;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(ws.zeros, 0, 256, st) != hipSuccess) return LFM_ERR_LAUNCH;
+  if (lfm_zero_async(ws.zeros, 256, st)) return LFM_ERR_LAUNCH;
   const int T = R * R;
   for (int n0 = 0; n0 < N; n0 += chunk) {
     const int n = (N - n0 < chunk) ? N - n0 : chunk;

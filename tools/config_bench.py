@@ -45,6 +45,7 @@ if "5" in which:  # origin-ADM celeb512, batch 32, 50-step Euler + VAE at 512x51
     sa = Namespace(method="euler", step_size=0.02, perturb=False, compute_nfe=False, cfg_scale=1.0, atol=1e-5, rtol=1e-5)
     def solve(): return sample_from_model(m, x, {}, sa)[-1]
     ds, lat = T(solve)
+    print('   latents right after the solve: finite =', bool(torch.isfinite(lat).all()), 'nonfinite count', int((~torch.isfinite(lat)).sum()), 'shape', tuple(lat.shape), flush=True)
     def dec(): return images_to_uint8(vae.decode(lat / 0.18215).sample)
     dd, img = T(dec)
     print(f"config5 ADM celeb512 B=32 50-step Euler: solver {ds:.2f} s + VAE512 decode {dd*1e3:.0f} ms -> {B/(ds+dd):.2f} img/s; img {tuple(img.shape)} finite={bool(torch.isfinite(lat).all())}", flush=True)
