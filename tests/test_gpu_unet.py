@@ -116,3 +116,31 @@ def test_unet_fullsize_vs_oracle_and_fused_sampling():
     # kernels agree to fp16-rounding level, not bit-for-bit
     assert rel_l2(fused, eager) < 1e-3
     assert rel_l2(fused, oracle) < 2e-3
+
+
+def test_graphed_solve_replayed_after_the_device_went_idle():
+    """Regression: the GroupNorm statistics used to be zeroed with hipMemsetAsync, i.e. a memset NODE inside the captured graph of the
+    host-sequenced UNet; replaying that graph on an idle device (a synchronize between two solves) produced NaN latents, while
+    back-to-back solves and the eager loop were fine.  Two 50-step solves separated by a synchronize must agree with the eager loop."""
+    from argparse import Namespace
+
+    from lfm_amd.models import create_network
+    from lfm_amd.test_flow_latent import dezero_, sample_from_model
+
+    dev = torch.device("cuda:0")
+    args = Namespace(use_origin_adm=True, layout=False, model_type="adm", image_size=128, f=8, num_in_channels=4, num_out_channels=4,
+                     nf=128, num_res_blocks=1, attn_resolutions=(4, 2), dropout=0.0, ch_mult=(1, 2, 2), resamp_with_conv=True, num_classes=None,
+                     num_heads=4, num_head_channels=-1, num_head_upsample=-1)
+    torch.manual_seed(0)
+    m = dezero_(create_network(args)).to(dev).eval()
+    x = torch.randn(8, 4, 16, 16, device=dev)
+    sargs = Namespace(method="euler", step_size=0.02, perturb=False, compute_nfe=False, cfg_scale=1.0, atol=1e-5, rtol=1e-5)
+    sample_from_model(m, x, {}, sargs)  # captures the graph; result dropped
+    torch.cuda.synchronize()            # the device goes idle
+    second = sample_from_model(m, x, {}, sargs)[-1].clone()
+    torch.cuda.synchronize()
+    third = sample_from_model(m, x, {}, sargs)[-1].clone()
+    sargs.fused = False
+    eager = sample_from_model(m, x, {}, sargs)[-1]
+    assert bool(torch.isfinite(second).all()) and bool(torch.isfinite(third).all()) and bool(torch.isfinite(eager).all())
+    assert rel_l2(second, eager.cpu()) < 1e-3 and rel_l2(third, eager.cpu()) < 1e-3
