@@ -89,6 +89,9 @@ typedef struct lfm_dit_call {
   const float* axpy_dt;   /* device scalar (read at kernel run time => one captured graph per solver) */
 } lfm_dit_call;
 
+/* Bytes of caller-owned scratch for batches up to max_batch: residual stream, LN / attention buffers, Q|K|Vt (reused for the fc1
+ * activation), conditioning vectors, the adaLN table and -- for small batches (<= 1024 tokens, latency mode) -- the fp32 slabs of the
+ * split-K GEMMs (reserved for every max_batch, so the requirement is monotone: a workspace sized for max_batch serves every smaller batch). */
 size_t lfm_dit_workspace_bytes(const lfm_dit_shape* shape, int max_batch);
 
 /* Replaces DiT.forward / DiT.forward_with_cfg (models/DiT.py:252-290) as called by the solver closure

@@ -479,7 +479,7 @@ struct DitWs {
   size_t total;
 };
 
-static DitWs carve(const lfm_dit_shape* s, int B, void* ws) {
+static DitWs carve(const lfm_dit_shape* s, int B, void* ws, bool sizing = false) {
   const size_t T = (size_t)(s->res / s->patch) * (s->res / s->patch), M = (size_t)B * T, D = s->hidden, H = s->mlp_hidden;
   const size_t J = (size_t)s->depth * 6 * D + 2 * D;
   size_t off = 0;
@@ -499,7 +499,10 @@ static DitWs carve(const lfm_dit_shape* s, int B, void* ws) {
   w.c_half = (half_t*)take((size_t)B * D * 2);
   w.mod = (float*)take((size_t)B * J * 4);
   // latency mode: room for up to 4 K slices of the widest GEMM output (fc1), when the token count is small
-  w.slab_bytes = M <= 1024 ? 4 * M * (H > 3 * D ? H : 3 * D) * 4 : 0;
+  // (when SIZING for a maximum batch, reserve the slabs of the largest small batch too, so that the requirement is monotone in the
+  // batch and a workspace sized for max_batch serves every smaller batch)
+  const size_t Ms = sizing ? (M < 1024 ? M : (size_t)1024 / T * T) : M;
+  w.slab_bytes = (sizing || M <= 1024) && Ms > 0 ? 4 * Ms * (H > 3 * D ? H : 3 * D) * 4 : 0;
   w.slab = w.slab_bytes ? (float*)take(w.slab_bytes) : nullptr;
   if (!base) w.slab = nullptr;
   w.total = off;
@@ -534,7 +537,7 @@ extern "C" int lfm_abi_version(void) { return 1; }
 
 extern "C" size_t lfm_dit_workspace_bytes(const lfm_dit_shape* shape, int max_batch) {
   if (check_shape(shape) != LFM_OK || max_batch <= 0) return 0;
-  return carve(shape, max_batch, nullptr).total;
+  return carve(shape, max_batch, nullptr, true).total;
 }
 
 int lfm_gemm_debug_flags();

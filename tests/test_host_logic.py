@@ -216,3 +216,22 @@ def test_unet_and_edm_state_dict_names_match_reference(golden_dir):
     assert list(m.state_dict().keys()) == list(rec["state_dict"].keys())
     assert all(m.state_dict()[k].shape == v.shape for k, v in rec["state_dict"].items())
     assert any(k.endswith("resample_filter") for k in rec["state_dict"])  # the up/down convolutions' buffers are mirrored too
+
+
+def test_dit_workspace_requirement_is_monotone_in_the_batch():
+    """lfm_dit_workspace_bytes is host-only arithmetic: small batches add split-K slabs, and the size for max_batch must still cover every
+    smaller batch (lfm_amd/models/DiT.py keeps ONE workspace sized for the largest batch it has seen)."""
+    import ctypes as C
+
+    from lfm_amd import hip
+
+    L = hip.lib()
+    for kw in (dict(depth=24, hidden=1024, heads=16, mlp_hidden=4096, patch=2, in_ch=4, res=32, label_rows=1),     # DiT-L/2, T = 256
+               dict(depth=12, hidden=768, heads=12, mlp_hidden=3072, patch=2, in_ch=4, res=32, label_rows=1001),   # DiT-B/2 class-conditional
+               dict(depth=12, hidden=384, heads=6, mlp_hidden=1536, patch=2, in_ch=4, res=16, label_rows=11)):    # T = 64
+        s = hip.DitShape(**kw)
+        sizes = [L.lfm_dit_workspace_bytes(C.byref(s), b) for b in range(1, 70)]
+        assert all(v > 0 for v in sizes)
+        assert all(b >= a for a, b in zip(sizes, sizes[1:])), kw
+    bad = hip.DitShape(depth=28, hidden=1152, heads=16, mlp_hidden=4608, patch=2, in_ch=4, res=32, label_rows=1)  # DiT-XL: head_dim 72
+    assert L.lfm_dit_workspace_bytes(C.byref(bad), 1) == 0
