@@ -79,7 +79,7 @@ typedef struct lfm_dit_call {
   const float* x;         /* [batch, C, R, R] fp32 NCHW                                               */
   const float* t;         /* [t_len] fp32, t_len = 1 (0-d / [1] time) or batch                        */
   int t_len;
-  const int64_t* y;       /* [batch] class labels, or NULL => row label_rows-1 (models/DiT.py:259-260) */
+  const int64_t* y;       /* [batch] class labels in [0, label_rows) (else the row is NaN), or NULL => row label_rows-1 (models/DiT.py:259-260) */
   int cfg;                /* 0: DiT.forward.  1: DiT.forward_with_cfg (models/DiT.py:274-290): rows
                              [0,batch/2) of x are used for BOTH halves, and both output halves carry
                              uncond + cfg_scale*(cond - uncond)                                        */
@@ -205,9 +205,11 @@ int lfm_upsample2_f16(const void* x, void* y, int N, int Ho, int Wo, int C, lfm_
 int lfm_concat_channels_f16(const void* a, const void* b, void* out, long pixels, int Ca, int Cb, lfm_stream_t stream);
 /* QKVAttentionLegacy (unet.py:310-334): qkv fp16 [N*T, 3C], columns [head][q|k|v][ch]; out fp16 [N*T, C] columns [head][ch] */
 int lfm_attention_small_f16(const void* qkv, void* out, int N, int T, int heads, int ch, lfm_stream_t stream);
-/* emb = time_embed(timestep_embedding(t, F)) (+ label_emb[y]) (nn.py:103-121, unet.py:633-641): fp32 [N,E] and fp16 silu(emb) */
+/* emb = time_embed(timestep_embedding(t, F)) (+ label_emb[y]) (nn.py:103-121, unet.py:633-641): fp32 [N,E] and fp16 silu(emb).
+ * label_table has label_rows rows; a label outside [0, label_rows) (an IndexError in the reference) poisons its row with NaN. */
 int lfm_time_embed(const float* t, int t_len, const float* w0, const float* b0, const float* w2, const float* b2, const float* label_table,
-                   const int64_t* y, float* scratch_h1, float* emb, void* emb_silu_f16, int N, int F, int E, lfm_stream_t stream);
+                   const int64_t* y, int label_rows, float* scratch_h1, float* emb, void* emb_silu_f16, int N, int F, int E,
+                   lfm_stream_t stream);
 
 /* ------------------------------------------------------------------ solver helpers (device-resident time grid)
  * Advance the captured step:  s = *step;  t_cur[0] = ts[s];  t_next[0] = ts[s+1];  dt_cur[0] = dts[s];  *step = s+1.

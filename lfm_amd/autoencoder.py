@@ -108,7 +108,7 @@ class AutoencoderKL(nn.Module):
 
             sd = load_file(st)
         else:
-            sd = torch.load(os.path.join(path, "diffusion_pytorch_model.bin"), map_location="cpu")
+            sd = torch.load(os.path.join(path, "diffusion_pytorch_model.bin"), map_location="cpu", weights_only=True)  # safe unpickler only
         m = cls(**kw)
         m.load_state_dict(sd)
         return m

@@ -48,12 +48,18 @@ __global__ __launch_bounds__(256) void temb2_kernel(const float* __restrict__ h1
 }
 
 // c_half[r] = fp16(silu(temb[t_len==1 ? 0 : r] + y_table[y ? y[r] : null_row]))   (DiT.py:259-264 + the SiLU of :125)
+// A label outside [0, label_rows) is an IndexError in the reference (nn.Embedding); a kernel inside a captured graph cannot raise,
+// so the row is POISONED with NaN instead of reading out of bounds (the host wrapper validates labels before they get here).
 __global__ void cond_kernel(const float* __restrict__ temb, int t_len, const float* __restrict__ y_table, const int64_t* __restrict__ y,
-                            int null_row, half_t* __restrict__ c_half, int D, int rows) {
+                            int label_rows, half_t* __restrict__ c_half, int D, int rows) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)rows * D) return;
   const int r = (int)(i / D), j = (int)(i - (long)r * D);
-  const long yr = y ? (long)y[r] : (long)null_row;
+  const long yr = y ? (long)y[r] : (long)(label_rows - 1);
+  if (yr < 0 || yr >= label_rows) {
+    c_half[i] = (half_t)__builtin_nanf("");
+    return;
+  }
   const float v = temb[(t_len == 1 ? 0 : (long)r * D) + j] + y_table[yr * D + j];
   c_half[i] = (half_t)silu_f(v);
 }
@@ -533,7 +539,7 @@ extern "C" const char* lfm_strerror(int code) {
   }
   return "unknown";
 }
-extern "C" int lfm_abi_version(void) { return 1; }
+extern "C" int lfm_abi_version(void) { return 2; }  // 2: lfm_time_embed takes label_rows
 
 extern "C" size_t lfm_dit_workspace_bytes(const lfm_dit_shape* shape, int max_batch) {
   if (check_shape(shape) != LFM_OK || max_batch <= 0) return 0;
@@ -682,7 +688,7 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
   LFM_CHECK_LAUNCH();
   hipLaunchKernelGGL(temb2_kernel, dim3(cdiv(D, 4), c->t_len), dim3(256), 0, st, ws.temb_h, w->t_w2, w->t_b2, ws.temb, D);
   LFM_CHECK_LAUNCH();
-  hipLaunchKernelGGL(cond_kernel, dim3(cdiv((long)rows * D, 256)), dim3(256), 0, st, ws.temb, c->t_len, w->y_table, c->y, s->label_rows - 1,
+  hipLaunchKernelGGL(cond_kernel, dim3(cdiv((long)rows * D, 256)), dim3(256), 0, st, ws.temb, c->t_len, w->y_table, c->y, s->label_rows,
                      ws.c_half, D, rows);
   LFM_CHECK_LAUNCH();
   rc = launch_gemm_tn(ASrcRowMajor{ws.c_half, D, rows, 0}, (const half_t*)w->ada_w, D, rows, (int)J, D, EpiBiasF32{ws.mod, J, w->ada_b}, st);

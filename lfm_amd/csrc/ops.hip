@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256) void time_embed1_kernel(const float* __restric
 }
 __global__ __launch_bounds__(256) void time_embed2_kernel(const float* __restrict__ h1, const float* __restrict__ w2, const float* __restrict__ b2,
                                                           const float* __restrict__ label_table, const int64_t* __restrict__ y,
-                                                          float* __restrict__ emb, half_t* __restrict__ emb_silu, int E) {
+                                                          int label_rows, float* __restrict__ emb, half_t* __restrict__ emb_silu, int E) {
   const int r = blockIdx.y, lane = threadIdx.x & 63;
   const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (j >= E) return;
@@ -526,22 +526,26 @@ __global__ __launch_bounds__(256) void time_embed2_kernel(const float* __restric
   s = wave_sum(s);
   if (lane == 0) {
     float v = s + b2[j];
-    if (label_table) v += label_table[(long)y[r] * E + j];
+    if (label_table) {  // out-of-range label: nn.Embedding raises in the reference; poison instead of reading out of bounds
+      const long yr = (long)y[r];
+      v = (yr >= 0 && yr < label_rows) ? v + label_table[yr * E + j] : __builtin_nanf("");
+    }
     emb[(long)r * E + j] = v;
     emb_silu[(long)r * E + j] = (half_t)silu_f(v);
   }
 }
 
 extern "C" int lfm_time_embed(const float* t, int t_len, const float* w0, const float* b0, const float* w2, const float* b2,
-                              const float* label_table, const int64_t* y, float* scratch_h1, float* emb, void* emb_silu_f16, int N, int F, int E,
-                              lfm_stream_t stream) {
+                              const float* label_table, const int64_t* y, int label_rows, float* scratch_h1, float* emb, void* emb_silu_f16, int N, int F,
+                              int E, lfm_stream_t stream) {
   if (!t || !w0 || !b0 || !w2 || !b2 || !scratch_h1 || !emb || !emb_silu_f16) return LFM_ERR_ARG;
   if ((label_table != nullptr) != (y != nullptr)) return LFM_ERR_ARG;
+  if (label_table && label_rows <= 0) return LFM_ERR_SHAPE;
   if (N <= 0 || F <= 0 || (F & 1) || E <= 0 || (t_len != 1 && t_len != N)) return LFM_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(time_embed1_kernel, dim3(cdiv(E, 4), N), dim3(256), 0, st, t, t_len, w0, b0, scratch_h1, F, E);
   LFM_CHECK_LAUNCH();
-  hipLaunchKernelGGL(time_embed2_kernel, dim3(cdiv(E, 4), N), dim3(256), 0, st, scratch_h1, w2, b2, label_table, y, emb, (half_t*)emb_silu_f16, E);
+  hipLaunchKernelGGL(time_embed2_kernel, dim3(cdiv(E, 4), N), dim3(256), 0, st, scratch_h1, w2, b2, label_table, y, label_rows, emb, (half_t*)emb_silu_f16, E);
   LFM_CHECK_LAUNCH();
   return LFM_OK;
 }

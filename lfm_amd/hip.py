@@ -31,17 +31,20 @@ class DitCall(C.Structure):
 
 
 def lib():
-    """Load the shared library (building it in-tree if hipcc is present and it is stale/missing)."""
+    """Load the shared library.  With hipcc present the stamp-checked in-tree build runs first (a no-op when the sources are
+    unchanged, a rebuild when they are stale); without hipcc the prebuilt library is used as shipped."""
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        try:
-            from . import _build
+    from . import _build
 
+    if os.path.exists(_build.HIPCC) or not os.path.exists(LIB_PATH):
+        try:
             _build.build()
         except Exception as e:  # noqa
-            raise LfmHipError(f"liblfm_hip.so is missing and could not be built: {e}") from e
+            if not os.path.exists(LIB_PATH):
+                raise LfmHipError(f"liblfm_hip.so is missing and could not be built: {e}") from e
+            raise LfmHipError(f"liblfm_hip.so is stale and could not be rebuilt: {e}") from e
     try:
         L = C.CDLL(LIB_PATH)
     except OSError as e:
@@ -105,7 +108,7 @@ def lib():
     L.lfm_attention_small_f16.restype = I
     L.lfm_attention_small_f16.argtypes = [V, V, I, I, I, I, V]
     L.lfm_time_embed.restype = I
-    L.lfm_time_embed.argtypes = [V, I, V, V, V, V, V, V, V, V, V, I, I, I, V]
+    L.lfm_time_embed.argtypes = [V, I, V, V, V, V, V, V, I, V, V, V, I, I, I, V]
     _lib = L
     return L
 
@@ -122,6 +125,27 @@ def stream_ptr(device=None):
 
 def ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+_LABELS_OK = {}
+
+
+def check_labels(y, rows, what):
+    """Labels must index the embedding table (the reference's nn.Embedding raises IndexError otherwise; a kernel cannot).  The check
+    reads two scalars back from the device, so it is cached per (storage, version) and skipped during graph capture -- solver loops
+    that pass the same label tensor to every evaluation pay for it once."""
+    if y is None or y.numel() == 0:
+        return
+    if y.is_cuda and torch.cuda.is_current_stream_capturing():
+        return
+    key = (y.data_ptr(), y._version, y.numel(), rows)
+    if _LABELS_OK.get("key") == key:
+        return
+    lo, hi = int(y.min()), int(y.max())
+    if lo < 0 or hi >= rows:
+        raise IndexError(f"{what}: label {hi if hi >= rows else lo} is outside the embedding table [0, {rows}) "
+                         "(classifier-free guidance needs a model built with label_dropout > 0: its null class is row num_classes)")
+    _LABELS_OK["key"] = key
 
 
 def require_gpu(t, what):

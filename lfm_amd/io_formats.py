@@ -32,11 +32,20 @@ def extract_state_dict(obj):
     return {(k[7:] if k.startswith("module.") else k): v for k, v in obj.items()}
 
 
-def load_state_dict_file(path, map_location="cpu"):
-    try:
+def load_state_dict_file(path, map_location="cpu", trust_checkpoint=False):
+    """Read ``model_{epoch}.pth`` / ``content.pth`` with the SAFE unpickler only.  ``content.pth`` pickles an ``argparse.Namespace``
+    next to the tensors (train_flow_latent.py:196-203): that one class is allow-listed; anything else the safe loader rejects stays
+    rejected (a file the safe loader refuses is exactly the file that must not reach the full unpickler), unless the caller passes
+    ``trust_checkpoint=True`` explicitly (``--trust_checkpoint``), which is logged."""
+    import argparse
+
+    if trust_checkpoint:
+        import warnings
+
+        warnings.warn(f"loading {path} with the full (unsafe) unpickler because trust_checkpoint=True", stacklevel=2)
+        return extract_state_dict(torch.load(path, map_location=map_location, weights_only=False))
+    with torch.serialization.safe_globals([argparse.Namespace]):
         obj = torch.load(path, map_location=map_location, weights_only=True)
-    except Exception:  # content.pth pickles an argparse.Namespace and optimizer state
-        obj = torch.load(path, map_location=map_location, weights_only=False)
     return extract_state_dict(obj)
 
 

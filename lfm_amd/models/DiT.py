@@ -139,10 +139,15 @@ class DiT(nn.Module):
 
     # ---- any parameter movement / reload invalidates the packed fp16 operands
     def _apply(self, fn, *a, **k):
-        self._packed = None
-        self._gen = getattr(self, "_gen", 0) + 1
-        self._ws = None
-        return super()._apply(fn, *a, **k)
+        # invalidate the packed operands / workspace / captured graphs only if a parameter really moved or changed dtype
+        # (NFECount(model).to(device) on an already-placed model must not re-pack 0.9 GB of weights per call)
+        before = [(p.data_ptr(), p.dtype, p.device) for p in self.parameters()]
+        out = super()._apply(fn, *a, **k)
+        if before != [(p.data_ptr(), p.dtype, p.device) for p in self.parameters()]:
+            self._packed = None
+            self._gen = getattr(self, "_gen", 0) + 1
+            self._ws = None
+        return out
 
     def load_state_dict(self, *a, **k):
         self._packed = None
@@ -214,6 +219,7 @@ class DiT(nn.Module):
             y = y.to(device=x.device, dtype=torch.long).contiguous()
             if y.numel() != N:
                 raise ValueError(f"y must have {N} elements")
+            hip.check_labels(y, self.y_embedder.get_in_channels(), "DiT")  # nn.Embedding's IndexError (reference DiT.py:99-103)
         if out is None:
             out = torch.empty_like(x)
         ws = self._workspace(N, x.device)

@@ -144,10 +144,13 @@ class DhariwalUNet(nn.Module):
 
     # ---- packing ------------------------------------------------------------------------------------------------------
     def _apply(self, fn, *a, **k):
-        self._packed = None
-        self._scratch = None
-        self._gen = getattr(self, "_gen", 0) + 1
-        return super()._apply(fn, *a, **k)
+        before = [(p.data_ptr(), p.dtype, p.device) for p in self.parameters()]
+        out = super()._apply(fn, *a, **k)
+        if before != [(p.data_ptr(), p.dtype, p.device) for p in self.parameters()]:  # only a real move / cast invalidates
+            self._packed = None
+            self._scratch = None
+            self._gen = getattr(self, "_gen", 0) + 1
+        return out
 
     def load_state_dict(self, *a, **k):
         self._packed = None
@@ -291,13 +294,16 @@ class DhariwalUNet(nn.Module):
             yy = y.to(dev, torch.long).clone()
             if drop_half_label:
                 yy[N // 2:] = self.label_dim  # the all-zero row (EDM.py:825-826)
+        n_labels = 0 if P["label"] is None else int(P["label"].shape[0])
+        if yy is not None:
+            hip.check_labels(yy, n_labels, "DhariwalUNet")
         emb = torch.empty(N, E, device=dev)
         emb_silu = torch.empty(N, E, device=dev, dtype=torch.float16)
         h1 = torch.empty(N, E, device=dev)
         tw = P["time"]
         hip.check(L.lfm_time_embed(hip.ptr(t), t.numel(), hip.ptr(tw[0]), hip.ptr(tw[1]), hip.ptr(tw[2]), hip.ptr(tw[3]),
-                                   hip.ptr(P["label"] if yy is not None else None), hip.ptr(yy), hip.ptr(h1), hip.ptr(emb), hip.ptr(emb_silu),
-                                   N, F, E, hip.stream_ptr(dev)), "lfm_time_embed")
+                                   hip.ptr(P["label"] if yy is not None else None), hip.ptr(yy), n_labels, hip.ptr(h1), hip.ptr(emb),
+                                   hip.ptr(emb_silu), N, F, E, hip.stream_ptr(dev)), "lfm_time_embed")
         skips, h = [], None
         for name, b in self.enc.items():
             if isinstance(b, Conv2d):

@@ -135,10 +135,13 @@ class UNetModel(nn.Module):
 
     # ---- packing ------------------------------------------------------------------------------------------------------
     def _apply(self, fn, *a, **k):
-        self._packed = None
-        self._gen = getattr(self, "_gen", 0) + 1
-        self._scratch = None
-        return super()._apply(fn, *a, **k)
+        before = [(p.data_ptr(), p.dtype, p.device) for p in self.parameters()]
+        out = super()._apply(fn, *a, **k)
+        if before != [(p.data_ptr(), p.dtype, p.device) for p in self.parameters()]:  # only a real move / cast invalidates
+            self._packed = None
+            self._scratch = None
+            self._gen = getattr(self, "_gen", 0) + 1
+        return out
 
     def load_state_dict(self, *a, **k):
         self._packed = None
@@ -279,12 +282,15 @@ class UNetModel(nn.Module):
         if y is not None:
             y = y.to(dev, torch.long).contiguous()
             assert y.shape == (N,)
+        n_labels = 0 if self._packed["label"] is None else int(self._packed["label"].shape[0])
+        if y is not None and n_labels:
+            hip.check_labels(y, n_labels, "UNetModel")
         emb = torch.empty(N, E, device=dev)
         emb_silu = torch.empty(N, E, device=dev, dtype=torch.float16)
         h1 = torch.empty(N, E, device=dev)
         tw = self._packed["time"]
         hip.check(L.lfm_time_embed(hip.ptr(t), t.numel(), hip.ptr(tw[0]), hip.ptr(tw[1]), hip.ptr(tw[2]), hip.ptr(tw[3]),
-                                   hip.ptr(self._packed["label"]), hip.ptr(y), hip.ptr(h1), hip.ptr(emb), hip.ptr(emb_silu), N, F, E,
+                                   hip.ptr(self._packed["label"]), hip.ptr(y), n_labels, hip.ptr(h1), hip.ptr(emb), hip.ptr(emb_silu), N, F, E,
                                    hip.stream_ptr(dev)), "lfm_time_embed")
         ci = self._packed["conv_in"]
         ch0 = ci[0].shape[0]

@@ -17,12 +17,13 @@ is applied to intervals i < 39 only, whatever the grid length.
 import numpy as np
 import torch as th
 
-from .random_util import get_generator
+from .random_util import _Deterministic, get_generator
 
 
 def karras_sample(model, x_T, steps, clip_denoised=True, progress=False, callback=None, model_kwargs=None, device=None,
                   sigma_min=0.002, sigma_max=80, sampler="heun", s_churn=0.0, s_tmin=0.0, s_tmax=float("inf"), s_noise=1.0,
-                  generator=None, classifier=None, cond_func=None, rho=None, ts=None, heun_reference_quirk=True, fused=None):
+                  generator=None, classifier=None, cond_func=None, rho=None, ts=None, heun_reference_quirk=True, fused=None,
+                  reference_rng=None):
     if generator is None:
         generator = get_generator("dummy")
     model_kwargs = model_kwargs or {}
@@ -30,12 +31,20 @@ def karras_sample(model, x_T, steps, clip_denoised=True, progress=False, callbac
     if sampler not in ("heun", "euler"):
         raise KeyError(sampler)
 
+    # sample_heun draws one noise tensor per interval even when it is multiplied by zero (karras_sample.py:143-145).  The value is
+    # irrelevant, the RNG STATE is not: with the stateful determ / determ-indiv generators every later draw (the next batch's x_T and
+    # labels) depends on it.  reference_rng (default: on for exactly those generators) performs and discards the draws.
+    if reference_rng is None:
+        reference_rng = isinstance(generator, _Deterministic)
     use_cfg = model_kwargs.get("cfg_scale", 1.0) > 1.0
     if classifier is None and not clip_denoised and callback is None:
         from ..solvers import fused_fixed_grid_available, sample_fixed_grid_fused
 
         if fused is not False and fused_fixed_grid_available(model, x_T) and (sampler == "euler" or s_churn == 0.0):
             heun_limit = (40 if heun_reference_quirk else steps) if sampler == "heun" else 0
+            if sampler == "heun" and reference_rng:
+                for _ in range(steps - 1):  # the draws do not depend on the trajectory: advance the RNG as the reference does
+                    generator.randn_like(x_T)
             return sample_fixed_grid_fused(model, x_T, sigmas, model_kwargs, heun_limit=heun_limit)
     if fused is True:
         raise RuntimeError("fused=True but the fused path is not applicable (needs the HIP DiT on a GPU, no classifier/clip/callback)")
@@ -54,7 +63,7 @@ def karras_sample(model, x_T, steps, clip_denoised=True, progress=False, callbac
     if sampler == "euler":
         return sample_euler(fn, x_T, sigmas, generator, progress=progress, callback=callback)
     return sample_heun(fn, x_T, sigmas, generator, progress=progress, callback=callback, s_churn=s_churn, s_tmin=s_tmin,
-                       s_tmax=s_tmax, s_noise=s_noise, steps=40 if heun_reference_quirk else steps)
+                       s_tmax=s_tmax, s_noise=s_noise, steps=40 if heun_reference_quirk else steps, reference_rng=reference_rng)
 
 
 @th.no_grad()
@@ -72,9 +81,10 @@ def sample_euler(denoiser, x, sigmas, generator, progress=False, callback=None):
 
 @th.no_grad()
 def sample_heun(distiller, x, sigmas, generator, progress=False, callback=None, steps=40, s_churn=0.0, s_tmin=0.0,
-                s_tmax=float("inf"), s_noise=1.0):
+                s_tmax=float("inf"), s_noise=1.0, reference_rng=False):
     """Heun (karras_sample.py:121-161).  With s_churn = 0 the noise term is exactly zero; the reference still draws it
-    (an 819 MB RNG call per interval at 50k samples) -- we skip the draw when gamma == 0, the result is identical."""
+    (an 819 MB RNG call per interval at 50k samples).  The result of THIS batch is identical without the draw, so it is skipped
+    unless ``reference_rng`` asks for the reference's RNG stream (stateful generators: see karras_sample)."""
     s_in = x.new_ones([x.shape[0]])
     x_next = x
     n = len(sigmas) - 1
@@ -85,6 +95,8 @@ def sample_heun(distiller, x, sigmas, generator, progress=False, callback=None, 
         t_hat = th.as_tensor(t_cur + gamma * t_cur)
         if gamma == 0:
             x_hat = x_cur
+            if reference_rng:
+                generator.randn_like(x_cur)  # drawn and discarded: keeps the generator state on the reference's stream
         else:
             x_hat = x_cur + (t_hat ** 2 - t_cur ** 2).sqrt() * s_noise * generator.randn_like(x_cur)
         d_cur = distiller(x_hat, t_hat * s_in)

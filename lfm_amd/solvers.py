@@ -216,7 +216,7 @@ class GraphedFixedGrid:
         if use_cfg and not self.is_dit:
             raise NotImplementedError("classifier-free guidance needs forward_with_cfg, which the origin-ADM UNet does not have")
         self.model, self.batch, self.dev = model, batch, dev
-        self.y = None if y is None else y.to(dev, torch.long).contiguous()
+        self.y = None if y is None else y.to(dev, torch.long).clone()  # own the buffer the captured graph reads (never alias the caller's)
         self.use_cfg, self.cfg_scale = bool(use_cfg), float(cfg_scale)
         self.x = torch.zeros(batch, C, R, R, device=dev)
         self.d1 = torch.zeros_like(self.x)
@@ -319,22 +319,32 @@ class GraphedFixedGrid:
         return self.x
 
 
-_FUSED_CACHE = {}
+# The captured solvers of a model live ON the model object (not in a table keyed by id(model): a recycled id after GC would replay
+# another model's graph), so they are collected with it.
+
+
+def _label_rows(model):
+    if hasattr(model, "y_embedder"):
+        return model.y_embedder.get_in_channels()
+    return getattr(model, "num_classes", None)
 
 
 def _fused(model, x, model_kwargs):
     y = model_kwargs.get("y")
     cfg_scale = float(model_kwargs.get("cfg_scale", 1.0))
     use_cfg = cfg_scale > 1.0
-    key = (id(model), tuple(x.shape), use_cfg, cfg_scale, y is not None, x.device)
-    fg = _FUSED_CACHE.get(key)
+    if y is not None and _label_rows(model):
+        hip.check_labels(y, _label_rows(model), type(model).__name__)  # once, before the labels go into the captured graph's buffer
+    per_model = model.__dict__.setdefault("_fused_solvers", {})
+    key = (tuple(x.shape), use_cfg, cfg_scale, y is not None, x.device)
+    fg = per_model.get(key)
     if fg is None:
-        if len(_FUSED_CACHE) > 8:
-            _FUSED_CACHE.clear()
+        if len(per_model) > 8:
+            per_model.clear()
         fg = GraphedFixedGrid(model, x.shape[0], y=y, cfg_scale=cfg_scale, use_cfg=use_cfg, resolution=x.shape[-1])
-        _FUSED_CACHE[key] = fg
+        per_model[key] = fg
     elif y is not None:
-        fg.y.copy_(y)  # labels are read by the captured kernels from this buffer
+        fg.y.copy_(y)  # labels are read by the captured kernels from this (solver-owned) buffer
     return fg
 
 

@@ -63,7 +63,8 @@ def sample_from_model(model, x_0, model_kwargs, args):
         return torch.stack([x_0, x1], 0)
 
     if count:
-        model = NFECount(model).to(x_0.device)
+        model = NFECount(model)
+        model.nfe = model.nfe.to(x_0.device)  # only the counter moves: .to() on the wrapper would walk the wrapped model
     t = torch.tensor([1.0, 0.0], device=x_0.device)
 
     def denoiser(t, x):
@@ -123,12 +124,12 @@ def run_sampling(model, first_stage_model, args, num_samples, generator, device,
     return first_stage_model.decode(fake_sample / args.scale_factor).sample
 
 
-def load_checkpoint(model, path, device):
+def load_checkpoint(model, path, device, trust_checkpoint=False):
     """``model_{epoch}.pth`` (flat state_dict of an accelerate/DDP-wrapped model, train_flow_latent.py:211-214: ``module.`` stripped when
     present) or ``content.pth`` (train_flow_latent.py:196-203: the weights sit under ``model_dict``)."""
     from .io_formats import load_state_dict_file
 
-    model.load_state_dict(load_state_dict_file(path, map_location=device), strict=True)
+    model.load_state_dict(load_state_dict_file(path, map_location=device, trust_checkpoint=trust_checkpoint), strict=True)
 
 
 def build_parser():
@@ -190,6 +191,7 @@ def build_parser():
     p.add_argument("--random_weights", action="store_true", help="synthetic weights instead of ./saved_info checkpoints (benchmarking)")
     p.add_argument("--heun_reference_quirk", type=int, default=1, help="1: corrector only on intervals < 39 as the reference does")
     p.add_argument("--save_dir", type=str, default=None)
+    p.add_argument("--trust_checkpoint", action="store_true", help="allow the full (unsafe) unpickler for checkpoints the safe loader rejects")
     return p
 
 
@@ -211,7 +213,8 @@ def build_models(args, device):
         dezero_(model)
         vae = AutoencoderKL.from_random(seed=args.seed)
     else:
-        load_checkpoint(model, "./saved_info/latent_flow/{}/{}/model_{}.pth".format(args.dataset, args.exp, args.epoch_id), "cpu")
+        load_checkpoint(model, "./saved_info/latent_flow/{}/{}/model_{}.pth".format(args.dataset, args.exp, args.epoch_id), "cpu",
+                        trust_checkpoint=getattr(args, "trust_checkpoint", False))
         vae = AutoencoderKL.from_pretrained(args.pretrained_autoencoder_ckpt)
     return model.to(device).eval(), vae.to(device)
 

@@ -62,8 +62,8 @@ def main(argv=None):
     torch.cuda.set_device(device)
     dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
     rank, world = dist.get_rank(), dist.get_world_size()
-    args.seed = args.seed + rank  # reference :30
-    model, vae = build_models(args, device)
+    model, vae = build_models(args, device)  # un-offset seed: --random_weights must give every rank the SAME synthetic model
+    args.seed = args.seed + rank  # reference :30 (rank-local noise / label stream)
     generator = get_generator(args.generator, args.n_sample, args.seed)
     total, _, iters = shard_plan(args.n_sample, args.batch_size, world)
     save_dir = args.save_dir or "./generated_samples/{}/exp{}_ep{}_m{}".format(args.dataset, args.exp, args.epoch_id, args.method)

@@ -106,6 +106,29 @@ def golden_karras(ref_karras, ref_rand):
     return out
 
 
+def golden_karras_rng(ref_karras, ref_rand):
+    """Two consecutive Heun batches drawn from ONE stateful reference generator: the second batch's x_T depends on the noise
+    tensors sample_heun draws (and multiplies by zero) during the first (karras_sample.py:143-145, random_util.py:72-75)."""
+    g = torch.Generator().manual_seed(7)
+    A = torch.randn(16, 16, generator=g) * 0.3
+
+    def field(t, x, **kw):
+        flat = x.flatten(1)
+        return (torch.tanh(flat @ A) * (1.0 + t[:, None]) - 0.5 * flat).reshape(x.shape)
+
+    out = {"A": A}
+    for kind in ("determ", "determ-indiv"):
+        gen = ref_rand.get_generator(kind, 12, 5)
+        for b in range(2):
+            x = gen.randn(4, 1, 4, 4)
+            gen.done_samples = 0  # the reference driver never advances it either (test_flow_latent.py:161-162)
+            out[f"{kind}_x{b}"] = x
+            out[f"{kind}_out{b}"] = ref_karras.karras_sample(field, x.clone(), steps=11, model_kwargs={}, device="cpu", clip_denoised=False,
+                                                             sigma_min=1e-5, sigma_max=1.0, s_tmin=0.0, s_tmax=1.0, s_churn=0.0,
+                                                             sampler="heun", generator=gen)
+    return out
+
+
 def golden_randgen(ref_rand):
     out = {}
     for n, seed, bs in ((64, 42, 8), (10, 7, 4)):
@@ -217,6 +240,7 @@ def main():
     ref_dit, ref_karras, ref_rand = _import_reference()
     torch.save(golden_dit(ref_dit), os.path.join(OUT, "dit_tiny.pt"))
     torch.save(golden_karras(ref_karras, ref_rand), os.path.join(OUT, "karras.pt"))
+    torch.save(golden_karras_rng(ref_karras, ref_rand), os.path.join(OUT, "karras_rng.pt"))
     torch.save(golden_randgen(ref_rand), os.path.join(OUT, "randgen.pt"))
     torch.save(golden_unet(), os.path.join(OUT, "unet_tiny.pt"))
     torch.save(golden_edm(), os.path.join(OUT, "edm_tiny.pt"))

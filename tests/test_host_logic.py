@@ -63,6 +63,29 @@ def test_karras_sample_matches_reference(golden_dir, sampler, steps):
     torch.testing.assert_close(out, gold[f"{sampler}_{steps}"], rtol=0, atol=0)
 
 
+@pytest.mark.parametrize("kind", ["determ", "determ-indiv"])
+def test_heun_keeps_the_reference_rng_stream(golden_dir, kind):
+    """Two consecutive Heun batches from ONE stateful generator: batch 2's x_T depends on the (zero-weighted) noise tensors the
+    reference draws during batch 1 (karras_sample.py:143-145).  With the default reference_rng (on for determ*) the product
+    reproduces both batches bit-for-bit; with the draws skipped only the first one."""
+    from lfm_amd.sampler.karras_sample import karras_sample
+    from lfm_amd.sampler.random_util import get_generator
+
+    gold = _load(golden_dir, "karras_rng.pt")
+    field = _Field(gold["A"])
+    kw = dict(steps=11, model_kwargs={}, device="cpu", clip_denoised=False, sigma_min=1e-5, sigma_max=1.0, s_tmin=0.0, s_tmax=1.0,
+              s_churn=0.0, sampler="heun")
+    gen = get_generator(kind, 12, 5)
+    for b in range(2):
+        x = gen.randn(4, 1, 4, 4)
+        assert torch.equal(x, gold[f"{kind}_x{b}"]), b
+        assert torch.equal(karras_sample(field, x.clone(), generator=gen, **kw), gold[f"{kind}_out{b}"])
+    gen = get_generator(kind, 12, 5)
+    x0 = gen.randn(4, 1, 4, 4)
+    assert torch.equal(karras_sample(field, x0.clone(), generator=gen, reference_rng=False, **kw), gold[f"{kind}_out0"])  # same batch result
+    assert not torch.equal(gen.randn(4, 1, 4, 4), gold[f"{kind}_x1"])  # ... but the stream has left the reference's
+
+
 def test_heun_quirk_counts_nfe():
     """steps=40 default is frozen: a 50-point grid does 49 predictor + 39 corrector evaluations = 88 NFE."""
     from lfm_amd.sampler.karras_sample import karras_sample
@@ -235,3 +258,27 @@ def test_dit_workspace_requirement_is_monotone_in_the_batch():
         assert all(b >= a for a, b in zip(sizes, sizes[1:])), kw
     bad = hip.DitShape(depth=28, hidden=1152, heads=16, mlp_hidden=4608, patch=2, in_ch=4, res=32, label_rows=1)  # DiT-XL: head_dim 72
     assert L.lfm_dit_workspace_bytes(C.byref(bad), 1) == 0
+
+
+# ----------------------------------------------------------------------------- label bounds, buffer ownership, invalidation
+def test_label_bounds_raise_like_nn_embedding():
+    from lfm_amd import hip
+
+    hip.check_labels(torch.tensor([0, 3, 9]), 10, "t")
+    with pytest.raises(IndexError):
+        hip.check_labels(torch.tensor([0, 10]), 10, "t")   # e.g. CFG's null class on a model built with label_dropout = 0
+    with pytest.raises(IndexError):
+        hip.check_labels(torch.tensor([-1, 2]), 10, "t")
+
+
+def test_apply_without_a_move_keeps_the_packed_operands():
+    """NFECount(model).to(device) / model.to(same device) must not drop packed weights, workspaces or captured graphs."""
+    from lfm_amd.models import DiT_models
+
+    m = DiT_models["DiT-S/2"](img_resolution=32, in_channels=4, num_classes=1, label_dropout=0.0).eval()
+    m._packed, gen = "sentinel", m._gen
+    m.to("cpu")
+    m.float()
+    assert m._packed == "sentinel" and m._gen == gen
+    m.double()
+    assert m._packed is None and m._gen == gen + 1

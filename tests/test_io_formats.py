@@ -54,10 +54,28 @@ def test_checkpoint_layouts(tmp_path):
         assert sorted(got) == sorted(sd)          # 'modulex.bias' keeps its name: only a real 'module.' prefix is stripped
         for k in sd:
             assert torch.equal(got[k], sd[k])
+    # a real content.pth also carries optimizer state with non-tensor leaves: still the safe unpickler
+    content["optimizer"] = {"state": {0: {"step": 5, "exp_avg": torch.zeros(2)}}, "param_groups": [{"lr": 1e-4, "betas": (0.9, 0.999)}]}
+    torch.save(content, tmp_path / "content2.pth")
+    assert sorted(io.load_state_dict_file(str(tmp_path / "content2.pth"))) == sorted(sd)
     with pytest.raises(ValueError):
         io.extract_state_dict({"epoch": 1, "args": None})
     with pytest.raises(ValueError):
         io.extract_state_dict([1, 2, 3])
+
+
+class _Evil:
+    def __reduce__(self):
+        return (os.system, ("echo pwned > /dev/null",))
+
+
+def test_checkpoint_loader_never_falls_back_to_the_unsafe_unpickler(tmp_path):
+    """A pickle the safe loader rejects must stay rejected: no automatic weights_only=False retry."""
+    import pickle
+
+    torch.save({"w": torch.zeros(1), "payload": _Evil()}, tmp_path / "evil.pth")
+    with pytest.raises(pickle.UnpicklingError):
+        io.load_state_dict_file(str(tmp_path / "evil.pth"))
 
 
 def test_uint8_conversions_and_grid(tmp_path):

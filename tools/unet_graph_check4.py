@@ -9,7 +9,7 @@ a = Namespace(use_origin_adm=True, layout=False, model_type="adm", image_size=12
               attn_resolutions=(4, 2), dropout=0.0, ch_mult=(1, 2, 2), resamp_with_conv=True, num_classes=None, num_heads=4, num_head_channels=-1, num_head_upsample=-1)
 def fin(t): return bool(torch.isfinite(t).all())
 for mode in ("V1 expr;sync", "V2 hold;sync;del", "V3 expr;nosync", "V4 hold;del;sync", "V1 again", "V6 expr;sync;x-clone-input"):
-    solvers._FUSED_CACHE.clear(); gc.collect()
+    gc.collect()  # the captured solvers live on the model object and die with it
     sa = Namespace(method="euler", step_size=0.02, perturb=False, compute_nfe=False, cfg_scale=1.0, atol=1e-5, rtol=1e-5)
     torch.manual_seed(0); m = dezero_(create_network(a)).to(dev).eval()
     x = torch.randn(8, 4, 16, 16, device=dev)
@@ -25,6 +25,6 @@ for mode in ("V1 expr;sync", "V2 hold;sync;del", "V3 expr;nosync", "V4 hold;del;
     else:
         sample_from_model(m, x.clone(), {}, sa)[-1]; torch.cuda.synchronize()
     r2 = solve(); torch.cuda.synchronize()
-    fg = list(solvers._FUSED_CACHE.values())[0]
+    fg = list(m.__dict__['_fused_solvers'].values())[0]
     print(f"{mode:28s}: second finite={fin(r2)}  fg.x finite={fin(fg.x)} d tcur={float(fg.tcur):.3f} step={int(fg.step)}", flush=True)
     del m, fg
