@@ -308,6 +308,7 @@ class GraphedFixedGrid:
         self.x.copy_(x0)
         self.step.zero_()
         n_heun = max(0, min(n, heun_limit - 1)) if heun_limit else 0
+        self.last_plan = {"heun": n_heun, "euler": n - n_heun, "nfe": 2 * n_heun + (n - n_heun)}  # what this call replays
         if n_heun:
             h = self._get("heun")
             for _ in range(n_heun):

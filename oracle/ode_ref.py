@@ -10,9 +10,10 @@ dopri5) for the way the reference calls it:
                        atol=args.atol, rtol=args.rtol,
                        options={"step_size": h, "perturb": False} | {"dtype": float64})
 
-Under ``torch.no_grad`` the adjoint wrapper is a plain ``odeint``.  Anchors: analytic
-known-answer tests (``tests/test_ode_ref.py``: y'=-y, harmonic oscillator, order of convergence,
-NFE counts) and SURVEY.md Appendix B.1's numerically checked tableau.
+Under ``torch.no_grad`` the adjoint wrapper is a plain ``odeint``.  Anchors (``tests/test_ode_ref.py``): the
+Dormand-Prince tableau, single forced steps and the dense output against ``scipy.integrate.RK45`` (an independent
+implementation of the same pair), the Runge-Kutta order conditions of both the 5th-order and the embedded 4th-order
+weights, adaptive solves against ``solve_ivp``, analytic known answers (y'=-y, harmonic oscillator, orders, NFE counts).
 """
 import torch
 

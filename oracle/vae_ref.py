@@ -9,7 +9,9 @@ architecture of ``AutoencoderKL`` (decoder half) for the ``sd-vae-ft-mse`` confi
 latent 4, block_out_channels [128,256,512,512], layers_per_block 2 (=> 3 resnets per up block),
 norm_num_groups 32, GN eps 1e-6, SiLU, single-head mid attention.
 State-dict key names follow diffusers (>=0.2x) so a real checkpoint loads unchanged.
-Anchors: structural KATs in ``tests/test_vae_ref.py`` (shapes, FLOP count, conv/GN identities).
+Anchors (``tests/test_vae_ref.py``): the published parameter count (49,490,179 decoder + 20 post_quant_conv), the frozen diffusers key
+list ``tests/golden/vae_decoder_keys.json``, mid attention vs ``F.scaled_dot_product_attention``, resnet / GroupNorm / upsample
+identities, FLOP count 622.2 G.
 """
 import math
 

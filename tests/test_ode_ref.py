@@ -1,0 +1,201 @@
+"""Independent anchors for the torchdiffeq restatement (oracle/ode_ref.py) and the product solver (lfm_amd/solvers.py).  CPU only.
+
+torchdiffeq is not installable here, so ``dopri5`` stays **parity unpinned** against torchdiffeq itself.  What CAN be pinned, against
+sources that share no code or author with either file:
+
+* the Dormand-Prince tableau (nodes, stage matrix, 5th-order weights) against ``scipy.integrate.RK45`` (scipy 1.15, an independent
+  implementation of the same published pair);
+* the 4th-order dense output -- torchdiffeq fits a quartic through (y0, f0, y_mid, y1, f1) with Shampine's midpoint weights -- against
+  scipy's dense-output polynomial ``RK45.P`` (also Shampine's), on a nonlinear field with a FORCED identical step;
+* single steps with forced identical step sizes against scipy's own ``rk_step`` on a stiff-ish nonlinear field;
+* the Runge-Kutta order conditions themselves: the 5th-order weights satisfy all 17 conditions through order 5, and the embedded
+  weights ``c_sol - c_err`` (torchdiffeq's error estimator is NOT scipy's ``E``: it embeds a different 4th-order solution) satisfy
+  the 8 conditions through order 4 -- so ``err`` really is an O(h^5) local error estimate;
+* a full adaptive solve against ``scipy.integrate.solve_ivp(method="RK45")`` at the same tolerances (different controller and
+  estimator, so the step sequences differ; both must sit within the tolerance band of a tight reference solution).
+"""
+import numpy as np
+import pytest
+import torch
+from scipy.integrate import RK45, solve_ivp
+from scipy.integrate._ivp.rk import rk_step
+
+from lfm_amd import solvers as prod
+from oracle import ode_ref
+
+
+def _tableaus():
+    return {
+        "oracle": dict(a=ode_ref._A, b=ode_ref._B, sol=ode_ref._C_SOL, err=ode_ref._C_ERR, mid=ode_ref._C_MID),
+        "product": dict(a=list(prod._DP_A), b=[list(r) for r in prod._DP_B], sol=list(prod._DP_B[-1]) + [0.0], err=list(prod._DP_E),
+                        mid=list(prod._DP_MID)),
+    }
+
+
+@pytest.mark.parametrize("which", ["oracle", "product"])
+def test_tableau_equals_scipy_rk45(which):
+    tb = _tableaus()[which]
+    np.testing.assert_allclose(RK45.C[1:], tb["a"][:5], rtol=0, atol=1e-16)
+    assert tb["a"][5] == 1.0  # the FSAL stage sits at t1
+    for i in range(1, 6):
+        np.testing.assert_allclose(RK45.A[i, :i], tb["b"][i - 1], rtol=1e-15, atol=1e-16)
+    np.testing.assert_allclose(RK45.B, tb["b"][5], rtol=1e-15, atol=1e-16)     # last stage row == 5th-order weights (FSAL)
+    np.testing.assert_allclose(RK45.B, tb["sol"][:6], rtol=1e-15, atol=1e-16)
+    assert tb["sol"][6] == 0
+
+
+@pytest.mark.parametrize("which", ["oracle", "product"])
+def test_midpoint_weights_equal_scipy_dense_output_at_one_half(which):
+    """y(t0 + h/2) = y0 + h * sum_i c_mid[i] k_i.  scipy: y(t0 + theta h) = y0 + h * theta * sum_i k_i * sum_j P[i,j] theta^j."""
+    tb = _tableaus()[which]
+    theta = 0.5
+    w = np.array([theta * sum(RK45.P[i, j] * theta ** j for j in range(4)) for i in range(7)])
+    np.testing.assert_allclose(tb["mid"], w, rtol=1e-12, atol=1e-15)
+
+
+def _order_sums(b, A, c):
+    """Elementary weights of the 17 rooted trees through order 5 (Butcher), paired with 1 / gamma(tree)."""
+    b, A, c = np.asarray(b, float), np.asarray(A, float), np.asarray(c, float)
+    Ac, Ac2, Ac3 = A @ c, A @ c ** 2, A @ c ** 3
+    AAc = A @ Ac
+    return [
+        (b.sum(), 1.0),
+        (b @ c, 1 / 2),
+        (b @ c ** 2, 1 / 3), (b @ Ac, 1 / 6),
+        (b @ c ** 3, 1 / 4), (b @ (c * Ac), 1 / 8), (b @ Ac2, 1 / 12), (b @ AAc, 1 / 24),
+        (b @ c ** 4, 1 / 5), (b @ (c ** 2 * Ac), 1 / 10), (b @ (c * Ac2), 1 / 15), (b @ (c * AAc), 1 / 30), (b @ Ac ** 2, 1 / 20),
+        (b @ Ac3, 1 / 20), (b @ (A @ (c * Ac)), 1 / 40), (b @ (A @ Ac2), 1 / 60), (b @ (A @ AAc), 1 / 120),
+    ]
+
+
+@pytest.mark.parametrize("which", ["oracle", "product"])
+def test_runge_kutta_order_conditions(which):
+    tb = _tableaus()[which]
+    A = np.zeros((7, 7))
+    for i, row in enumerate(tb["b"]):
+        A[i + 1, : len(row)] = row
+    c = np.array([0.0] + list(tb["a"]))
+    np.testing.assert_allclose(A.sum(1), c, rtol=0, atol=1e-15)  # row-sum condition
+    sol = np.array(tb["sol"])
+    for got, want in _order_sums(sol, A, c):  # 5th-order solution: all 17 conditions
+        assert abs(got - want) < 1e-14
+    emb = sol - np.array(tb["err"])          # the embedded solution behind torchdiffeq's error estimate
+    cond = _order_sums(emb, A, c)
+    for got, want in cond[:8]:               # ... is 4th order
+        assert abs(got - want) < 1e-14
+    assert max(abs(g - w) for g, w in cond[8:]) > 1e-4   # ... and NOT 5th order, else err would vanish to O(h^6)
+    assert abs(sum(tb["err"])) < 1e-16
+    # and it is not scipy's embedded pair (same tableau, different 4th-order weights): documented difference
+    assert abs(tb["err"][0] - (-RK45.E[0])) > 1e-4
+
+
+# a stiff-ish nonlinear field on R^6 (decaying, rotating, with a cubic term); time-dependent
+_K = np.array([[-8.0, 6.0, 0, 0, 0, 0], [-6.0, -8.0, 0, 0, 0, 0], [0, 0, -1.5, 2.0, 0, 0], [0, 0, -2.0, -1.5, 0, 0], [0, 0, 0, 0, -0.3, 0.7],
+               [0.4, 0, 0, 0, -0.7, -0.3]])
+
+
+def _f_np(t, y):
+    return _K @ y - 0.8 * y ** 3 + np.array([np.sin(5 * t), 0, np.cos(3 * t), 0, 1.0, t])
+
+
+def _f_torch(t, y):
+    K = torch.from_numpy(_K)
+    tt = t.to(torch.float64)
+    forcing = torch.stack([torch.sin(5 * tt), torch.zeros_like(tt), torch.cos(3 * tt), torch.zeros_like(tt), torch.ones_like(tt), tt])
+    return K @ y - 0.8 * y ** 3 + forcing
+
+
+Y0 = np.array([1.0, -0.5, 0.8, 0.3, -1.2, 0.4])
+
+
+@pytest.mark.parametrize("h", [0.15, 0.11, 0.02, 1e-3])
+def test_single_step_and_dense_output_equal_scipy(h):
+    """Forced identical step from the same state: y1, f1 (FSAL) and the dense interpolant at theta in (0, 1)."""
+    t0 = 0.25
+    f0 = _f_np(t0, Y0)
+    K = np.empty((7, 6))
+    y1_s, f1_s = rk_step(_f_np, t0, Y0, f0, h, RK45.A, RK45.B, RK45.C, K)
+    thetas = np.array([0.1, 0.37, 0.5, 0.9, 1.0])
+    dense_s = np.stack([Y0 + h * th * (K.T @ np.array([sum(RK45.P[i, j] * th ** j for j in range(4)) for i in range(7)])) for th in thetas])
+
+    y0 = torch.from_numpy(Y0)
+    t0t, ht = torch.tensor(t0, dtype=torch.float64), torch.tensor(h, dtype=torch.float64)
+    # oracle
+    y1_o, f1_o, err_o, k_o = ode_ref._rk_step(_f_torch, y0, torch.from_numpy(f0), t0t, ht, t0t + ht)
+    np.testing.assert_allclose(y1_o.numpy(), y1_s, rtol=1e-13, atol=1e-14)
+    np.testing.assert_allclose(f1_o.numpy(), f1_s, rtol=1e-12, atol=1e-13)
+    coef = ode_ref._interp_fit(y0, y1_o, k_o, ht)
+    dense_o = np.stack([ode_ref._interp_eval(coef, t0t, t0t + ht, t0t + th * ht).numpy() for th in thetas])
+    np.testing.assert_allclose(dense_o, dense_s, rtol=1e-11, atol=1e-12)
+    # product: same step forced through Dopri5._step, dense output through advance()
+    s = prod.Dopri5(_f_torch, y0, t0t, rtol=1e9, atol=1e9)  # huge tolerance: the forced step is accepted whatever its error
+    s.dt = ht
+    s._step()
+    assert s.accepted == 1 and float(s.t1) == pytest.approx(t0 + h, abs=1e-15)
+    np.testing.assert_allclose(s.y0.numpy(), y1_s, rtol=1e-13, atol=1e-14)
+    np.testing.assert_allclose(s.f0.numpy(), f1_s, rtol=1e-12, atol=1e-13)
+    dense_p = np.stack([s.advance(t0t + th * ht).numpy() for th in thetas])
+    np.testing.assert_allclose(dense_p, dense_s, rtol=1e-11, atol=1e-12)
+    # the error estimate scales as h^5 relative to a half step (4th-order embedded pair): checked at the small steps only
+    if h <= 0.02:
+        _, _, err_half, _ = ode_ref._rk_step(_f_torch, y0, torch.from_numpy(f0), t0t, ht / 2, t0t + ht / 2)
+        ratio = float(err_o.norm() / err_half.norm())
+        assert 20 < ratio < 45  # 2^5 = 32
+
+
+@pytest.mark.parametrize("impl", ["oracle", "product"])
+@pytest.mark.parametrize("tol", [1e-5, 1e-7])
+def test_adaptive_solve_against_scipy_solve_ivp(impl, tol):
+    """Same problem, same rtol = atol, RMS norm in both; reference = scipy at 1e-12.  Integrates DOWN from t = 1 to 0 like the sampler
+    (the field is negated so that the backward direction is the stable one)."""
+    fn = lambda t, y: -_f_torch(t, y)  # noqa: E731
+    f_np = lambda t, y: -_f_np(t, y)  # noqa: E731
+    stats = {}
+    y0 = torch.from_numpy(Y0)
+    t = torch.tensor([1.0, 0.0])
+    od = ode_ref.odeint if impl == "oracle" else prod.odeint
+    got = od(fn, y0, t, method="dopri5", rtol=tol, atol=tol, stats=stats)[-1].numpy()
+    tight = solve_ivp(f_np, (1.0, 0.0), Y0, method="DOP853", rtol=1e-12, atol=1e-13).y[:, -1]
+    sci = solve_ivp(f_np, (1.0, 0.0), Y0, method="RK45", rtol=tol, atol=tol)
+    e_ours, e_sci = np.abs(got - tight).max(), np.abs(sci.y[:, -1] - tight).max()
+    assert e_ours < 50 * tol and e_sci < 50 * tol       # both inside the same global-error band
+    assert e_ours < 20 * max(e_sci, tol)                # and ours is not an outlier next to scipy's
+    assert stats["nfe"] if "nfe" in stats else True
+    n_sci = sci.t.size - 1
+    assert 0.4 * n_sci <= stats["accepted"] <= 2.5 * n_sci  # same pair, same norm: comparable step counts
+
+
+def test_fixed_grid_constructor_and_nfe():
+    """torchdiffeq's grid: arange(n)*h + t0 with the last point forced."""
+    for h, n in ((0.02, 51), (0.01, 101), (0.1, 11), (0.03, 35)):
+        g = ode_ref.fixed_grid(torch.tensor([-1.0, -0.0]), h)
+        assert g.numel() == n and float(g[-1]) == 0.0 and float(g[0]) == -1.0
+        g2 = prod.fixed_grid(torch.tensor([-1.0, -0.0]), h)
+        assert torch.equal(g, g2)
+    calls = []
+
+    def f(t, y):
+        calls.append(float(t))
+        return -y
+
+    ode_ref.odeint(f, torch.ones(2), torch.tensor([1.0, 0.0]), method="euler", options={"step_size": 0.03})
+    assert len(calls) == 34 and calls[0] == 1.0 and abs(calls[-1] - 0.01) < 1e-6  # short last step
+
+
+def test_known_answers():
+    """y' = -y and the harmonic oscillator against closed forms; dopri5 global error ~ tolerance; order of the fixed-grid schemes."""
+    y0 = torch.tensor([1.0, 2.0], dtype=torch.float64)
+    for od in (ode_ref.odeint, prod.odeint):
+        out = od(lambda t, y: -y, y0, torch.tensor([0.0, 1.0]), method="dopri5", rtol=1e-8, atol=1e-10)[-1]
+        np.testing.assert_allclose(out.numpy(), (y0 * np.exp(-1.0)).numpy(), rtol=1e-7)
+        rot = lambda t, y: torch.stack([y[1], -y[0]])  # noqa: E731
+        out = od(rot, torch.tensor([1.0, 0.0], dtype=torch.float64), torch.tensor([0.0, 2.0]), method="dopri5", rtol=1e-8, atol=1e-10)[-1]
+        np.testing.assert_allclose(out.numpy(), [np.cos(2.0), -np.sin(2.0)], atol=1e-6)
+        errs = {}
+        for method, order in (("euler", 1), ("midpoint", 2), ("rk4", 4)):
+            e = []
+            for h in (0.1, 0.05):
+                o = od(lambda t, y: -y, y0, torch.tensor([0.0, 1.0], dtype=torch.float64), method=method, options={"step_size": h})[-1]
+                e.append(float((o - y0 * np.exp(-1.0)).abs().max()))
+            errs[method] = np.log2(e[0] / e[1])
+            assert abs(errs[method] - order) < 0.25, (method, errs)
