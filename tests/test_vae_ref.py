@@ -93,7 +93,8 @@ def test_decode_shapes_upsampling_and_flops(sd):
     up = F.interpolate(h, scale_factor=2.0, mode="nearest")
     assert torch.equal(up[0, 0, 3], torch.tensor([4.0, 4, 5, 5, 6, 6, 7, 7]))
     assert abs(vae_ref.vae_decode_flops(32) / 1e9 - 622.2) < 0.05
-    assert abs(vae_ref.vae_decode_flops(64) / vae_ref.vae_decode_flops(32) - 4.0) < 0.03  # the T^2 attention term grows x16, the rest x4
+    r = vae_ref.vae_decode_flops(64) / vae_ref.vae_decode_flops(32)
+    assert 4.0 < r < 4.06  # everything grows x4 except the T^2 attention products (2.1 of the 622.2 G), which grow x16
     # per-block breakdown of SURVEY.md Appendix B.3 (GFLOP at R = 32): mid resnets 19.3 (each 9.66), conv_in 0.04, conv_out 0.45
     assert abs(2 * 2 * 32 * 32 * 512 * 512 * 9 * 2 / 1e9 - 19.3) < 0.05
     assert abs(2 * 256 * 256 * 128 * 3 * 9 / 1e9 - 0.45) < 0.01
