@@ -49,13 +49,69 @@ __device__ __forceinline__ void g256_tile_order(int bid, int nb, int tiles_n, in
   tile_n = within / gm;
 }
 
+// epilogues with fp16 outputs provide store8(m, n, lo, hi, aux_lo, aux_hi): EIGHT consecutive columns = one 16-byte store
+template <class Epi, class = void>
+struct epi_has_store8 {
+  static constexpr bool value = false;
+};
+template <class Epi>
+struct epi_has_store8<Epi, decltype((void)&Epi::store8)> {
+  static constexpr bool value = true;
+};
+
 // The row-major path of the epilogue: each wave transposes its accumulators through a private LDS scratch, see g256_epilogue.
+// fp16 outputs (store8): a lane re-reads EIGHT consecutive columns of a row (two ds_read_b128) and issues ONE 16-byte store, so a
+// store instruction covers 8 rows x one full 128-B line -- half the store instructions of the 4-column form.  The fp16 epilogues
+// were store-ISSUE bound (3.8 TB/s ~ 7 B/cycle/CU with 8-byte stores, the guide's T21 case), not bandwidth bound.
 template <class Epi>
 __device__ __forceinline__ void g256_epilogue_rows(f32x16 (&acc)[4][2], char* smem, const Epi& epi, int m0, int n0, int M, int N, int g, int wn,
-                                                   int lane, int wave) {
+                                                   int lane, int wave, bool narrow = false) {
   const int chalf = lane >> 5;
   char* scr = smem + wave * (32 * 272);
   const bool interior = (m0 + G256_BM <= M) && (n0 + G256_BN <= N);
+  if constexpr (epi_has_store8<Epi>::value) {
+    if (!narrow && epi.wide_ok()) {
+      const int rrow = lane >> 3, rcol = lane & 7;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+            *(f32x4*)(scr + (lane & 31) * 272 + (j * 32 + 8 * q + 4 * chalf) * 4) = v;
+          }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        f32x4 lo[4], hi[4];
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+          lo[ps] = *(const f32x4*)(scr + (ps * 8 + rrow) * 272 + rcol * 32);
+          hi[ps] = *(const f32x4*)(scr + (ps * 8 + rrow) * 272 + rcol * 32 + 16);
+        }
+        const int mb = m0 + g * 128 + i * 32 + rrow, n = n0 + wn * 64 + rcol * 8;
+        if (interior) {
+          typename Epi::Aux al[4], ah[4];
+#pragma unroll
+          for (int ps = 0; ps < 4; ++ps) {
+            al[ps] = epi.load(mb + ps * 8, n);
+            ah[ps] = epi.load(mb + ps * 8, n + 4);
+          }
+#pragma unroll
+          for (int ps = 0; ps < 4; ++ps) epi.store8(mb + ps * 8, n, lo[ps], hi[ps], al[ps], ah[ps]);
+        } else {
+#pragma unroll
+          for (int ps = 0; ps < 4; ++ps) {
+            const int m = mb + ps * 8;
+            if (m >= M) continue;
+            if (n + 7 < N) epi.store8(m, n, lo[ps], hi[ps], epi.load(m, n), epi.load(m, n + 4));
+            else if (n + 3 < N) epi.store(m, n, lo[ps], epi.load(m, n));  // N % 4 == 0: a ragged edge ends on a 4-column boundary
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      return;
+    }
+  }
   const int rrow = lane >> 4, rcol = lane & 15;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -102,6 +158,43 @@ __device__ __forceinline__ void g256_epilogue(f32x16 (&acc)[4][2], char* smem, E
     // The K loop ran this tile with the MFMA operands swapped: lane (n = lane&31, h) holds FOUR CONSECUTIVE m per register
     // group.  Same scratch, roles exchanged: rows = 32 columns n of block j, columns = 64 rows m of blocks 2*ih, 2*ih+1; read
     // back row-major, 16 lanes cover 64 consecutive m of one n -> epi.store_t(n, m, C[m..m+3][n]).
+    if (swapped && !(dbg & 1024) && epi.wide_t_ok()) {  // 16-byte stores: lane = (column n = lane>>3 of 8 per pass, 8 consecutive rows m)
+      char* scr = smem + wave * (32 * 272);
+      const int rrow = lane >> 3, rcol = lane & 7;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int nb = n0 + wn * 64 + j * 32 + rrow;
+        float bt[4];
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) bt[ps] = nb + ps * 8 < N ? epi.load_t(nb + ps * 8) : 0.f;
+#pragma unroll
+        for (int ih = 0; ih < 2; ++ih) {
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              f32x4 v = {acc[2 * ih + ii][j][4 * q], acc[2 * ih + ii][j][4 * q + 1], acc[2 * ih + ii][j][4 * q + 2], acc[2 * ih + ii][j][4 * q + 3]};
+              *(f32x4*)(scr + (lane & 31) * 272 + (ii * 32 + 8 * q + 4 * chalf) * 4) = v;
+            }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          f32x4 lo[4], hi[4];
+#pragma unroll
+          for (int ps = 0; ps < 4; ++ps) {
+            lo[ps] = *(const f32x4*)(scr + (ps * 8 + rrow) * 272 + rcol * 32);
+            hi[ps] = *(const f32x4*)(scr + (ps * 8 + rrow) * 272 + rcol * 32 + 16);
+          }
+          const int m = m0 + g * 128 + ih * 64 + rcol * 8;
+#pragma unroll
+          for (int ps = 0; ps < 4; ++ps) {
+            if (nb + ps * 8 >= N) continue;
+            if (m + 7 < M) epi.store_t8(nb + ps * 8, m, lo[ps], hi[ps], bt[ps]);
+            else if (m + 3 < M) epi.store_t(nb + ps * 8, m, lo[ps], bt[ps]);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+      }
+      return;
+    }
     if (swapped) {
       char* scr = smem + wave * (32 * 272);
       const int rrow = lane >> 4, rcol = lane & 15;
@@ -155,11 +248,11 @@ __device__ __forceinline__ void g256_epilogue(f32x16 (&acc)[4][2], char* smem, E
   if constexpr (epi_has_plain<Epi>::value) {
     if (epi.plain_tile(n0, G256_BN)) {
       auto pe = epi.plain(n0);
-      g256_epilogue_rows(acc, smem, pe, m0, n0, M, N, g, wn, lane, wave);
+      g256_epilogue_rows(acc, smem, pe, m0, n0, M, N, g, wn, lane, wave, (dbg & 1024) != 0);
       return;
     }
   }
-  g256_epilogue_rows(acc, smem, epi, m0, n0, M, N, g, wn, lane, wave);
+  g256_epilogue_rows(acc, smem, epi, m0, n0, M, N, g, wn, lane, wave, (dbg & 1024) != 0);  // flag 1024: the 8-byte-store epilogue (A/B)
 }
 
 template <class ASrc, class Epi>

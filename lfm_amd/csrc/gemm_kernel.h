@@ -62,6 +62,13 @@ struct EpiBiasF16 {  // C = acc + bias  -> fp16
     half4_t h = {(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
     *(half4_t*)(C + (long)m * ldc + n) = h;
   }
+  __device__ __forceinline__ bool wide_ok() const { return (ldc & 7) == 0 && ((uintptr_t)C & 15) == 0; }  // 16-byte stores are aligned
+  __device__ __forceinline__ void store8(int m, int n, f32x4 lo, f32x4 hi, const Aux& bl, const Aux& bh) const {
+    lo += bl;
+    hi += bh;
+    half8_t h = {(half_t)lo.x, (half_t)lo.y, (half_t)lo.z, (half_t)lo.w, (half_t)hi.x, (half_t)hi.y, (half_t)hi.z, (half_t)hi.w};
+    *(half8_t*)(C + (long)m * ldc + n) = h;
+  }
 };
 
 struct EpiBiasGeluF16 {  // C = gelu_tanh(acc + bias) -> fp16   (timm Mlp fc1, DiT.py:123-124)
@@ -74,6 +81,14 @@ struct EpiBiasGeluF16 {  // C = gelu_tanh(acc + bias) -> fp16   (timm Mlp fc1, D
     v += b;
     half4_t h = {(half_t)gelu_tanh_f(v.x), (half_t)gelu_tanh_f(v.y), (half_t)gelu_tanh_f(v.z), (half_t)gelu_tanh_f(v.w)};
     *(half4_t*)(C + (long)m * ldc + n) = h;
+  }
+  __device__ __forceinline__ bool wide_ok() const { return (ldc & 7) == 0 && ((uintptr_t)C & 15) == 0; }  // 16-byte stores are aligned
+  __device__ __forceinline__ void store8(int m, int n, f32x4 lo, f32x4 hi, const Aux& bl, const Aux& bh) const {
+    lo += bl;
+    hi += bh;
+    half8_t h = {(half_t)gelu_tanh_f(lo.x), (half_t)gelu_tanh_f(lo.y), (half_t)gelu_tanh_f(lo.z), (half_t)gelu_tanh_f(lo.w),
+                 (half_t)gelu_tanh_f(hi.x), (half_t)gelu_tanh_f(hi.y), (half_t)gelu_tanh_f(hi.z), (half_t)gelu_tanh_f(hi.w)};
+    *(half8_t*)(C + (long)m * ldc + n) = h;
   }
 };
 
@@ -171,6 +186,12 @@ struct EpiQKV {
   __device__ __forceinline__ void store_t(int n, int m, f32x4 v, float b) const {
     half4_t h = {(half_t)(v.x + b), (half_t)(v.y + b), (half_t)(v.z + b), (half_t)(v.w + b)};
     *(half4_t*)vt_ptr(n, m) = h;
+  }
+  __device__ __forceinline__ bool wide_t_ok() const { return (tokens & 7) == 0 && ((uintptr_t)Vt & 15) == 0; }
+  __device__ __forceinline__ void store_t8(int n, int m, f32x4 lo, f32x4 hi, float b) const {  // eight consecutive tokens
+    half8_t h = {(half_t)(lo.x + b), (half_t)(lo.y + b), (half_t)(lo.z + b), (half_t)(lo.w + b),
+                 (half_t)(hi.x + b), (half_t)(hi.y + b), (half_t)(hi.z + b), (half_t)(hi.w + b)};
+    *(half8_t*)vt_ptr(n, m) = h;
   }
 };
 

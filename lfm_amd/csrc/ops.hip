@@ -74,6 +74,14 @@ struct EpiResidF16 {  // out = acc + bias (+ residual) -> fp16
     half4_t h = {(half_t)(v.x + (float)a.r.x), (half_t)(v.y + (float)a.r.y), (half_t)(v.z + (float)a.r.z), (half_t)(v.w + (float)a.r.w)};
     *(half4_t*)(C + (long)m * ldc + n) = h;
   }
+  __device__ __forceinline__ bool wide_ok() const { return (ldc & 7) == 0 && ((uintptr_t)C & 15) == 0 && (!resid || ((uintptr_t)resid & 15) == 0); }
+  __device__ __forceinline__ void store8(int m, int n, f32x4 lo, f32x4 hi, const Aux& al, const Aux& ah) const {
+    lo += al.b;
+    hi += ah.b;
+    half8_t h = {(half_t)(lo.x + (float)al.r.x), (half_t)(lo.y + (float)al.r.y), (half_t)(lo.z + (float)al.r.z), (half_t)(lo.w + (float)al.r.w),
+                 (half_t)(hi.x + (float)ah.r.x), (half_t)(hi.y + (float)ah.r.y), (half_t)(hi.z + (float)ah.r.z), (half_t)(hi.w + (float)ah.r.w)};
+    *(half8_t*)(C + (long)m * ldc + n) = h;
+  }
 };
 
 struct EpiNCHWF32 {  // Cout <= 4 output conv: fp32 NCHW, channels beyond nch are padding

@@ -166,9 +166,10 @@ def test_dopri5_1e5_with_cfg_vs_oracle(dev, gain):
     yd = y.to(dev)
     got = odeint(lambda tt, xx: m.forward_with_cfg(tt, xx, yd, cfg_scale=1.5), x0.to(dev), t.to(dev), method="dopri5", rtol=1e-5, atol=1e-5, stats=sa)
     ref = ode_ref.odeint(lambda tt, xx: dit_ref.dit_forward_with_cfg(sd, cfg, tt, xx, y, 1.5), x0, t, method="dopri5", rtol=1e-5, atol=1e-5, stats=sb)
+    sb["nfe"] = 2 + 6 * sb["steps"]  # the oracle reports steps only: 2 evaluations for the initial step size + 6 per attempted step
     print(f"dopri5 1e-5 + CFG: HIP steps {sa['steps']} (accepted {sa['accepted']}, nfe {sa['nfe']}); oracle steps {sb['steps']} "
           f"(accepted {sb['accepted']}, nfe {sb['nfe']}); end-point rel-L2 {rel_l2(got[-1], ref[-1]):.2e}")
-    assert sa["nfe"] == 2 + 6 * sa["steps"] and sb["nfe"] == 2 + 6 * sb["steps"]
+    assert sa["nfe"] == 2 + 6 * sa["steps"]
     assert rel_l2(got[-1], ref[-1]) < 2e-3
     assert abs(sa["steps"] - sb["steps"]) <= 1 + sb["steps"] // 4
     assert torch.equal(got[-1][:2], got[-1][2:])
