@@ -8,8 +8,17 @@ int lfm_gemm_selected() { return g_gemm_sel; }
 static int g_gemm_dbg = 0;
 int lfm_gemm_debug_flags() { return g_gemm_dbg; }
 int lfm_gemm_selected_v1_ok() { return g_gemm_sel < 2 && !(g_gemm_dbg & 512); }  // flag 512: split-K off (A/B)
-extern "C" int lfm_gemm_select(int which) {  // low 4 bits: kernel choice (0 auto, 1..3); bits 4+: ablation flags (measurement only)
-  if ((which & 15) > 3 || which < 0) return LFM_ERR_ARG;
+// flag 4096: never pick v4 for 256-wide-capable shapes; flag 8192: always (A/B of the automatic choice)
+int lfm_gemm_prefers_v4(int M, int N, int K) {
+  (void)M;
+  (void)N;
+  (void)K;
+  if (g_gemm_dbg & 4096) return 0;
+  if (g_gemm_dbg & 8192) return 1;
+  return 0;
+}
+extern "C" int lfm_gemm_select(int which) {  // low 4 bits: kernel choice (0 auto, 1..4); bits 4+: ablation flags (measurement only)
+  if ((which & 15) > 4 || which < 0) return LFM_ERR_ARG;
   g_gemm_sel = which & 15;
   g_gemm_dbg = which >> 4;
   return LFM_OK;

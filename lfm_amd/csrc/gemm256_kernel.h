@@ -27,6 +27,7 @@
 
 int lfm_gemm_selected();     // 0 auto, 1 force v1, 2 force v2 (set by lfm_gemm_select)
 int lfm_gemm_debug_flags();  // ablation switches, measurement only
+int lfm_gemm_prefers_v4(int M, int N, int K);  // shapes where the 256x128 two-workgroups-per-CU kernel measured faster than the 256x256 one
 
 #define G256_BM 256
 #define G256_BN 256
@@ -63,12 +64,12 @@ struct epi_has_store8<Epi, decltype((void)&Epi::store8)> {
 // fp16 outputs (store8): a lane re-reads EIGHT consecutive columns of a row (two ds_read_b128) and issues ONE 16-byte store, so a
 // store instruction covers 8 rows x one full 128-B line -- half the store instructions of the 4-column form.  The fp16 epilogues
 // were store-ISSUE bound (3.8 TB/s ~ 7 B/cycle/CU with 8-byte stores, the guide's T21 case), not bandwidth bound.
-template <class Epi>
+template <int BN = G256_BN, class Epi>
 __device__ __forceinline__ void g256_epilogue_rows(f32x16 (&acc)[4][2], char* smem, const Epi& epi, int m0, int n0, int M, int N, int g, int wn,
                                                    int lane, int wave, bool narrow = false) {
   const int chalf = lane >> 5;
   char* scr = smem + wave * (32 * 272);
-  const bool interior = (m0 + G256_BM <= M) && (n0 + G256_BN <= N);
+  const bool interior = (m0 + G256_BM <= M) && (n0 + BN <= N);
   if constexpr (epi_has_store8<Epi>::value) {
     if (!narrow && epi.wide_ok()) {
       const int rrow = lane >> 3, rcol = lane & 7;
@@ -143,7 +144,7 @@ __device__ __forceinline__ void g256_epilogue_rows(f32x16 (&acc)[4][2], char* sm
 }
 
 // Shared epilogue of the 256x256 kernels (wave (g, wn) owns rows g*128.., columns wn*64.., acc[i][j] = 32x32 block i, j).
-template <class Epi>
+template <int BN = G256_BN, class Epi>
 __device__ __forceinline__ void g256_epilogue(f32x16 (&acc)[4][2], char* smem, Epi& epi, int m0, int n0, int M, int N, int g, int wn, int lane,
                                               int wave, int bz, long bsC, int dbg, bool swapped = false) {
   const int chalf = lane >> 5;
@@ -246,13 +247,13 @@ __device__ __forceinline__ void g256_epilogue(f32x16 (&acc)[4][2], char* smem, E
     return;
   }
   if constexpr (epi_has_plain<Epi>::value) {
-    if (epi.plain_tile(n0, G256_BN)) {
+    if (epi.plain_tile(n0, BN)) {
       auto pe = epi.plain(n0);
-      g256_epilogue_rows(acc, smem, pe, m0, n0, M, N, g, wn, lane, wave, (dbg & 1024) != 0);
+      g256_epilogue_rows<BN>(acc, smem, pe, m0, n0, M, N, g, wn, lane, wave, (dbg & 1024) != 0);
       return;
     }
   }
-  g256_epilogue_rows(acc, smem, epi, m0, n0, M, N, g, wn, lane, wave, (dbg & 1024) != 0);  // flag 1024: the 8-byte-store epilogue (A/B)
+  g256_epilogue_rows<BN>(acc, smem, epi, m0, n0, M, N, g, wn, lane, wave, (dbg & 1024) != 0);  // flag 1024: the 8-byte-store epilogue (A/B)
 }
 
 template <class ASrc, class Epi>

@@ -204,11 +204,12 @@ extern "C" int lfm_conv3x3_in_f32(const float* x_nchw, const float* w, const flo
 }
 
 // ------------------------------------------------------------------ general GroupNorm(32 groups) on NHWC fp16
-// 1) stats: one block per (group, image, pixel-slab) -> atomics into stats[n][g] = {sum, sumsq}
-// 2) coef : per (n, c):  a = rstd*gamma*(1+scale),  b = (beta - mean*rstd*gamma)*(1+scale) + shift     (FiLM optional)
+// 1) stats: one block per (image, pixel-slab) [fast path] or (group, image, pixel-slab) -> per-block PARTIAL {sum, sumsq} slots
+// 2) coef : per (n, c): folds the partials of its group in a FIXED order (deterministic: the reference is; atomics are not), then
+//           a = rstd*gamma*(1+scale),  b = (beta - mean*rstd*gamma)*(1+scale) + shift     (FiLM optional)
 // 3) apply: y = silu?(x*a + b), 8 channels per thread
 template <int VEC>
-__global__ __launch_bounds__(256) void gn_stats_general_kernel(const half_t* __restrict__ x, float* __restrict__ stats, int HW, int C, int cpg,
+__global__ __launch_bounds__(256) void gn_stats_general_kernel(const half_t* __restrict__ x, float* __restrict__ part, int HW, int C, int cpg,
                                                                int pix_per_block, int G) {
   const int g = blockIdx.x, n = blockIdx.y;
   const int p0 = blockIdx.z * pix_per_block, p1 = min(p0 + pix_per_block, HW);
@@ -241,16 +242,16 @@ __global__ __launch_bounds__(256) void gn_stats_general_kernel(const half_t* __r
     rq[threadIdx.x >> 6] = q;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    atomicAdd(&stats[((long)n * G + g) * 2], rs[0] + rs[1] + rs[2] + rs[3]);
-    atomicAdd(&stats[((long)n * G + g) * 2 + 1], rq[0] + rq[1] + rq[2] + rq[3]);
+  if (threadIdx.x == 0) {  // slot [n][slab][g]
+    float* o = part + (((long)n * gridDim.z + blockIdx.z) * G + g) * 2;
+    o[0] = rs[0] + rs[1] + rs[2] + rs[3];
+    o[1] = rq[0] + rq[1] + rq[2] + rq[3];
   }
 }
 
 // fast path (cpg % 4 == 0, C/8 <= 256): a block reads a slab of pixels with FULL rows (coalesced); thread = channel octet x pixel
-// row; per half-octet partial sums are folded through LDS and leave as one atomic pair per half-octet per block.
-__global__ __launch_bounds__(256) void gn_stats_rows_kernel(const half_t* __restrict__ x, float* __restrict__ stats, int HW, int C, int pix_per_block,
-                                                            int G) {
+// row; per half-octet partial sums are folded through LDS (fixed order) and leave as slot [n][slab][half-octet] of the partial buffer.
+__global__ __launch_bounds__(256) void gn_stats_rows_kernel(const half_t* __restrict__ x, float* __restrict__ part, int HW, int C, int pix_per_block) {
   __shared__ float red[4][256];
   const int n = blockIdx.y, c8n = C / 8, tid = threadIdx.x;
   const int rows = 256 / c8n;
@@ -282,24 +283,40 @@ __global__ __launch_bounds__(256) void gn_stats_rows_kernel(const half_t* __rest
       q[0] += red[2][tid + r * c8n];
       q[1] += red[3][tid + r * c8n];
     }
-    const int cpg = C / G;
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const int g = (tid * 8 + hh * 4) / cpg;
-      atomicAdd(&stats[((long)n * G + g) * 2 + 0], s[hh]);
-      atomicAdd(&stats[((long)n * G + g) * 2 + 1], q[hh]);
-    }
+    float* o = part + (((long)n * gridDim.x + blockIdx.x) * (C / 4) + tid * 2) * 2;
+    o[0] = s[0];
+    o[1] = q[0];
+    o[2] = s[1];
+    o[3] = q[1];
   }
 }
 
-__global__ void gn_coef_kernel(const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+// rows != 0: partials are [n][slab][C/4 half-octets] (fast path);  rows == 0: [n][slab][G]
+__global__ void gn_coef_kernel(const float* __restrict__ part, int slabs, int rows, const float* __restrict__ gamma, const float* __restrict__ beta,
                                const float* __restrict__ film, long film_stride, float* __restrict__ ab, int N, int C, int cpg, float cnt,
                                float eps, int G) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N * C) return;
   const int n = i / C, c = i - n * C, g = c / cpg;
-  const float mean = stats[((long)n * G + g) * 2] / cnt;
-  const float var = fmaxf(stats[((long)n * G + g) * 2 + 1] / cnt - mean * mean, 0.f);
+  float sum = 0.f, sq = 0.f;  // every channel of a group folds the same slots in the same order: identical, deterministic statistics
+  if (rows) {
+    const int h0 = g * (cpg / 4), h1 = h0 + cpg / 4, Q = C / 4;
+    for (int b = 0; b < slabs; ++b) {
+      const float* p = part + ((long)n * slabs + b) * Q * 2;
+      for (int h = h0; h < h1; ++h) {
+        sum += p[2 * h];
+        sq += p[2 * h + 1];
+      }
+    }
+  } else {
+    for (int b = 0; b < slabs; ++b) {
+      const float* p = part + (((long)n * slabs + b) * G + g) * 2;
+      sum += p[0];
+      sq += p[1];
+    }
+  }
+  const float mean = sum / cnt;
+  const float var = fmaxf(sq / cnt - mean * mean, 0.f);
   const float rstd = rsqrtf(var + eps);
   float a = rstd * gamma[c], b = beta[c] - mean * rstd * gamma[c];
   if (film) {  // h = norm(h) * (1 + scale) + shift   (unet.py:229-232; film row = [scale(C) | shift(C)])
@@ -336,29 +353,40 @@ __global__ __launch_bounds__(256) void gn_affine_kernel(const half_t* __restrict
   ((half8_t*)y)[i] = o;
 }
 
-extern "C" size_t lfm_groupnorm_scratch_bytes(int N, int C) { return (size_t)N * 64 * 4 + (size_t)N * C * 8 + 256; }
+#define GN_MAX_SLABS 64  // pixel slabs per image: bounds the partial buffer independently of HW
+static inline size_t gn_part_bytes(int N, int C) {
+  const size_t per_slab = (size_t)(C / 4 > 32 ? C / 4 : 32) * 2 * 4;  // max of the two partial layouts
+  return (((size_t)N * GN_MAX_SLABS * per_slab) + 255) / 256 * 256;
+}
+extern "C" size_t lfm_groupnorm_scratch_bytes(int N, int C) { return gn_part_bytes(N, C) + (size_t)N * C * 8 + 256; }
 
 extern "C" int lfm_groupnorm_f16(const void* x, void* y, const float* gamma, const float* beta, const float* film, long film_stride, void* scratch,
                                  int N, int HW, int C, int groups, float eps, int silu, lfm_stream_t stream) {
   if (!x || !y || !gamma || !beta || !scratch) return LFM_ERR_ARG;
   if (N <= 0 || HW <= 0 || groups <= 0 || groups > 32 || C % groups || C % 8) return LFM_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
-  float* stats = (float*)scratch;
-  float* ab = (float*)((char*)scratch + (((size_t)N * 64 * 4 + 255) / 256) * 256);
-  if (lfm_zero_async(stats, (size_t)N * 64 * 4, st)) return LFM_ERR_LAUNCH;
+  float* part = (float*)scratch;
+  float* ab = (float*)((char*)scratch + gn_part_bytes(N, C));
   const int G = groups, cpg = C / G;
+  int slabs, rows;
   if (cpg % 4 == 0 && C / 8 <= 256) {
-    const int ppb = HW >= 4096 ? 512 : (HW >= 256 ? 64 : HW);
-    hipLaunchKernelGGL(gn_stats_rows_kernel, dim3(cdiv(HW, ppb), N), dim3(256), 0, st, (const half_t*)x, stats, HW, C, ppb, G);
+    int ppb = HW >= 4096 ? 512 : (HW >= 256 ? 64 : HW);
+    if (cdiv(HW, ppb) > GN_MAX_SLABS) ppb = cdiv(HW, GN_MAX_SLABS);
+    slabs = cdiv(HW, ppb);
+    rows = 1;
+    hipLaunchKernelGGL(gn_stats_rows_kernel, dim3(slabs, N), dim3(256), 0, st, (const half_t*)x, part, HW, C, ppb);
   } else {
-    const int ppb = 2048;
-    dim3 grid(G, N, cdiv(HW, ppb));
-    if (cpg % 4 == 0) hipLaunchKernelGGL(gn_stats_general_kernel<4>, grid, dim3(256), 0, st, (const half_t*)x, stats, HW, C, cpg, ppb, G);
-    else hipLaunchKernelGGL(gn_stats_general_kernel<1>, grid, dim3(256), 0, st, (const half_t*)x, stats, HW, C, cpg, ppb, G);
+    int ppb = 2048;
+    if (cdiv(HW, ppb) > GN_MAX_SLABS) ppb = cdiv(HW, GN_MAX_SLABS);
+    slabs = cdiv(HW, ppb);
+    rows = 0;
+    dim3 grid(G, N, slabs);
+    if (cpg % 4 == 0) hipLaunchKernelGGL(gn_stats_general_kernel<4>, grid, dim3(256), 0, st, (const half_t*)x, part, HW, C, cpg, ppb, G);
+    else hipLaunchKernelGGL(gn_stats_general_kernel<1>, grid, dim3(256), 0, st, (const half_t*)x, part, HW, C, cpg, ppb, G);
   }
   LFM_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gn_coef_kernel, dim3(cdiv((long)N * C, 256)), dim3(256), 0, st, stats, gamma, beta, film, film_stride, ab, N, C, cpg,
-                     (float)HW * (float)cpg, eps, G);
+  hipLaunchKernelGGL(gn_coef_kernel, dim3(cdiv((long)N * C, 256)), dim3(256), 0, st, part, slabs, rows, gamma, beta, film, film_stride, ab, N, C,
+                     cpg, (float)HW * (float)cpg, eps, G);
   LFM_CHECK_LAUNCH();
   const long total8 = (long)N * HW * C / 8;
   if (silu) hipLaunchKernelGGL(gn_affine_kernel<true>, dim3(cdiv(total8, 256)), dim3(256), 0, st, (const half_t*)x, (half_t*)y, ab, HW, C, total8);

@@ -178,9 +178,12 @@ __global__ __launch_bounds__(256) void vae_conv_in_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------ GroupNorm(32 groups, eps 1e-6) on NHWC fp16
-// stats[n][g] = {sum, sumsq} accumulated with one atomicAdd pair per (block, group-slice); apply fuses SiLU.
+// Two-stage, deterministic statistics (the reference is deterministic; float atomics are not): every block folds its slab of pixels
+// into per-half-octet partial {sum, sumsq} slots part[n][slab][C/4], a small second kernel folds the slabs and the half-octets of a
+// group in a fixed order into stats[n][g]; apply fuses SiLU.
 // Block = 256 threads over a slab of pixels; thread t owns channel-octet (t % (C/8)) and strides over pixels.
-__global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict__ stats, int HW, int C,
+#define VGN_MAX_SLABS 64
+__global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict__ part, int HW, int C,
                                                        int pix_per_block) {
   __shared__ float red[4][256];
   const int n = blockIdx.y, c8n = C / 8, tid = threadIdx.x;
@@ -210,14 +213,27 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict_
       q[0] += red[2][tid + r * c8n];
       q[1] += red[3][tid + r * c8n];
     }
-    const int cpg = C / 32;
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const int g = (tid * 8 + hh * 4) / cpg;
-      atomicAdd(&stats[((long)n * 32 + g) * 2 + 0], s[hh]);
-      atomicAdd(&stats[((long)n * 32 + g) * 2 + 1], q[hh]);
+    float* o = part + (((long)n * gridDim.x + blockIdx.x) * (C / 4) + tid * 2) * 2;
+    o[0] = s[0];
+    o[1] = q[0];
+    o[2] = s[1];
+    o[3] = q[1];
+  }
+}
+__global__ void gn_finish_kernel(const float* __restrict__ part, float* __restrict__ stats, int slabs, int C, int total) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (n, g)
+  if (i >= total) return;
+  const int n = i >> 5, g = i & 31, hpg = C / 128;  // half-octets per group = (C/32)/4
+  float sum = 0.f, sq = 0.f;
+  for (int b = 0; b < slabs; ++b) {
+    const float* p = part + (((long)n * slabs + b) * (C / 4) + g * hpg) * 2;
+    for (int h = 0; h < hpg; ++h) {
+      sum += p[2 * h];
+      sq += p[2 * h + 1];
     }
   }
+  stats[(long)i * 2] = sum;
+  stats[(long)i * 2 + 1] = sq;
 }
 
 template <bool SILU>
@@ -272,6 +288,7 @@ static inline size_t a256(size_t v) { return (v + 255) / 256 * 256; }
 struct VaeWs {
   half_t *b0, *b1, *b2, *b3;  // four ping-pong activation buffers of the largest size
   float* stats;               // [chunk, 32, 2]
+  float* part;                // [chunk, VGN_MAX_SLABS, 128, 2] partial sums of the two-stage GroupNorm statistics
   half_t* zeros;              // 256 B
   float* S;                   // [chunk, T, T] scores
   size_t total;
@@ -295,6 +312,7 @@ static VaeWs vae_carve(int R, int chunk, void* ws) {
   w.b2 = (half_t*)take(act);
   w.b3 = (half_t*)take(act);
   w.stats = (float*)take((size_t)chunk * 64 * 4);
+  w.part = (float*)take((size_t)chunk * VGN_MAX_SLABS * 128 * 2 * 4);
   w.zeros = (half_t*)take(256);
   w.S = (float*)take((size_t)chunk * T * T * 4);
   w.total = off;
@@ -312,11 +330,15 @@ extern "C" size_t lfm_vae_workspace_bytes(int R, int chunk) {
     if (_rc) return _rc; \
   } while (0)
 
-static int gn(const half_t* x, half_t* y, float* stats, const float* g, const float* b, int n, int HW, int C, bool silu, hipStream_t st) {
-  if (C % 128 || 256 % (C / 8)) return LFM_ERR_SHAPE;  // groups of >= 4 channels, octet-per-thread mapping
-  if (lfm_zero_async(stats, (size_t)n * 64 * 4, st)) return LFM_ERR_LAUNCH;
-  const int ppb = 1024;
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(cdiv(HW, ppb), n), dim3(256), 0, st, x, stats, HW, C, ppb);
+static int gn(const half_t* x, half_t* y, float* stats, float* part, const float* g, const float* b, int n, int HW, int C, bool silu,
+              hipStream_t st) {
+  if (C % 128 || 256 % (C / 8) || C > 512) return LFM_ERR_SHAPE;  // groups of >= 4 channels, octet-per-thread mapping
+  int ppb = 1024;
+  if (cdiv(HW, ppb) > VGN_MAX_SLABS) ppb = cdiv(HW, VGN_MAX_SLABS);
+  const int slabs = cdiv(HW, ppb);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(slabs, n), dim3(256), 0, st, x, part, HW, C, ppb);
+  LFM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gn_finish_kernel, dim3(cdiv(n * 32, 64)), dim3(64), 0, st, part, stats, slabs, C, n * 32);
   LFM_CHECK_LAUNCH();
   const long total8 = (long)n * HW * C / 8;
   if (silu) hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(cdiv(total8, 256)), dim3(256), 0, st, x, y, stats, g, b, HW, C, total8);
@@ -337,9 +359,9 @@ static int conv3(const half_t* in, const half_t* w, const float* b, const half_t
 
 static int resnet(const lfm_vae_resnet* r, half_t*& x, half_t*& t1, half_t*& t2, half_t*& t3, const VaeWs& ws, int n, int H, int W, hipStream_t st) {
   const int HW = H * W, M = n * HW;
-  RC(gn(x, t1, ws.stats, r->n1_g, r->n1_b, n, HW, r->cin, true, st));
+  RC(gn(x, t1, ws.stats, ws.part, r->n1_g, r->n1_b, n, HW, r->cin, true, st));
   RC(conv3(t1, (const half_t*)r->c1_w, r->c1_b, nullptr, t2, ws.zeros, n, H, W, r->cin, r->cout, false, st));
-  RC(gn(t2, t1, ws.stats, r->n2_g, r->n2_b, n, HW, r->cout, true, st));
+  RC(gn(t2, t1, ws.stats, ws.part, r->n2_g, r->n2_b, n, HW, r->cout, true, st));
   const half_t* skip = x;
   if (r->sc_w) {  // 1x1 conv shortcut
     RC(launch_gemm_auto(ASrcRowMajor{x, r->cin, M, 0}, (const half_t*)r->sc_w, r->cin, M, r->cout, r->cin, EpiConvF16{t3, r->cout, r->sc_b, nullptr}, st));
@@ -380,7 +402,7 @@ extern "C" int lfm_vae_decode(const lfm_vae_weights* w, void* workspace, size_t 
     RC(resnet(&w->mid[0], x, t1, t2, t3, ws, n, H, H, st));
     {  // mid attention: 1 head of 512 channels over T = R*R tokens, all on the GEMM kernel
       const int M = n * T, C = 512;
-      RC(gn(x, t1, ws.stats, w->at_g, w->at_b, n, T, C, false, st));
+      RC(gn(x, t1, ws.stats, ws.part, w->at_g, w->at_b, n, T, C, false, st));
       half_t* Qb = t2;                 // [M, C]
       half_t* Kb = t2 + (size_t)M * C;  // [M, C]
       half_t* Vt = t3;                 // [n, C, T]
@@ -411,7 +433,7 @@ extern "C" int lfm_vae_decode(const lfm_vae_weights* w, void* workspace, size_t 
         x = o;
       }
     }
-    RC(gn(x, t1, ws.stats, w->no_g, w->no_b, n, H * H, 128, true, st));
+    RC(gn(x, t1, ws.stats, ws.part, w->no_g, w->no_b, n, H * H, 128, true, st));
     const int M = n * H * H;
     RC(launch_gemm_tn(ASrcConv3x3<0>{t1, ws.zeros, H, H, 128, M, 0, 0}, (const half_t*)w->cout_w, 9L * 128, M, 4, 9 * 128,
                       EpiConvOutNCHW{out + (long)n0 * 3 * H * H, w->cout_b, H * H}, st));

@@ -112,9 +112,11 @@ def test_unet_fullsize_vs_oracle_and_fused_sampling():
     eager = sample_from_model(m, x0.to(dev), {}, sargs)[-1]
     oracle = ode_ref.odeint(lambda tt, xx: unet_ref.unet_forward(sd, cfg, tt, xx), x0, torch.tensor([1.0, 0.0]), method="euler",
                             options={"step_size": 0.25})[-1]
-    # GroupNorm statistics are accumulated with fp32 atomics (summation order varies run to run), so two runs of the same
-    # kernels agree to fp16-rounding level, not bit-for-bit
-    assert rel_l2(fused, eager) < 1e-3
+    # GroupNorm statistics are a two-stage fixed-order reduction (no atomics): the forward is deterministic bit for bit, and the
+    # captured-graph solve runs exactly the kernels of the eager loop
+    v1, v2 = m(t.to(dev), x0.to(dev)), m(t.to(dev), x0.to(dev))
+    assert torch.equal(v1, v2)
+    assert rel_l2(fused, eager) < 1e-6
     assert rel_l2(fused, oracle) < 2e-3
 
 
@@ -143,4 +145,5 @@ def test_graphed_solve_replayed_after_the_device_went_idle():
     sargs.fused = False
     eager = sample_from_model(m, x, {}, sargs)[-1]
     assert bool(torch.isfinite(second).all()) and bool(torch.isfinite(third).all()) and bool(torch.isfinite(eager).all())
-    assert rel_l2(second, eager.cpu()) < 1e-3 and rel_l2(third, eager.cpu()) < 1e-3
+    assert torch.equal(second, third)  # deterministic replays
+    assert rel_l2(second, eager.cpu()) < 1e-5 and rel_l2(third, eager.cpu()) < 1e-5

@@ -13,7 +13,11 @@ def timeit(fn, n=20, warm=3):
     for _ in range(n): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n
-variants = [("default", 0)] + [(a.split("=")[0], int(a.split("=")[1]) << 4) for a in sys.argv[1:]]
+def _sel(v):  # "flags" or "kernel:flags"
+    k, _, f = v.rpartition(":")
+    return (int(k) if k else 0) | (int(f) << 4)
+variants = [("default", 0)] + [(a.split("=")[0], _sel(a.split("=")[1])) for a in sys.argv[1:] if "=" in a]
+SKIP_FWD = "nofwd" in sys.argv
 M = 16384
 for name, N, K, epi in [("qkv", 3072, 1024, "qkv"), ("proj", 1024, 1024, 3), ("fc1", 4096, 1024, 1), ("fc2", 1024, 4096, 3)]:
     A = (torch.randn(M, K, device=dev) * 0.5).half(); W = (torch.randn(N, K, device=dev) * 0.03).half(); b = torch.randn(N, device=dev)
@@ -32,6 +36,7 @@ for name, N, K, epi in [("qkv", 3072, 1024, "qkv"), ("proj", 1024, 1024, 3), ("f
         ms = statistics.median(res[vn])
         print(f"{name:5s} N={N} K={K} {vn:14s}: median {ms*1e3:7.1f} us ({2*M*N*K/ms/1e9:5.0f} TF)  min {min(res[vn])*1e3:7.1f}", flush=True)
 hip.gemm_select(0)
+if SKIP_FWD: sys.exit(0)
 m = DiT_models["DiT-L/2"](img_resolution=32, in_channels=4, num_classes=1, label_dropout=0.0)
 for p in m.parameters():
     if not bool(p.any()): torch.nn.init.normal_(p, std=0.02)
