@@ -168,6 +168,25 @@ size_t lfm_vae_workspace_bytes(int R, int chunk);
 int lfm_vae_decode(const lfm_vae_weights* w, void* workspace, size_t workspace_bytes, const float* z, float* out, int N, int R,
                    int chunk, lfm_stream_t stream);
 
+/* Encoder half (diffusers AutoencoderKL.encode as called at train_flow_latent.py:143 and
+ * downstream_tasks/test_flow_latent_inpainting.py:146).  fp16 tensors are GEMM operands [Cout][tap][Cin]. */
+typedef struct lfm_vae_enc_weights {
+  const float* cin_w; const float* cin_b;   /* encoder.conv_in [128,3,3,3], [128]         fp32 */
+  lfm_vae_resnet down[4][2];                /* encoder.down_blocks.i.resnets.j                 */
+  const void* ds_w[3]; const float* ds_b[3]; /* encoder.down_blocks.i.downsamplers.0.conv (stride 2, pad (0,1,0,1)) */
+  lfm_vae_resnet mid[2];                    /* encoder.mid_block.resnets.{0,1}                 */
+  const float* at_g; const float* at_b;     /* encoder.mid_block.attentions.0.group_norm       */
+  const void* q_w; const float* q_b; const void* k_w; const float* k_b;
+  const void* v_w; const float* v_b; const void* o_w; const float* o_b;
+  const float* no_g; const float* no_b;     /* encoder.conv_norm_out                           */
+  const void* cout_w; const float* cout_b;  /* quant_conv o encoder.conv_out folded: fp16 [8][9][512], fp32 [8] */
+} lfm_vae_enc_weights;
+
+/* moments[N,8,R,R] fp32 NCHW (mean | log-variance of the latent distribution) = quant_conv(Encoder(x)), x[N,3,8R,8R] fp32 NCHW.
+ * Workspace: lfm_vae_workspace_bytes(R, chunk), as for the decoder. */
+int lfm_vae_encode(const lfm_vae_enc_weights* w, void* workspace, size_t workspace_bytes, const float* x, float* moments, int N, int R,
+                   int chunk, lfm_stream_t stream);
+
 /* u8 NHWC = trunc(clamp((x+1)/2, 0, 1) * 255) of fp32 NCHW images (test_flow_latent_ddp.py:131-135). */
 int lfm_images_to_uint8(const float* x, uint8_t* out, int N, int H, int W, lfm_stream_t stream);
 /* Same with rounding != 0: trunc(clamp((x+1)/2, 0, 1) * 255 + 0.5), the conversion of torchvision.utils.save_image that the

@@ -48,6 +48,45 @@ struct ASrcConv3x3 {
   }
 };
 
+// Encoder downsampling (diffusers Downsample2D with padding=0: F.pad(x, (0,1,0,1)) then conv3x3, stride 2): output (oy, ox) reads
+// input (2*oy + ky, 2*ox + kx), zero beyond the bottom / right edge.  H, W are the OUTPUT size; the input is [N, 2H, 2W, Cin].
+struct ASrcConvDown {
+  const half_t* in;
+  const half_t* zeros;
+  int H, W, Cin, M;
+  int tap, ci0;
+  __device__ __forceinline__ void init(int, long) {}
+  struct Row {
+    int n, y, x;
+  };
+  __device__ __forceinline__ Row row(int m) const {
+    if (m >= M) m = M - 1;
+    Row r;
+    r.x = m % W;
+    const int t = m / W;
+    r.y = t % H;
+    r.n = t / H;
+    return r;
+  }
+  __device__ __forceinline__ void begin_tile(int kt, int bk) {
+    if (kt == 0) {
+      tap = 0;
+      ci0 = 0;
+    } else {
+      ci0 += bk;
+      if (ci0 >= Cin) {
+        ci0 = 0;
+        ++tap;
+      }
+    }
+  }
+  __device__ __forceinline__ const half_t* ptr(const Row& r, int koff) const {
+    const int iy = 2 * r.y + tap / 3, ix = 2 * r.x + tap % 3;
+    if (iy >= 2 * H || ix >= 2 * W) return zeros + koff;
+    return in + (((long)r.n * (2 * H) + iy) * (2 * W) + ix) * Cin + ci0 + koff;
+  }
+};
+
 // ------------------------------------------------------------------ epilogues
 struct EpiConvF16 {  // out = acc + bias (+ residual)  -> fp16 NHWC
   half_t* C;
@@ -133,6 +172,24 @@ struct EpiConvOutNCHW {  // final conv (Cout=3, padded to 4): fp32 NCHW image, t
     o[0] = v.x;
     o[HW] = v.y;
     o[2 * HW] = v.z;
+  }
+};
+
+struct EpiMomentsNCHW {  // encoder conv_out (+ folded quant_conv): fp32 NCHW [img][nch][pix], nch a multiple of 4
+  float* out;
+  const float* bias;
+  int HW, nch;
+  typedef f32x4 Aux;
+  __device__ __forceinline__ Aux load(int, int n) const { return n < nch ? *(const f32x4*)(bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  __device__ __forceinline__ void store(int m, int n, f32x4 v, const Aux& b) const {
+    if (n >= nch) return;
+    v += b;
+    const int img = m / HW, pix = m - img * HW;
+    float* o = out + ((long)img * nch + n) * HW + pix;
+    o[0] = v.x;
+    o[HW] = v.y;
+    o[2 * HW] = v.z;
+    o[3 * HW] = v.w;
   }
 };
 
@@ -374,6 +431,32 @@ static int resnet(const lfm_vae_resnet* r, half_t*& x, half_t*& t1, half_t*& t2,
   return LFM_OK;
 }
 
+// mid-block attention (diffusers Attention, 1 head of 512 channels over T tokens, residual): GroupNorm -> q, k, v -> softmax(q k^T / sqrt(C)) v
+// -> to_out + x, all on the GEMM kernel.  x is replaced by the result (buffers rotate).
+static int mid_attention(const float* at_g, const float* at_b, const void* q_w, const float* q_b, const void* k_w, const float* k_b, const void* v_w,
+                         const float* v_b, const void* o_w, const float* o_b, half_t*& x, half_t*& t1, half_t*& t2, half_t*& t3, const VaeWs& ws,
+                         int n, int T, hipStream_t st) {
+  const int M = n * T, C = 512;
+  RC(gn(x, t1, ws.stats, ws.part, at_g, at_b, n, T, C, false, st));
+  half_t* Qb = t2;                 // [M, C]
+  half_t* Kb = t2 + (size_t)M * C;  // [M, C]
+  half_t* Vt = t3;                 // [n, C, T]
+  half_t* Pb = t3 + (size_t)M * C;  // [n, T, T]
+  RC(launch_gemm_tn(ASrcRowMajor{t1, C, M, 0}, (const half_t*)q_w, C, M, C, C, EpiConvF16{Qb, C, q_b, nullptr}, st));
+  RC(launch_gemm_tn(ASrcRowMajor{t1, C, M, 0}, (const half_t*)k_w, C, M, C, C, EpiConvF16{Kb, C, k_b, nullptr}, st));
+  RC(launch_gemm_tn(ASrcRowMajor{t1, C, M, 0}, (const half_t*)v_w, C, M, C, C, EpiTransposeF16{Vt, v_b, T, C}, st));
+  RC(launch_gemm_tn(ASrcRowMajor{Qb, C, T, 0}, Kb, C, T, T, C, EpiBatchF32{ws.S, T}, st, n, (long)T * C, (long)T * C, (long)T * T));
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv((long)n * T, 4)), dim3(256), 0, st, ws.S, Pb, (long)n * T, T, 1.4426950408889634f / sqrtf((float)C));
+  LFM_CHECK_LAUNCH();
+  half_t* Ob = t1;  // GN output is dead now
+  RC(launch_gemm_tn(ASrcRowMajor{Pb, T, T, 0}, Vt, T, T, C, T, EpiBatchF16{Ob, C}, st, n, (long)T * T, (long)C * T, (long)T * C));
+  RC(launch_gemm_tn(ASrcRowMajor{Ob, C, M, 0}, (const half_t*)o_w, C, M, C, C, EpiConvF16{t2, C, o_b, x}, st));
+  half_t* o = t2;
+  t2 = x;
+  x = o;
+  return LFM_OK;
+}
+
 extern "C" int lfm_vae_decode(const lfm_vae_weights* w, void* workspace, size_t workspace_bytes, const float* z, float* out, int N, int R,
                               int chunk, lfm_stream_t stream) {
   if (!w || !workspace || !z || !out) return LFM_ERR_ARG;
@@ -400,27 +483,7 @@ extern "C" int lfm_vae_decode(const lfm_vae_weights* w, void* workspace, size_t 
     LFM_CHECK_LAUNCH();
     int H = R;
     RC(resnet(&w->mid[0], x, t1, t2, t3, ws, n, H, H, st));
-    {  // mid attention: 1 head of 512 channels over T = R*R tokens, all on the GEMM kernel
-      const int M = n * T, C = 512;
-      RC(gn(x, t1, ws.stats, ws.part, w->at_g, w->at_b, n, T, C, false, st));
-      half_t* Qb = t2;                 // [M, C]
-      half_t* Kb = t2 + (size_t)M * C;  // [M, C]
-      half_t* Vt = t3;                 // [n, C, T]
-      half_t* Pb = t3 + (size_t)M * C;  // [n, T, T]
-      RC(launch_gemm_tn(ASrcRowMajor{t1, C, M, 0}, (const half_t*)w->q_w, C, M, C, C, EpiConvF16{Qb, C, w->q_b, nullptr}, st));
-      RC(launch_gemm_tn(ASrcRowMajor{t1, C, M, 0}, (const half_t*)w->k_w, C, M, C, C, EpiConvF16{Kb, C, w->k_b, nullptr}, st));
-      RC(launch_gemm_tn(ASrcRowMajor{t1, C, M, 0}, (const half_t*)w->v_w, C, M, C, C, EpiTransposeF16{Vt, w->v_b, T, C}, st));
-      RC(launch_gemm_tn(ASrcRowMajor{Qb, C, T, 0}, Kb, C, T, T, C, EpiBatchF32{ws.S, T}, st, n, (long)T * C, (long)T * C, (long)T * T));
-      hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv((long)n * T, 4)), dim3(256), 0, st, ws.S, Pb, (long)n * T, T,
-                         1.4426950408889634f / sqrtf((float)C));
-      LFM_CHECK_LAUNCH();
-      half_t* Ob = t1;  // GN output is dead now
-      RC(launch_gemm_tn(ASrcRowMajor{Pb, T, T, 0}, Vt, T, T, C, T, EpiBatchF16{Ob, C}, st, n, (long)T * T, (long)C * T, (long)T * C));
-      RC(launch_gemm_tn(ASrcRowMajor{Ob, C, M, 0}, (const half_t*)w->o_w, C, M, C, C, EpiConvF16{t2, C, w->o_b, x}, st));
-      half_t* o = t2;
-      t2 = x;
-      x = o;
-    }
+    RC(mid_attention(w->at_g, w->at_b, w->q_w, w->q_b, w->k_w, w->k_b, w->v_w, w->v_b, w->o_w, w->o_b, x, t1, t2, t3, ws, n, T, st));
     RC(resnet(&w->mid[1], x, t1, t2, t3, ws, n, H, H, st));
     for (int i = 0; i < 4; ++i) {
       for (int j = 0; j < 3; ++j) RC(resnet(&w->up[i][j], x, t1, t2, t3, ws, n, H, H, st));
@@ -437,6 +500,59 @@ extern "C" int lfm_vae_decode(const lfm_vae_weights* w, void* workspace, size_t 
     const int M = n * H * H;
     RC(launch_gemm_tn(ASrcConv3x3<0>{t1, ws.zeros, H, H, 128, M, 0, 0}, (const half_t*)w->cout_w, 9L * 128, M, 4, 9 * 128,
                       EpiConvOutNCHW{out + (long)n0 * 3 * H * H, w->cout_b, H * H}, st));
+  }
+  return LFM_OK;
+}
+
+
+// ------------------------------------------------------------------ encoder (diffusers AutoencoderKL.encode, sd-vae-ft-mse config)
+// Reference call sites: train_flow_latent.py:143 and downstream_tasks/test_flow_latent_inpainting.py:146
+//   first_stage_model.encode(x).latent_dist.sample().mul_(scale_factor)
+// moments[N,8,R,R] fp32 NCHW = quant_conv(Encoder(x)) for x[N,3,8R,8R] fp32 NCHW: channels 0..3 the mean, 4..7 the log-variance of the
+// DiagonalGaussianDistribution (the sampling / clamping of the distribution is host code).  quant_conv (1x1, 8 -> 8) is folded into
+// conv_out's weights by the caller (exact algebra).  Same workspace as the decoder (lfm_vae_workspace_bytes(R, chunk)).
+extern "C" int lfm_conv3x3_in_f32(const float* x_nchw, const float* w, const float* bias, void* out_nhwc, int N, int H, int W, int Cin, int Cout,
+                                  lfm_stream_t stream);
+
+static int conv_down(const half_t* in, const half_t* w, const float* b, half_t* out, const half_t* zeros, int n, int Ho, int Wo, int C, hipStream_t st) {
+  if (C % 64) return LFM_ERR_SHAPE;
+  const int M = n * Ho * Wo;
+  return launch_gemm_auto(ASrcConvDown{in, zeros, Ho, Wo, C, M, 0, 0}, w, 9L * C, M, C, 9 * C, EpiConvF16{out, C, b, nullptr}, st);
+}
+
+extern "C" int lfm_vae_encode(const lfm_vae_enc_weights* w, void* workspace, size_t workspace_bytes, const float* x, float* moments, int N, int R,
+                              int chunk, lfm_stream_t stream) {
+  if (!w || !workspace || !x || !moments) return LFM_ERR_ARG;
+  if (N <= 0 || R <= 0 || (R % 8) || chunk <= 0) return LFM_ERR_SHAPE;
+  const VaeWs ws = vae_carve(R, chunk, workspace);
+  if (ws.total > workspace_bytes) return LFM_ERR_WORKSPACE;
+  if ((uintptr_t)workspace & 255) return LFM_ERR_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  if (lfm_zero_async(ws.zeros, 256, st)) return LFM_ERR_LAUNCH;
+  const int S = 8 * R;
+  for (int n0 = 0; n0 < N; n0 += chunk) {
+    const int n = (N - n0 < chunk) ? N - n0 : chunk;
+    half_t *h = ws.b0, *t1 = ws.b1, *t2 = ws.b2, *t3 = ws.b3;
+    RC(lfm_conv3x3_in_f32(x + (long)n0 * 3 * S * S, w->cin_w, w->cin_b, h, n, S, S, 3, 128, stream));
+    int H = S;
+    for (int i = 0; i < 4; ++i) {
+      for (int j = 0; j < 2; ++j) RC(resnet(&w->down[i][j], h, t1, t2, t3, ws, n, H, H, st));
+      if (i < 3) {
+        const int C = w->down[i][1].cout;
+        H /= 2;
+        RC(conv_down(h, (const half_t*)w->ds_w[i], w->ds_b[i], t1, ws.zeros, n, H, H, C, st));
+        half_t* o = t1;
+        t1 = h;
+        h = o;
+      }
+    }
+    RC(resnet(&w->mid[0], h, t1, t2, t3, ws, n, H, H, st));
+    RC(mid_attention(w->at_g, w->at_b, w->q_w, w->q_b, w->k_w, w->k_b, w->v_w, w->v_b, w->o_w, w->o_b, h, t1, t2, t3, ws, n, H * H, st));
+    RC(resnet(&w->mid[1], h, t1, t2, t3, ws, n, H, H, st));
+    RC(gn(h, t1, ws.stats, ws.part, w->no_g, w->no_b, n, H * H, 512, true, st));
+    const int M = n * H * H;
+    RC(launch_gemm_tn(ASrcConv3x3<0>{t1, ws.zeros, H, H, 512, M, 0, 0}, (const half_t*)w->cout_w, 9L * 512, M, 8, 9 * 512,
+                      EpiMomentsNCHW{moments + (long)n0 * 8 * H * H, w->cout_b, H * H, 8}, st));
   }
   return LFM_OK;
 }

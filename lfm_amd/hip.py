@@ -82,6 +82,8 @@ def lib():
     L.lfm_vae_workspace_bytes.argtypes = [C.c_int, C.c_int]
     L.lfm_vae_decode.restype = C.c_int
     L.lfm_vae_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.lfm_vae_encode.restype = C.c_int
+    L.lfm_vae_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.lfm_images_to_uint8.restype = C.c_int
     L.lfm_images_to_uint8.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.lfm_images_to_uint8_mode.restype = C.c_int

@@ -196,7 +196,8 @@ def fused_fixed_grid_available(model, x):
     from .models.DiT import DiT
     from .models.unet import UNetModel
 
-    return isinstance(model, (DiT, UNetModel)) and x.is_cuda and not model.training
+    inner = getattr(model, "model", None) if type(model).__name__ == "WrapperCondFlow" else model  # downstream-task conditioning wrapper
+    return isinstance(inner, (DiT, UNetModel)) and x.is_cuda and not inner.training
 
 
 class GraphedFixedGrid:

@@ -181,6 +181,43 @@ def golden_unet():
     return out
 
 
+def golden_inpaint():
+    """The conditional velocity field of the downstream samplers: the unmodified reference UNetModel with 9 input channels behind the
+    reference's WrapperCondFlow (downstream_tasks/test_flow_latent_inpainting.py:80-88 -- restated here in three lines because that file
+    imports torchdiffeq / diffusers / torchvision and cannot be imported), two velocity evaluations and a 4-step explicit Euler solve
+    from t = 1 to t = 0 (x <- x + dt * v(t, x), dt = -0.25: what torchdiffeq's fixed-grid euler does on this grid)."""
+    sys.path.insert(0, REF)
+    from models.guided_diffusion.unet import UNetModel
+
+    g = torch.Generator().manual_seed(31)
+    kw = dict(image_size=16, in_channels=9, model_channels=64, out_channels=4, num_res_blocks=1, dropout=0.0, conv_resample=True,
+              dims=2, use_checkpoint=False, use_fp16=False, num_head_channels=-1, num_heads_upsample=-1, use_scale_shift_norm=True,
+              resblock_updown=False, use_new_attention_order=False, attention_resolutions=(2,), channel_mult=(1, 2), num_classes=None, num_heads=2)
+    torch.manual_seed(0)
+    m = UNetModel(**kw).eval()
+    _dezero_module(m, 977)
+    sd = m.state_dict()
+    for k in sd:
+        sd[k].copy_(sd[k].half().float())
+    m.load_state_dict(sd)
+    x = torch.randn(2, 4, 16, 16, generator=g)
+    cond = torch.cat([torch.randn(2, 4, 16, 16, generator=g), (torch.rand(2, 1, 16, 16, generator=g) > 0.5).float() * 2 - 1], 1)
+
+    def wrapped(t, xx):  # WrapperCondFlow.forward
+        return m(t, torch.cat([xx, cond], 1))
+
+    rec = {"cfg": kw, "state_dict": {k: v.clone().half() for k, v in m.state_dict().items()}, "x": x, "cond": cond}
+    with torch.no_grad():
+        rec["v_t1"] = wrapped(torch.tensor([1.0, 1.0]), x)
+        rec["v_tN"] = wrapped(torch.tensor([0.7, 0.2]), x)
+        xx = x.clone()
+        for k in range(4):
+            t = torch.full((2,), 1.0 - 0.25 * k)
+            xx = xx + (-0.25) * wrapped(t, xx)
+        rec["x_euler4"] = xx
+    return rec
+
+
 def golden_edm():
     """DhariwalUNet (models/EDM.py:716-861): plain forward with labels, and forward_with_cfg."""
     import models.EDM as ref_edm
@@ -244,6 +281,7 @@ def main():
     torch.save(golden_randgen(ref_rand), os.path.join(OUT, "randgen.pt"))
     torch.save(golden_unet(), os.path.join(OUT, "unet_tiny.pt"))
     torch.save(golden_edm(), os.path.join(OUT, "edm_tiny.pt"))
+    torch.save(golden_inpaint(), os.path.join(OUT, "inpaint_tiny.pt"))
     torch.save(golden_fid(), os.path.join(OUT, "fid.pt"))
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

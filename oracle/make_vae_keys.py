@@ -1,4 +1,4 @@
-"""Writes tests/golden/vae_decoder_keys.json: the state-dict keys and shapes of the DECODE half of diffusers' ``AutoencoderKL`` for the
+"""Writes tests/golden/vae_decoder_keys.json (+ vae_encoder_keys.json): the state-dict keys and shapes of diffusers' ``AutoencoderKL`` for the
 ``stabilityai/sd-vae-ft-mse`` config, spelled out from the published module tree (diffusers >= 0.2x naming: ``to_q / to_k / to_v /
 to_out.0``; config: latent_channels 4, block_out_channels [128, 256, 512, 512], layers_per_block 2, norm_num_groups 32).
 Deliberately independent of oracle/vae_ref.py and lfm_amd/autoencoder.py (test infrastructure; diffusers itself is not installable)."""
@@ -58,6 +58,33 @@ def main():
     conv("decoder.conv_out", 3, 128, 3)
     json.dump(keys, open(OUT, "w"), indent=0, sort_keys=True)
     print(len(keys), "keys ->", OUT)
+
+    # ---- encoder half + quant_conv: down_blocks over block_out_channels = 128, 256, 512, 512; TWO resnets each (layers_per_block);
+    # a stride-2 downsampler conv on all but the last; mid block as in the decoder; double_z => conv_out has 2 * latent_channels outputs
+    keys.clear()
+    conv("quant_conv", 8, 8, 1)
+    conv("encoder.conv_in", 128, 3, 3)
+    resnet("encoder.down_blocks.0.resnets.0", 128, 128)
+    resnet("encoder.down_blocks.0.resnets.1", 128, 128)
+    conv("encoder.down_blocks.0.downsamplers.0.conv", 128, 128, 3)
+    resnet("encoder.down_blocks.1.resnets.0", 128, 256)
+    resnet("encoder.down_blocks.1.resnets.1", 256, 256)
+    conv("encoder.down_blocks.1.downsamplers.0.conv", 256, 256, 3)
+    resnet("encoder.down_blocks.2.resnets.0", 256, 512)
+    resnet("encoder.down_blocks.2.resnets.1", 512, 512)
+    conv("encoder.down_blocks.2.downsamplers.0.conv", 512, 512, 3)
+    resnet("encoder.down_blocks.3.resnets.0", 512, 512)
+    resnet("encoder.down_blocks.3.resnets.1", 512, 512)
+    resnet("encoder.mid_block.resnets.0", 512, 512)
+    vec("encoder.mid_block.attentions.0.group_norm", 512)
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        lin("encoder.mid_block.attentions.0." + n, 512, 512)
+    resnet("encoder.mid_block.resnets.1", 512, 512)
+    vec("encoder.conv_norm_out", 512)
+    conv("encoder.conv_out", 8, 512, 3)
+    out2 = OUT.replace("vae_decoder_keys", "vae_encoder_keys")
+    json.dump(keys, open(out2, "w"), indent=0, sort_keys=True)
+    print(len(keys), "keys ->", out2)
 
 
 if __name__ == "__main__":

@@ -71,6 +71,61 @@ def vae_decode(sd, z):
     return _conv(sd, "decoder.conv_out", h, 1)
 
 
+def downsample(sd, pre, x):
+    """diffusers Downsample2D(use_conv=True, padding=0): F.pad(x, (0, 1, 0, 1)) then conv3x3 stride 2."""
+    return F.conv2d(F.pad(x, (0, 1, 0, 1)), sd[pre + ".weight"], sd[pre + ".bias"], stride=2)
+
+
+@torch.no_grad()
+def vae_encode_moments(sd, x):
+    """``AutoencoderKL.encode(x).latent_dist.parameters`` : [N,3,8R,8R] -> [N,8,R,R] (mean | logvar before the clamp).
+    Restates diffusers' Encoder for the sd-vae-ft-mse config (block_out_channels [128,256,512,512], layers_per_block 2,
+    double_z) followed by quant_conv; call sites train_flow_latent.py:143, downstream_tasks/test_flow_latent_inpainting.py:146."""
+    h = _conv(sd, "encoder.conv_in", x, 1)
+    for i in range(4):
+        for j in range(2):
+            h = resnet(sd, f"encoder.down_blocks.{i}.resnets.{j}", h)
+        if i < 3:
+            h = downsample(sd, f"encoder.down_blocks.{i}.downsamplers.0.conv", h)
+    h = resnet(sd, "encoder.mid_block.resnets.0", h)
+    h = mid_attention(sd, "encoder.mid_block.attentions.0", h)
+    h = resnet(sd, "encoder.mid_block.resnets.1", h)
+    h = F.silu(_gn(sd, "encoder.conv_norm_out", h))
+    h = _conv(sd, "encoder.conv_out", h, 1)
+    return _conv(sd, "quant_conv", h, 0)
+
+
+def vae_encoder_layout():
+    """(key prefix, kind, cin, cout) for the encoder half + quant_conv, in execution order."""
+    L = [("encoder.conv_in", "conv3", 3, 128)]
+
+    def res(pre, cin, cout):
+        L.append((pre + ".norm1", "gn", cin, cin))
+        L.append((pre + ".conv1", "conv3", cin, cout))
+        L.append((pre + ".norm2", "gn", cout, cout))
+        L.append((pre + ".conv2", "conv3", cout, cout))
+        if cin != cout:
+            L.append((pre + ".conv_shortcut", "conv1", cin, cout))
+
+    cin = 128
+    for i, cout in enumerate(BLOCK_OUT):
+        for j in range(2):
+            res(f"encoder.down_blocks.{i}.resnets.{j}", cin if j == 0 else cout, cout)
+        if i < 3:
+            L.append((f"encoder.down_blocks.{i}.downsamplers.0.conv", "conv3", cout, cout))
+        cin = cout
+    res("encoder.mid_block.resnets.0", 512, 512)
+    a = "encoder.mid_block.attentions.0"
+    L.append((a + ".group_norm", "gn", 512, 512))
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        L.append((f"{a}.{n}", "linear", 512, 512))
+    res("encoder.mid_block.resnets.1", 512, 512)
+    L.append(("encoder.conv_norm_out", "gn", 512, 512))
+    L.append(("encoder.conv_out", "conv3", 512, 8))
+    L.append(("quant_conv", "conv1", 8, 8))
+    return L
+
+
 def vae_decoder_layout():
     """(key prefix, kind, cin, cout) for every parameterised layer, in execution order."""
     L = [("post_quant_conv", "conv1", LATENT, LATENT), ("decoder.conv_in", "conv3", LATENT, 512)]
@@ -101,14 +156,15 @@ def vae_decoder_layout():
     return L
 
 
-def make_vae_state(seed=0):
-    """Seeded random decoder weights of the sd-vae-ft-mse architecture (no checkpoint on disk).
+def make_vae_state(seed=0, with_encoder=False):
+    """Seeded random weights of the sd-vae-ft-mse architecture (no checkpoint on disk); the encoder half is drawn AFTER the decoder
+    from the same generator, so the decoder weights of a seed do not depend on ``with_encoder``.
 
     Conv/linear weights ~ U(+-sqrt(3/fan_in)) (unit gain), biases N(0,0.02), GN affine 1+N(0,0.1)/N(0,0.1):
     keeps activations O(1) through 30 layers so fp16 paths are exercised without overflow."""
     g = torch.Generator().manual_seed(seed)
     sd = {}
-    for pre, kind, cin, cout in vae_decoder_layout():
+    for pre, kind, cin, cout in vae_decoder_layout() + (vae_encoder_layout() if with_encoder else []):
         if kind == "gn":
             sd[pre + ".weight"] = 1 + 0.1 * torch.randn(cin, generator=g)
             sd[pre + ".bias"] = 0.1 * torch.randn(cin, generator=g)

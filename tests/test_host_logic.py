@@ -282,3 +282,24 @@ def test_apply_without_a_move_keeps_the_packed_operands():
     assert m._packed == "sentinel" and m._gen == gen
     m.double()
     assert m._packed is None and m._gen == gen + 1
+
+
+# ----------------------------------------------------------------------------- training pair (train_flow_latent.py:143-155)
+def test_flow_matching_pair_defines_the_sampled_ode():
+    from lfm_amd.train_flow_latent import SIGMA_MIN, flow_matching_loss, flow_matching_pair
+
+    g = torch.Generator().manual_seed(0)
+    z0, z1 = torch.randn(3, 4, 8, 8, generator=g), torch.randn(3, 4, 8, 8, generator=g)
+    t = torch.tensor([0.0, 0.3, 1.0])
+    zt, u, _ = flow_matching_pair(z0, t, z1)
+    tt = t.view(-1, 1, 1, 1)
+    assert torch.equal(zt, (1 - tt) * z0 + (1e-5 + (1 - 1e-5) * tt) * z1)   # the reference's line, verbatim arithmetic
+    assert torch.equal(u, (1 - 1e-5) * z1 - z0)
+    torch.testing.assert_close(zt[0], z0[0] + SIGMA_MIN * z1[0])            # t = 0: data (+ sigma_min noise)
+    torch.testing.assert_close(zt[2], z1[2])                                # t = 1: noise
+    # d z_t / dt = u: the ODE the samplers integrate from t = 1 to 0 carries z_1 back to z_0 + sigma_min z_1 when v = u
+    eps = 1e-3
+    zt2, _, _ = flow_matching_pair(z0, t + eps, z1)
+    torch.testing.assert_close((zt2 - zt) / eps, u, rtol=1e-2, atol=1e-3)
+    loss = flow_matching_loss(lambda t, x, y: torch.zeros_like(x), z0, generator=torch.Generator().manual_seed(1))
+    assert float(loss) > 0

@@ -98,3 +98,45 @@ def test_decode_shapes_upsampling_and_flops(sd):
     # per-block breakdown of SURVEY.md Appendix B.3 (GFLOP at R = 32): mid resnets 19.3 (each 9.66), conv_in 0.04, conv_out 0.45
     assert abs(2 * 2 * 32 * 32 * 512 * 512 * 9 * 2 / 1e9 - 19.3) < 0.05
     assert abs(2 * 256 * 256 * 128 * 3 * 9 / 1e9 - 0.45) < 0.01
+
+
+# ----------------------------------------------------------------------------- encoder half
+def test_encoder_published_parameter_count_and_keys():
+    sd = vae_ref.make_vae_state(seed=3, with_encoder=True)
+    assert sum(v.numel() for k, v in sd.items() if k.startswith("encoder.")) == 34_163_592
+    assert sum(v.numel() for k, v in sd.items() if k.startswith("quant_conv.")) == 72
+    assert sum(v.numel() for v in sd.values()) == 83_653_863  # the published size of AutoencoderKL(sd-vae-ft-mse)
+    frozen = json.load(open(os.path.join(GOLDEN, "vae_encoder_keys.json")))
+    frozen.update(json.load(open(os.path.join(GOLDEN, "vae_decoder_keys.json"))))
+    assert {k: list(v.shape) for k, v in sd.items()} == frozen
+    from lfm_amd.autoencoder import AutoencoderKL
+
+    assert {k: list(v.shape) for k, v in AutoencoderKL(with_encoder=True).state_dict().items()} == frozen
+    dec_only = AutoencoderKL()
+    dec_only.load_state_dict(sd)  # a full checkpoint loads into the decoder-only module (encoder keys dropped) ...
+    with pytest.raises(Exception):
+        dec_only.encode(torch.zeros(1, 3, 64, 64))  # ... which then refuses to encode (and there is no CPU fallback either)
+
+
+def test_encoder_restatement_identities():
+    sd = vae_ref.make_vae_state(seed=3, with_encoder=True)
+    x = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(4))
+    m = vae_ref.vae_encode_moments(sd, x)
+    assert m.shape == (2, 8, 8, 8) and bool(torch.isfinite(m).all())
+    # Downsample2D with padding 0: pad right/bottom by one, stride 2 => out[y, x] sees in[2y .. 2y+2, 2x .. 2x+2]
+    w = torch.zeros(1, 1, 3, 3)
+    w[0, 0, 2, 2] = 1.0  # picks in[2y+2, 2x+2], i.e. the zero pad on the last row / column
+    img = torch.arange(36.0).reshape(1, 1, 6, 6)
+    d = vae_ref.downsample({"c.weight": w, "c.bias": torch.zeros(1)}, "c", img)
+    assert d.shape == (1, 1, 3, 3)
+    assert d[0, 0].tolist() == [[14.0, 16.0, 0.0], [26.0, 28.0, 0.0], [0.0, 0.0, 0.0]]
+    # the latent distribution object of the product (host code): clamp, std, sample with a generator, mode
+    from lfm_amd.autoencoder import DiagonalGaussianDistribution
+
+    mom = torch.cat([torch.full((1, 4, 2, 2), 0.5), torch.tensor([-40.0, 0.0, 2.0, 30.0]).reshape(1, 4, 1, 1).expand(1, 4, 2, 2)], 1)
+    dist = DiagonalGaussianDistribution(mom)
+    assert dist.logvar[0, :, 0, 0].tolist() == [-30.0, 0.0, 2.0, 20.0]
+    g = torch.Generator().manual_seed(0)
+    want = 0.5 + torch.exp(0.5 * dist.logvar) * torch.randn(1, 4, 2, 2, generator=torch.Generator().manual_seed(0))
+    torch.testing.assert_close(dist.sample(generator=g), want)
+    assert torch.equal(dist.mode(), dist.mean)
