@@ -1,14 +1,20 @@
 """Headline benchmark: images/sec of the LFM sampling hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): DiT-L/2 on 4x32x32 f8 latents (256x256 images), batch 64 per GPU, 50 Euler NFE on
+Default workload (BASELINE.json configs[1]): DiT-L/2 on 4x32x32 f8 latents (256x256 images), batch 64 per GPU, 50 Euler NFE on
 the torchdiffeq grid (step_size 0.02, the path the reference actually runs) + f8 VAE decode + uint8 NHWC conversion.
-Synthetic data: seeded random-init weights of the real architectures (de-zeroed), seeded Gaussian latents resident in HBM.
+Synthetic data: seeded random-init weights of the real architectures (de-zeroed), seeded Gaussian latents; one "step" = one full batch
+through the hot path, INCLUDING the host-to-device copy of its latents (64 x 16 KiB from pinned memory) -- everything else is resident.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One "step" = one full batch through the hot path.  Ranks shard batches (weak scaling, no data-path collective during the
-solve); with N > 1 every batch ends with one RCCL all_gather_into_tensor of the uint8 images.
+--config selects another BASELINE.json configuration (same JSON contract, its own `roofline`):
+  3  DiT-L/2 class-conditional, dopri5 rtol = atol = 1e-5, CFG 1.5, 64 live + 64 null rows, + decode
+  4  DiT-B/2 imnet class-conditional, CFG 1.5, batch 256 (+256 null), 50-point Karras grid Heun with the reference's steps=40 quirk (88 NFE), + decode
+  5  origin-ADM celeb512 (352 M parameters), batch 32, 64x64 latents, 50-step Euler + VAE decode at 512x512
+
+Ranks shard batches (weak scaling, no data-path collective during the solve); with N > 1 every batch ends with one RCCL
+all_gather_into_tensor of the uint8 images, issued on a side stream so that it overlaps the next batch's solve.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -25,14 +31,21 @@ sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense fp16/bf16 (MI355X_MICROARCH.md)
 
+# L2-miss traffic of the dominant GEMM of config 2 (fc1 + GELU, M 16384 x N 4096 x K 1024) per launch, from separate rocprofv3 PMC
+# passes of the shipped kernel: FETCH_SIZE x 2 (gfx950 correction for 16-B-per-lane streams, MI355X_MICROARCH.md) + WRITE_SIZE, KiB.
+# These are fabric-side request counters: Infinity-Cache hits are INCLUDED (the whole working set of this GEMM fits the 256 MiB cache),
+# so this is an upper bound on HBM bytes, not HBM bytes.  Source file named in `traffic_source`.
+FC1_TRAFFIC = {"fetch_kib": 100694.4, "write_kib": 135168.0, "source": "profiles/r02_gemm_pmc.txt (fc1_fetch / fc1_write passes)"}
+
 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=3)
     p.add_argument("--warmup", type=int, default=1)
-    p.add_argument("--batch", type=int, default=64, help="images per GPU per step")
-    p.add_argument("--model", type=str, default="DiT-L/2")
+    p.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5])
+    p.add_argument("--batch", type=int, default=0, help="images per GPU per step (0 = the configuration's own)")
+    p.add_argument("--model", type=str, default="", help="override the DiT of configs 2-4")
     p.add_argument("--nfe", type=int, default=50)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
@@ -52,8 +65,8 @@ def usable_cores():
 
 
 def cpu_baseline(model_name, nfe, budget_s=25.0):
-    """The oracle (CPU restatement of the reference path, fp32 torch) timed on the host cores on a BOUNDED sample: a few
-    velocity evaluations of the DiT at N=2 plus one VAE decode of one image, scaled to `nfe` evaluations + decode per image."""
+    """The oracle (CPU restatement of the reference path, fp32 torch) timed on the host cores on a BOUNDED sample: a few velocity
+    evaluations of the DiT at N=2 plus VAE decodes of one image (1 warm-up + 3 timed), scaled to `nfe` evaluations + decode per image."""
     from oracle import dit_ref, vae_ref
 
     threads = min(usable_cores(), 32)  # torch-CPU GEMMs of this size stop scaling (and oversubscribe) beyond ~32 threads
@@ -76,13 +89,168 @@ def cpu_baseline(model_name, nfe, budget_s=25.0):
     R = 32 if first < budget_s / 6 else 16
     z = torch.randn(1, 4, R, R, generator=torch.Generator().manual_seed(1))
     t0 = time.perf_counter()
-    vae_ref.vae_decode(vsd, z)
-    t_dec = (time.perf_counter() - t0) * (32 // R) ** 2
+    vae_ref.vae_decode(vsd, z)  # warm-up (thread pool, oneDNN primitive caches)
+    warm = time.perf_counter() - t0
+    vreps = 3 if warm < budget_s / 9 else 1
+    t0 = time.perf_counter()
+    for _ in range(vreps):
+        vae_ref.vae_decode(vsd, z)
+    t_dec = (time.perf_counter() - t0) / vreps * (32 // R) ** 2
     ips = 1.0 / (nfe * t_eval + t_dec)
     return {"value": ips, "unit": "images/sec", "cores": threads, "kind": "port",
             "sample": f"oracle (fp32 torch-CPU restatement of the reference path), {threads} threads: {max(reps, 1)} {model_name} velocity "
-                      f"evals at N=2 ({t_eval:.3f} s/img/eval) + 1 VAE decode at {8 * R}x{8 * R} ({t_dec:.2f} s/img at 256x256), scaled to "
-                      f"{nfe} NFE + decode per image"}
+                      f"evals at N=2 after a warm-up ({t_eval:.3f} s/img/eval) + {vreps} VAE decodes at {8 * R}x{8 * R} after a warm-up "
+                      f"({t_dec:.2f} s/img at 256x256), scaled to {nfe} NFE + decode per image"}
+
+
+# ------------------------------------------------------------------------------------------------ workloads
+def build_workload(a, dev, rank):
+    """Returns dict(step_fn(x_dev) -> fp32 images, x_host (pinned), B, res, workload, flop_per_image, model, solve_fn, extra)."""
+    from lfm_amd.autoencoder import AutoencoderKL
+    from lfm_amd.models import DiT_models, create_network
+    from lfm_amd.solvers import GraphedFixedGrid, odeint, torchdiffeq_euler_grid
+    from lfm_amd.test_flow_latent import dezero_
+    from oracle import dit_ref, vae_ref  # FLOP closed forms only
+
+    vae = AutoencoderKL.from_random(seed=0).to(dev)
+    g = torch.Generator().manual_seed(42 + rank)
+    if a.config == 2:
+        name = a.model or "DiT-L/2"
+        B = a.batch or 64
+        torch.manual_seed(0)
+        model = dezero_(DiT_models[name](img_resolution=32, in_channels=4, label_dropout=0.0, num_classes=1)).to(dev).eval()
+        ts, dts = torchdiffeq_euler_grid(1.0 / a.nfe)
+        assert dts.numel() == a.nfe
+        solver = GraphedFixedGrid(model, B)
+        solver.set_grid(ts, dts)
+        solve = lambda x: solver.run(x)  # noqa: E731
+        f_model = a.nfe * dit_ref.dit_flops_per_image(dit_ref.DiTCfg.named(name, num_classes=1, label_dropout=0.0))
+        wl = f"{name} celeb256 f8 (4x32x32 latents), batch {B}/GPU, {a.nfe}-step Euler (torchdiffeq grid) + f8 VAE decode to 256x256 + uint8 NHWC"
+        x_shape, res, extra = (B, 4, 32, 32), 32, {"nfe": a.nfe}
+    elif a.config in (3, 4):
+        name = a.model or ("DiT-L/2" if a.config == 3 else "DiT-B/2")
+        B = a.batch or (64 if a.config == 3 else 256)
+        torch.manual_seed(0)
+        model = dezero_(DiT_models[name](img_resolution=32, in_channels=4, label_dropout=0.1, num_classes=1000)).to(dev).eval()
+        y = torch.cat([torch.randint(0, 1000, (B,), generator=g), torch.full((B,), 1000)]).to(dev)
+        per_eval = 2 * dit_ref.dit_flops_per_image(dit_ref.DiTCfg.named(name, num_classes=1000, label_dropout=0.1))  # CFG: 2 rows per image
+        extra = {}
+        if a.config == 3:
+            stats = {}
+
+            def solve(x):
+                stats.clear()
+                xx = torch.cat([x, x], 0)
+                return odeint(lambda t, v: model.forward_with_cfg(t, v, y, cfg_scale=1.5), xx, torch.tensor([1.0, 0.0], device=dev), method="dopri5",
+                              rtol=1e-5, atol=1e-5, stats=stats)[-1][:B]
+
+            extra["solver_stats"] = stats
+            f_model = None  # NFE is data dependent: filled in after the run
+            wl = f"{name} class-conditional, dopri5 rtol=atol=1e-5, CFG 1.5, batch {B}(+{B} null)/GPU + f8 VAE decode + uint8"
+        else:
+            from lfm_amd.sampler.karras_sample import karras_sample
+
+            def solve(x):
+                xx = torch.cat([x, x], 0)
+                return karras_sample(model, xx, steps=50, model_kwargs=dict(y=y, cfg_scale=1.5), device=dev, clip_denoised=False, sigma_min=1e-5,
+                                     sigma_max=1.0, s_tmin=0.0, s_tmax=1.0, s_churn=0.0, sampler="heun")[:B]
+
+            f_model = 88 * per_eval
+            extra["nfe"] = 88
+            wl = (f"{name} imnet class-conditional, CFG 1.5, batch {B}(+{B} null)/GPU, 50-point Karras grid Heun with the reference's steps=40 quirk "
+                  "(88 NFE) + f8 VAE decode + uint8")
+        extra["per_eval_flop"] = per_eval
+        x_shape, res = (B, 4, 32, 32), 32
+    else:
+        from argparse import Namespace
+
+        B = a.batch or 32
+        cfg = Namespace(use_origin_adm=True, layout=False, model_type="adm", image_size=512, f=8, num_in_channels=4, num_out_channels=4, nf=256,
+                        num_res_blocks=2, attn_resolutions=(16, 8), dropout=0.0, ch_mult=(1, 2, 2, 2, 4), resamp_with_conv=True, num_classes=None,
+                        num_heads=4, num_head_channels=-1, num_head_upsample=-1)
+        torch.manual_seed(0)
+        model = dezero_(create_network(cfg)).to(dev).eval()
+        ts, dts = torchdiffeq_euler_grid(1.0 / a.nfe)
+        solver = GraphedFixedGrid(model, B, resolution=64)
+        solver.set_grid(ts, dts)
+        solve = lambda x: solver.run(x)  # noqa: E731
+        f_model = a.nfe * 189.7e9  # hook-counted on the reference module (SURVEY.md §8d)
+        wl = f"origin-ADM celeb512 (352 M params), 4x64x64 latents, batch {B}/GPU, {a.nfe}-step Euler + f8 VAE decode to 512x512 + uint8 NHWC"
+        x_shape, res, extra = (B, 4, 64, 64), 64, {"nfe": a.nfe}
+    x_host = torch.randn(*x_shape, generator=g).pin_memory()
+    return dict(model=model, vae=vae, solve=solve, B=B, res=res, x_host=x_host, workload=wl, f_model=f_model, f_vae=vae_ref.vae_decode_flops(res),
+                extra=extra, name=(a.model or {2: "DiT-L/2", 3: "DiT-L/2", 4: "DiT-B/2", 5: "ADM-celeb512"}[a.config]))
+
+
+def roofline_dit(model, lat, rows, dev):
+    """Dominant kernel of the DiT configurations: the fc1 MFMA GEMM + GELU epilogue (gemm256q_tn_kernel<ASrcRowMajor, EpiBiasGeluF16>).
+    Timed LIVE and IN SITU: eager forwards of the real model on the solver's latents with one HIP event pair recorded around every
+    block's fc1 launch on the launching stream (lfm_profile_fc1; a captured graph cannot be bracketed)."""
+    import ctypes as C
+
+    from lfm_amd import hip
+
+    D, H, M = model.hidden_size, model.mlp_hidden, rows * 256
+    L = hip.lib()
+    tmid = torch.tensor(0.5, device=dev)
+    x = lat if lat.shape[0] == rows else torch.cat([lat, lat], 0)[:rows]
+    y = None
+    if model.num_classes and model.num_classes > 1:
+        y = torch.zeros(rows, dtype=torch.long, device=dev)
+    model(tmid, x, y)  # warm
+    durs = []
+    for _ in range(3):
+        hip.check(L.lfm_profile_fc1(1), "lfm_profile_fc1")
+        model(tmid, x, y)
+        buf = (C.c_float * 64)()
+        n = L.lfm_profile_fc1_read(buf, 64)
+        durs += [buf[i] for i in range(n)]
+    L.lfm_profile_fc1(0)
+    dur = sum(durs) / len(durs) * 1e-3
+    ach = 2.0 * M * H * D / dur / 1e12
+    r = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
+         "algorithmic_bytes": 2.0 * (M * D + H * D + M * H), "algorithmic_flop": 2.0 * M * H * D,
+         "kernel": "gemm256q_tn_kernel<ASrcRowMajor,EpiBiasGeluF16> (DiT fc1 + GELU)", "shape": {"M": M, "N": H, "K": D}, "avg_launch_us": dur * 1e6,
+         "launches_timed": len(durs)}
+    if (M, H, D) == (16384, 4096, 1024):
+        r["traffic"] = (2 * FC1_TRAFFIC["fetch_kib"] + FC1_TRAFFIC["write_kib"]) * 1024
+        r["traffic_unit"] = "bytes/launch leaving the L2s (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes); Infinity-Cache hits included, so an upper bound on HBM bytes"
+        r["traffic_source"] = FC1_TRAFFIC["source"]
+    return r
+
+
+def roofline_adm(B, dev):
+    """Dominant kernel of config 5: the 3x3 implicit-GEMM convolution of the 64x64, 256-channel ResBlocks (M = B*4096 pixels, N = 256, K = 2304;
+    8 of them per evaluation plus the 512-input ones of the up path).  Timed live with HIP events on the launching stream, standalone on
+    random NHWC activations of the real shape."""
+    from lfm_amd import hip
+
+    N, H, W, Cin, Cout = B, 64, 64, 256, 256
+    x = (torch.randn(N * H * W, Cin, device=dev) * 0.5).half()
+    w = (torch.randn(Cout, 9 * Cin, device=dev) * 0.02).half()
+    b = torch.zeros(Cout, device=dev)
+    out = torch.empty(N * H * W, Cout, device=dev, dtype=torch.float16)
+    L = hip.lib()
+    st = torch.cuda.current_stream(dev)
+
+    def run():
+        hip.check(L.lfm_conv3x3_f16(hip.ptr(x), hip.ptr(w), hip.ptr(b), None, hip.ptr(out), N, H, W, Cin, Cout, 0, hip.stream_ptr(dev)), "conv")
+
+    for _ in range(3):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(10):
+        run()
+    e1.record(st)
+    torch.cuda.synchronize()
+    dur = e0.elapsed_time(e1) / 10 * 1e-3
+    M, K = N * H * W, 9 * Cin
+    ach = 2.0 * M * Cout * K / dur / 1e12
+    return {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
+            "algorithmic_bytes": 2.0 * (M * Cin + Cout * K + M * Cout), "algorithmic_flop": 2.0 * M * Cout * K,
+            "kernel": "gemm256q_tn_kernel<ASrcConv<0>,EpiResidF16> (3x3 conv 256->256 at 64x64, implicit GEMM)", "shape": {"M": M, "N": Cout, "K": K},
+            "avg_launch_us": dur * 1e6, "launches_timed": 10}
 
 
 def main():
@@ -100,34 +268,29 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
-    from lfm_amd import hip
-    from lfm_amd.autoencoder import AutoencoderKL, images_to_uint8
-    from lfm_amd.models import DiT_models
-    from lfm_amd.solvers import GraphedFixedGrid, torchdiffeq_euler_grid
-    from lfm_amd.test_flow_latent import dezero_
+    from lfm_amd.autoencoder import images_to_uint8
+    from lfm_amd.test_flow_latent_ddp import GatherPipeline
 
-    # ---- models (celeb256_dit.txt: --num_classes 1 --label_dropout 0.)
-    torch.manual_seed(0)
-    model = dezero_(DiT_models[a.model](img_resolution=32, in_channels=4, label_dropout=0.0, num_classes=1)).to(dev).eval()
-    vae = AutoencoderKL.from_random(seed=0).to(dev)
-    B = a.batch
-    h = 1.0 / a.nfe
-    ts, dts = torchdiffeq_euler_grid(h)
-    assert dts.numel() == a.nfe
-    solver = GraphedFixedGrid(model, B)
-    solver.set_grid(ts, dts)
-    x0 = torch.randn(B, 4, 32, 32, generator=torch.Generator().manual_seed(42 + rank)).to(dev)  # resident in HBM
-    gathered = torch.empty(world * B, 256, 256, 3, dtype=torch.uint8, device=dev) if world > 1 else None
+    w = build_workload(a, dev, rank)
+    B, vae, solve = w["B"], w["vae"], w["solve"]
+    S = 8 * w["res"]
+    x_dev = torch.empty(w["x_host"].shape, device=dev)
+    pipe = GatherPipeline(world, dev)
+    gather_ms = []
 
     def step():
-        lat = solver.run(x0)
+        x_dev.copy_(w["x_host"], non_blocking=True)  # the batch's latents cross PCIe inside the timed region (1 MiB at batch 64)
+        lat = solve(x_dev)
         img = vae.decode(lat / 0.18215).sample
         u8 = images_to_uint8(img)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, u8)
+            t0 = time.perf_counter()
+            pipe.submit(u8)  # the collective runs on a side stream under the next batch's solve
+            gather_ms.append((time.perf_counter() - t0) * 1e3)
         return u8
 
     def fence():
+        pipe.flush()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -136,29 +299,39 @@ def main():
     for _ in range(max(a.warmup, 0)):
         step()
     fence()
+    gather_ms.clear()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = step()
     fence()
-    el = time.perf_counter() - t0
+    el_local = time.perf_counter() - t0
+    el = el_local
+    rank_ips = [B * a.steps / el_local]
     if world > 1:
-        tt = torch.tensor([el], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt)
-    assert out.shape == (B, 256, 256, 3) and float(out[:4].float().std()) > 0
+        tt = torch.tensor([el_local], device=dev, dtype=torch.float64)
+        allt = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(allt, tt)
+        el = max(float(t) for t in allt)
+        rank_ips = [B * a.steps / float(t) for t in allt]
+    assert out.shape == (B, S, S, 3) and float(out[:4].float().std()) > 0
     ips = world * B * a.steps / el
 
-    from oracle import dit_ref, vae_ref  # FLOP closed forms only
-
-    f_img = a.nfe * dit_ref.dit_flops_per_image(dit_ref.DiTCfg.named(a.model, num_classes=1, label_dropout=0.0)) + vae_ref.vae_decode_flops(32)
-
+    f_model = w["f_model"]
+    if f_model is None:  # dopri5: NFE of the last solve
+        f_model = w["extra"]["solver_stats"]["nfe"] * w["extra"]["per_eval_flop"]
+    f_img = f_model + w["f_vae"]
+    cfg = {"workload": w["workload"] + (" + RCCL all-gather of images (side stream)" if world > 1 else ""), "baseline_config": a.config,
+           "per_gpu_batch": B, "global_batch": B * world, "sharding": f"dp{world}", "h2d_of_latents": "inside the timed step"}
+    cfg.update({k: v for k, v in w["extra"].items() if k in ("nfe",)})
+    if "solver_stats" in w["extra"]:
+        cfg["dopri5"] = dict(w["extra"]["solver_stats"])
     res = {
         "metric": "images/sec", "value": ips, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * el / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
-        "data": "synthetic",
-        "config": {"workload": f"{a.model} celeb256 f8 (4x32x32 latents), batch {B}/GPU, {a.nfe}-step Euler (torchdiffeq grid) + f8 VAE decode "
-                               f"to 256x256 + uint8 NHWC" + (" + RCCL all-gather of images" if world > 1 else ""),
-                   "per_gpu_batch": B, "global_batch": B * world, "nfe": a.nfe, "sharding": f"dp{world}"},
+        "data": "synthetic", "config": cfg,
+        "rccl_world": dist.get_world_size() if world > 1 else 1,
+        "per_rank_images_per_sec": {"min": min(rank_ips), "max": max(rank_ips)},
+        "allgather_host_ms_per_batch": (sum(gather_ms) / len(gather_ms)) if gather_ms else 0.0,
         "algorithmic_gflop_per_image": f_img / 1e9,
         "mfma_frac_whole_path": ips * f_img / (MFMA_PEAK_TFLOPS * 1e12 * world),
     }
@@ -166,7 +339,7 @@ def main():
     # split of one step (outside the timed region): solver-only and decode-only
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     ev[0].record()
-    lat = solver.run(x0)
+    lat = solve(x_dev)
     ev[1].record()
     images_to_uint8(vae.decode(lat / 0.18215).sample)
     ev[2].record()
@@ -174,36 +347,12 @@ def main():
     res["split_ms"] = {"solver": ev[0].elapsed_time(ev[1]), "vae_decode_u8": ev[1].elapsed_time(ev[2])}
 
     if rank == 0 and not a.no_roofline:
-        # dominant kernel: the fc1 MFMA GEMM + GELU epilogue (gemm256q_tn_kernel<ASrcRowMajor, EpiBiasGeluF16>, 25 % of the step).
-        # Timed LIVE and IN SITU: eager forwards of the real model on the solver's latents with one HIP event pair recorded
-        # around every block's fc1 launch on the launching stream (lfm_profile_fc1; a captured graph cannot be bracketed).
-        import ctypes as C
-
-        D, H, M = model.hidden_size, model.mlp_hidden, B * 256
-        L = hip.lib()
-        tmid = torch.tensor(0.5, device=dev)
-        model(tmid, lat)  # warm
-        durs = []
-        for _ in range(3):
-            hip.check(L.lfm_profile_fc1(1), "lfm_profile_fc1")
-            model(tmid, lat)
-            buf = (C.c_float * 64)()
-            n = L.lfm_profile_fc1_read(buf, 64)
-            durs += [buf[i] for i in range(n)]
-        L.lfm_profile_fc1(0)
-        dur = sum(durs) / len(durs) * 1e-3
-        ach = 2.0 * M * H * D / dur / 1e12
-        # HBM traffic per launch from PMC (profiles/r01_e_gemm_pmc.txt, separate FETCH_SIZE / WRITE_SIZE passes): FETCH_SIZE
-        # 100694.4 KB raw -> x2 (gfx950 correction of MI355X_MICROARCH.md for 16-B-per-lane streams) + WRITE_SIZE 135168 KB;
-        # measured at this shape on the shipped kernel.
-        traffic = (2 * 100694.4 + 135168.0) * 1024 if (M, H, D) == (16384, 4096, 1024) else None
-        res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
-                           "traffic": traffic, "traffic_unit": "bytes/launch (HBM, rocprofv3 PMC, separate passes)",
-                           "algorithmic_bytes": 2.0 * (M * D + H * D + M * H), "algorithmic_flop": 2.0 * M * H * D,
-                           "kernel": "gemm256q_tn_kernel<ASrcRowMajor,EpiBiasGeluF16> (DiT fc1 + GELU)",
-                           "shape": {"M": M, "N": H, "K": D}, "avg_launch_us": dur * 1e6, "launches_timed": len(durs)}
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(a.model, a.nfe)
+        if a.config == 5:
+            res["roofline"] = roofline_adm(B, dev)
+        else:
+            res["roofline"] = roofline_dit(w["model"], lat, B if a.config == 2 else 2 * B, dev)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.config == 2:
+        res["cpu_baseline"] = cpu_baseline(w["name"], a.nfe)
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -15,7 +15,7 @@ import torch.distributed as dist
 from .sampler.random_util import get_generator
 from .test_flow_latent import build_models, build_parser, run_sampling, save_images_uint8
 
-__all__ = ["shard_plan", "gather_images", "interleave_ranks", "global_indices", "main"]
+__all__ = ["shard_plan", "gather_images", "interleave_ranks", "global_indices", "GatherPipeline", "run", "main"]
 
 
 def shard_plan(n_sample, batch_size, world_size):
@@ -50,39 +50,107 @@ def gather_images(img_u8, world_size, out=None):
     return interleave_ranks(out, world_size)
 
 
-def main(argv=None):
+class GatherPipeline:
+    """One ``all_gather_into_tensor`` of the uint8 image block per batch, issued on a SIDE stream so that the next batch's solve
+    overlaps the collective and the device-to-host copy of the previous one: two gather buffers alternate; ``submit``
+    returns the PREVIOUS batch's gathered, reference-ordered block (or None), ``flush`` the last one.  On a CPU / gloo group (the
+    world-2 rehearsal in tests/) it degrades to the plain blocking collective."""
+
+    def __init__(self, world, device):
+        self.world, self.device = world, torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        self.side = torch.cuda.Stream(self.device) if self.cuda and world > 1 else None
+        self.bufs, self.k, self.pending = [None, None], 0, None
+        self.gather_seconds = 0.0
+
+    def _gather(self, u8):
+        import time
+
+        k = self.k
+        self.k ^= 1
+        if self.world == 1:
+            return u8
+        if self.bufs[k] is None or self.bufs[k].shape[0] != self.world * u8.shape[0]:
+            self.bufs[k] = torch.empty(self.world * u8.shape[0], *u8.shape[1:], dtype=u8.dtype, device=u8.device)
+        if self.side is None:
+            t0 = time.perf_counter()
+            dist.all_gather_into_tensor(self.bufs[k], u8.contiguous())
+            self.gather_seconds += time.perf_counter() - t0
+            return interleave_ranks(self.bufs[k], self.world)
+        self.side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.side):
+            u8.record_stream(self.side)
+            dist.all_gather_into_tensor(self.bufs[k], u8.contiguous())
+            out = interleave_ranks(self.bufs[k], self.world)
+            done = torch.cuda.Event()
+            done.record(self.side)
+        return out, done
+
+    def submit(self, u8):
+        prev = self.flush()
+        self.pending = self._gather(u8)
+        return prev
+
+    def flush(self):
+        p, self.pending = self.pending, None
+        if isinstance(p, tuple):
+            p[1].synchronize()
+            return p[0]
+        return p
+
+
+def run(args, model, vae, generator, rank, world, device, to_uint8, save=None, log=print):
+    """The reference's sampling loop (test_flow_latent_ddp.py:116-146) for one rank: ``iters`` batches, each solved and decoded
+    locally, converted to uint8 on the device, all-gathered (overlapped with the next batch) and -- on rank 0 under --compute_fid --
+    written out under the reference's global file indices ``j*world + rank + total`` (:138).  Returns what was done, for tests."""
+    total, _, iters = shard_plan(args.n_sample, args.batch_size, world)
+    if rank == 0:
+        log(f"Total number of images that will be sampled: {total}")
+    pipe = GatherPipeline(world, device)
+    written = []
+
+    def sink(block, i):
+        if block is not None and rank == 0 and args.compute_fid and save is not None:
+            save(block, i * args.batch_size * world)
+            written.append((i * args.batch_size * world, int(block.shape[0])))
+
+    for i in range(iters):
+        img = run_sampling(model, vae, args, args.batch_size, generator, device)
+        sink(pipe.submit(to_uint8(img)), i - 1)
+    sink(pipe.flush(), iters - 1)
+    return {"total": total, "iters": iters, "written": written, "gather_seconds": pipe.gather_seconds}
+
+
+def main(argv=None, hooks=None):
+    """torchrun entry point.  ``hooks`` (tests only) replaces the device-bound pieces for the CPU / gloo rehearsal of the multi-rank
+    control flow: {"backend", "device", "build_models", "to_uint8", "save"}; the product path (hooks=None) is RCCL + HIP only."""
     from .autoencoder import images_to_uint8
 
+    hooks = hooks or {}
     parser = build_parser()
     args = parser.parse_args(argv)
     torch.set_grad_enabled(False)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    device = torch.device(f"cuda:{local_rank}")
-    torch.cuda.set_device(device)
-    dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
+    device = torch.device(hooks.get("device") or f"cuda:{local_rank}")
+    if device.type == "cuda":
+        torch.cuda.set_device(device)
+        dist.init_process_group(hooks.get("backend", "nccl"), device_id=device)  # "nccl" is RCCL on ROCm
+    else:
+        dist.init_process_group(hooks["backend"])
     rank, world = dist.get_rank(), dist.get_world_size()
-    model, vae = build_models(args, device)  # un-offset seed: --random_weights must give every rank the SAME synthetic model
+    model, vae = hooks.get("build_models", build_models)(args, device)  # un-offset seed: --random_weights gives every rank the SAME model
     args.seed = args.seed + rank  # reference :30 (rank-local noise / label stream)
     generator = get_generator(args.generator, args.n_sample, args.seed)
-    total, _, iters = shard_plan(args.n_sample, args.batch_size, world)
     save_dir = args.save_dir or "./generated_samples/{}/exp{}_ep{}_m{}".format(args.dataset, args.exp, args.epoch_id, args.method)
-    if rank == 0:
-        print(f"Total number of images that will be sampled: {total}")
-    buf = None
-    for i in range(iters):
-        img = run_sampling(model, vae, args, args.batch_size, generator, device)
-        u8 = images_to_uint8(img)
-        if buf is None:
-            buf = torch.empty(world * u8.shape[0], *u8.shape[1:], dtype=u8.dtype, device=device)
-        allimg = gather_images(u8, world, out=buf)
-        if rank == 0 and args.compute_fid:
-            save_images_uint8(allimg, save_dir, i * args.batch_size * world)
+    save = hooks.get("save") or (lambda block, start: save_images_uint8(block, save_dir, start))
+    res = run(args, model, vae, generator, rank, world, device, hooks.get("to_uint8", images_to_uint8), save)
     dist.barrier()
     if rank == 0:
-        print(f"sampled {total} images on {world} GPUs" + (f" -> {save_dir}" if args.compute_fid else ""))
+        print(f"sampled {res['total']} images on {world} GPUs" + (f" -> {save_dir}" if args.compute_fid else ""))
     if dist.is_initialized():
         dist.destroy_process_group()
+    return res
 
 
 if __name__ == "__main__":

@@ -65,3 +65,80 @@ def test_interleave_is_a_permutation():
     out = interleave_ranks(g, 4).flatten().tolist()
     assert sorted(out) == list(range(20))
     assert out[:4] == [0, 5, 10, 15]  # image 0 of ranks 0..3 first
+
+
+# ----------------------------------------------------------------------------- the DDP driver end to end (world 2, gloo, stub networks)
+class _StubModel(torch.nn.Module):
+    """v(t, x) = -x: the Euler solve of 4 steps multiplies the noise by (1 - 0.25)^4... any deterministic field will do."""
+
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.zeros(1))
+
+    def forward(self, t, x, y=None, **kw):
+        return -x + 0.1 * torch.as_tensor(t, dtype=x.dtype).reshape(-1, *([1] * (x.dim() - 1)))[:1]
+
+
+class _StubVae:
+    def decode(self, z):
+        img = torch.tanh(z[:, :3].repeat_interleave(2, -1).repeat_interleave(2, -2))  # [N,3,2R,2R] in (-1, 1)
+        return type("O", (), {"sample": img})()
+
+
+def _ddp_worker(rank, world, port, q, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from lfm_amd import test_flow_latent_ddp as ddp
+    from lfm_amd.io_formats import to_uint8_truncating
+
+    saved = []
+    hooks = dict(backend="gloo", device="cpu", build_models=lambda a, d: (_StubModel().eval(), _StubVae()), to_uint8=to_uint8_truncating,
+                 save=lambda block, start: saved.append((start, block.clone())))
+    argv = ["--model_type", "DiT-S/2", "--image_size", "32", "--num_in_channels", "4", "--n_sample", "10", "--batch_size", "3", "--method", "euler",
+            "--step_size", "0.25", "--generator", "determ", "--seed", "7", "--compute_fid", "--save_dir", outdir]
+    res = ddp.main(argv, hooks=hooks)
+    q.put((rank, res["total"], res["iters"], res["written"], [(s, tuple(b.shape), b.numpy().tobytes()) for s, b in saved]))  # plain bytes: the
+    # producer exits right after the put, tensors would travel as shared-memory handles that die with it
+
+
+def test_world2_ddp_main_end_to_end(tmp_path):
+    """Drives lfm_amd.test_flow_latent_ddp.main with stub networks on a 2-rank gloo group: loop count, gather buffer reuse across
+    iterations (two alternating buffers), file indices j*world + rank + total (reference :138), rank-local seeds (seed + rank, :30) with the
+    determ generator's rank slicing, and rank 0 as the only writer."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, total, iters, written, saved), (r1, total1, iters1, written1, saved1) = res
+    assert (total, iters) == (12, 2) and (total1, iters1) == (12, 2)
+    assert written == [(0, 6), (6, 6)] and written1 == [] and saved1 == []
+    # recompute what every rank must have produced: rank r draws with seed 7 + r and takes rows r, r + 2, r + 4 of each global draw
+    from lfm_amd.io_formats import to_uint8_truncating
+    from lfm_amd.sampler.random_util import DeterministicGenerator
+
+    def rank_batches(r):
+        gen = DeterministicGenerator(10, 7 + r)
+        gen.rank, gen.world_size = r, world
+        outs = []
+        for _ in range(2):
+            x = gen.randn(3, 4, 4, 4)
+            for k in range(4):
+                t = 1.0 - 0.25 * k
+                x = x + (-0.25) * (-x + 0.1 * t)
+            outs.append(to_uint8_truncating(_StubVae().decode(x / 0.18215).sample))  # run_sampling divides by --scale_factor
+        return outs
+
+    want = [rank_batches(0), rank_batches(1)]
+    assert len(saved) == 2
+    for it, (start, shape, raw) in enumerate(saved):
+        block = torch.frombuffer(bytearray(raw), dtype=torch.uint8).reshape(shape)
+        assert start == it * 6 and block.shape == (6, 8, 8, 3)
+        for j in range(3):
+            for r in range(world):  # global index j*world + r + start  ->  position j*world + r of the gathered block
+                assert torch.equal(block[j * world + r], want[r][it][j]), (it, j, r)
