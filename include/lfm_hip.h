@@ -202,6 +202,11 @@ int lfm_images_to_uint8_mode(const float* x, uint8_t* out, int N, int H, int W, 
  *   the fly (Upsample, :73-100);  mode 2: in is [N,2H,2W,Cin], stride 2 (Downsample, :103-128). */
 int lfm_conv3x3_f16(const void* in, const void* w, const float* bias, const void* resid, void* out, int N, int H, int W, int Cin, int Cout,
                     int mode, lfm_stream_t stream);
+/* The same with a caller-owned workspace of lfm_conv3x3_workspace_bytes(...) bytes (0 = none needed): small-M / huge-K convolutions (the
+ * low-resolution levels of the UNets) then run split-K with a deterministic slab reduction.  workspace may be NULL. */
+size_t lfm_conv3x3_workspace_bytes(int N, int H, int W, int Cin, int Cout);
+int lfm_conv3x3_f16_ws(const void* in, const void* w, const float* bias, const void* resid, void* out, int N, int H, int W, int Cin, int Cout,
+                       int mode, void* workspace, size_t workspace_bytes, lfm_stream_t stream);
 /* first conv (unet.py:475): fp32 NCHW [N,Cin<=16,H,W] -> fp16 NHWC [N,H,W,Cout]; w fp32 [Cout,Cin,3,3] */
 int lfm_conv3x3_in_f32(const float* x_nchw, const float* w, const float* bias, void* out_nhwc, int N, int H, int W, int Cin, int Cout,
                        lfm_stream_t stream);

@@ -418,19 +418,26 @@ static inline int splitk_slices(int M, int N, int K, size_t slab_bytes) {
   return s;
 }
 
-// returns LFM_OK after launching both kernels, or 1 if split-K does not apply (the caller then takes the ordinary path)
-template <class Epi>
-static inline int launch_gemm_splitk(const half_t* A, long lda, const half_t* W, long ldw, int M, int N, int K, const Epi& epi, float* slab,
-                                     size_t slab_bytes, hipStream_t stream) {
+// returns LFM_OK after launching both kernels, or 1 if split-K does not apply (the caller then takes the ordinary path).
+// Slices are addressed through the batch index: asrc.init(bz, ks) makes slice bz start at k = bz * ks (row-major A advances its
+// pointer; an implicit-GEMM convolution source starts its tap / channel walk there), W advances by ks columns.
+template <class ASrc, class Epi>
+static inline int launch_gemm_splitk_src(const ASrc& asrc, const half_t* W, long ldw, int M, int N, int K, const Epi& epi, float* slab,
+                                         size_t slab_bytes, hipStream_t stream) {
   if (!slab || lfm_gemm_selected_v1_ok() == 0) return 1;
   const int S = splitk_slices(M, N, K, slab_bytes);
   if (S < 2) return 1;
   const int ks = K / S;
   const long stride = (long)M * N;
-  int rc = launch_gemm_tn(ASrcRowMajor{A, lda, M, 0}, W, ldw, M, N, ks, EpiSlabF32{slab, (long)N, stride}, stream, S, ks, ks, 0);
+  int rc = launch_gemm_tn(asrc, W, ldw, M, N, ks, EpiSlabF32{slab, (long)N, stride}, stream, S, ks, ks, 0);
   if (rc) return rc;
   const long work = (long)M * (N >> 2);
   hipLaunchKernelGGL((splitk_finish_kernel<Epi>), dim3((unsigned)cdiv(work, 256)), dim3(256), 0, stream, slab, S, stride, M, N, epi);
   LFM_CHECK_LAUNCH();
   return LFM_OK;
+}
+template <class Epi>
+static inline int launch_gemm_splitk(const half_t* A, long lda, const half_t* W, long ldw, int M, int N, int K, const Epi& epi, float* slab,
+                                     size_t slab_bytes, hipStream_t stream) {
+  return launch_gemm_splitk_src(ASrcRowMajor{A, lda, M, 0}, W, ldw, M, N, K, epi, slab, slab_bytes, stream);
 }

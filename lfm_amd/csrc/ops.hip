@@ -14,7 +14,12 @@ struct ASrcConv {
   const half_t* zeros;
   int H, W, Cin, M;  // OUTPUT spatial size; M = N*H*W
   int tap, ci0;
-  __device__ __forceinline__ void init(int, long) {}
+  int tap_begin, ci_begin;  // split-K: slice bz starts at k = bz * bs (init), a multiple of 64 <= Cin granularity
+  __device__ __forceinline__ void init(int bz, long bs) {
+    const long k = (long)bz * bs;
+    tap_begin = (int)(k / Cin);
+    ci_begin = (int)(k - (long)tap_begin * Cin);
+  }
   struct Row {
     int n, y, x;
   };
@@ -29,8 +34,8 @@ struct ASrcConv {
   }
   __device__ __forceinline__ void begin_tile(int kt, int bk) {
     if (kt == 0) {
-      tap = 0;
-      ci0 = 0;
+      tap = tap_begin;
+      ci0 = ci_begin;
     } else {
       ci0 += bk;
       if (ci0 >= Cin) {
@@ -114,11 +119,35 @@ static const half_t* zero_page() {
   return p;
 }
 
-extern "C" int lfm_conv3x3_f16(const void* in, const void* w, const float* bias, const void* resid, void* out, int N, int H, int W, int Cin,
-                               int Cout, int mode, lfm_stream_t stream) {
+// Low-resolution levels of a UNet are small-M, huge-K problems (celeb512 at batch 32: 4x4 maps = 512 rows x 1024 columns x K 9216..18432):
+// 32 tiles of 128x128 on 256 CUs, hundreds of K-tiles in sequence.  With a caller-provided workspace the K range is sliced over
+// blockIdx.y (fp32 slabs, summed in a fixed order by a finish kernel that applies the real epilogue -- deterministic), as for the
+// batch-1 DiT GEMMs.  workspace may be NULL (no split-K).
+extern "C" size_t lfm_conv3x3_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
+  const long M = (long)N * H * W;
+  if (M <= 0 || Cout <= 0 || Cin <= 0) return 0;
+  const long tiles = (long)cdiv(M, 128) * cdiv(Cout, 128);
+  if (tiles > 64) return 0;
+  int s = 1;
+  while (tiles * (s * 2) <= 256 && (9L * Cin) / (s * 2) >= 128 && ((9L * Cin) / (s * 2)) % 64 == 0) s *= 2;
+  return s < 2 ? 0 : (size_t)s * M * Cout * 4;
+}
+
+template <int MODE>
+static int conv3x3_mode(const half_t* xi, const half_t* z, const half_t* wi, const EpiResidF16& epi, int H, int W, int Cin, int Cout, int M, float* ws,
+                        size_t ws_bytes, hipStream_t st) {
+  ASrcConv<MODE> a{xi, z, H, W, Cin, M, 0, 0, 0, 0};
+  const int rc = launch_gemm_splitk_src(a, wi, 9L * Cin, M, Cout, 9 * Cin, epi, ws, ws_bytes, st);
+  if (rc != 1) return rc;
+  return launch_gemm_auto(a, wi, 9L * Cin, M, Cout, 9 * Cin, epi, st);
+}
+
+extern "C" int lfm_conv3x3_f16_ws(const void* in, const void* w, const float* bias, const void* resid, void* out, int N, int H, int W, int Cin,
+                                  int Cout, int mode, void* workspace, size_t workspace_bytes, lfm_stream_t stream) {
   if (!in || !w || !out) return LFM_ERR_ARG;
   if (N <= 0 || H <= 0 || W <= 0 || Cin % 64 || Cout % 4 || mode < 0 || mode > 2) return LFM_ERR_SHAPE;
   if (mode == 1 && ((H | W) & 1)) return LFM_ERR_SHAPE;
+  if (workspace && ((uintptr_t)workspace & 15)) return LFM_ERR_ALIGN;
   const half_t* z = zero_page();
   if (!z) return LFM_ERR_LAUNCH;
   const int M = N * H * W;
@@ -126,9 +155,15 @@ extern "C" int lfm_conv3x3_f16(const void* in, const void* w, const float* bias,
   hipStream_t st = (hipStream_t)stream;
   const half_t* wi = (const half_t*)w;
   const half_t* xi = (const half_t*)in;
-  if (mode == 0) return launch_gemm_auto(ASrcConv<0>{xi, z, H, W, Cin, M, 0, 0}, wi, 9L * Cin, M, Cout, 9 * Cin, epi, st);
-  if (mode == 1) return launch_gemm_auto(ASrcConv<1>{xi, z, H, W, Cin, M, 0, 0}, wi, 9L * Cin, M, Cout, 9 * Cin, epi, st);
-  return launch_gemm_auto(ASrcConv<2>{xi, z, H, W, Cin, M, 0, 0}, wi, 9L * Cin, M, Cout, 9 * Cin, epi, st);
+  float* ws = (float*)workspace;
+  if (mode == 0) return conv3x3_mode<0>(xi, z, wi, epi, H, W, Cin, Cout, M, ws, workspace_bytes, st);
+  if (mode == 1) return conv3x3_mode<1>(xi, z, wi, epi, H, W, Cin, Cout, M, ws, workspace_bytes, st);
+  return conv3x3_mode<2>(xi, z, wi, epi, H, W, Cin, Cout, M, ws, workspace_bytes, st);
+}
+
+extern "C" int lfm_conv3x3_f16(const void* in, const void* w, const float* bias, const void* resid, void* out, int N, int H, int W, int Cin,
+                               int Cout, int mode, lfm_stream_t stream) {
+  return lfm_conv3x3_f16_ws(in, w, bias, resid, out, N, H, W, Cin, Cout, mode, nullptr, 0, stream);
 }
 
 extern "C" int lfm_conv3x3_out_f32(const void* in, const void* w4, const float* bias4, float* out_nchw, int N, int H, int W, int Cin, int nch,
@@ -138,7 +173,7 @@ extern "C" int lfm_conv3x3_out_f32(const void* in, const void* w4, const float* 
   const half_t* z = zero_page();
   if (!z) return LFM_ERR_LAUNCH;
   const int M = N * H * W;
-  return launch_gemm_tn(ASrcConv<0>{(const half_t*)in, z, H, W, Cin, M, 0, 0}, (const half_t*)w4, 9L * Cin, M, 4, 9 * Cin,
+  return launch_gemm_tn(ASrcConv<0>{(const half_t*)in, z, H, W, Cin, M, 0, 0, 0, 0}, (const half_t*)w4, 9L * Cin, M, 4, 9 * Cin,
                         EpiNCHWF32{out_nchw, bias4, H * W, nch}, (hipStream_t)stream);
 }
 
@@ -353,6 +388,76 @@ __global__ __launch_bounds__(256) void gn_affine_kernel(const half_t* __restrict
   ((half8_t*)y)[i] = o;
 }
 
+// Fused small-tensor path (one launch instead of three): one block per (image, chunk of GPB groups) streams its channels of every pixel twice
+// (the second pass hits the L2): pass 1 per-group {sum, sumsq} with a fixed-order block reduction, pass 2 y = silu?(x*a + b) with the
+// per-channel a, b (FiLM folded) held in registers.  cpg % 8 == 0, HW <= 4096: every GroupNorm of the UNets below the top resolution.
+template <bool SILU>
+__global__ __launch_bounds__(256) void gn_fused_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ film, long film_stride, int HW,
+                                                       int C, int cpg, int gpb, float eps) {
+  __shared__ float red[2][256];
+  __shared__ float mr[2][32];
+  const int n = blockIdx.y, tid = threadIdx.x;
+  const int CW = gpb * cpg, o8 = CW >> 3;          // channels / octets of this block
+  const int oct = tid % o8, prow = tid / o8, rows = 256 / o8;
+  const int c0 = blockIdx.x * CW + oct * 8;         // first channel of this thread's octet
+  const half_t* xb = x + (long)n * HW * C + c0;
+  float s = 0.f, q = 0.f;
+  if (prow < rows)
+    for (int p = prow; p < HW; p += rows) {
+      const half8_t v = *(const half8_t*)(xb + (long)p * C);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float f = (float)v[j];
+        s += f;
+        q += f * f;
+      }
+    }
+  red[0][tid] = s;
+  red[1][tid] = q;
+  __syncthreads();
+  if (tid < gpb) {  // group tid of this block: octets [tid*cpg/8, (tid+1)*cpg/8) of every pixel row, folded in a fixed order
+    const int ob = tid * (cpg >> 3), oe = ob + (cpg >> 3);
+    float ss = 0.f, qq = 0.f;
+    for (int r = 0; r < rows; ++r)
+      for (int o = ob; o < oe; ++o) {
+        ss += red[0][r * o8 + o];
+        qq += red[1][r * o8 + o];
+      }
+    const float cnt = (float)HW * (float)cpg, mean = ss / cnt;
+    mr[0][tid] = mean;
+    mr[1][tid] = rsqrtf(fmaxf(qq / cnt - mean * mean, 0.f) + eps);
+  }
+  __syncthreads();
+  if (prow >= rows) return;
+  const int gl = (oct * 8) / cpg;
+  const float mean = mr[0][gl], rstd = mr[1][gl];
+  float a[8], b[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = c0 + j;
+    a[j] = rstd * gamma[c];
+    b[j] = beta[c] - mean * a[j];
+    if (film) {
+      const float sc = 1.0f + film[(long)n * film_stride + c], sh = film[(long)n * film_stride + C + c];
+      a[j] *= sc;
+      b[j] = b[j] * sc + sh;
+    }
+  }
+  half_t* yb = y + (long)n * HW * C + c0;
+  for (int p = prow; p < HW; p += rows) {
+    const half8_t v = *(const half8_t*)(xb + (long)p * C);
+    half8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float f = (float)v[j] * a[j] + b[j];
+      if (SILU) f = silu_f(f);
+      o[j] = (half_t)f;
+    }
+    *(half8_t*)(yb + (long)p * C) = o;
+  }
+}
+
 #define GN_MAX_SLABS 64  // pixel slabs per image: bounds the partial buffer independently of HW
 static inline size_t gn_part_bytes(int N, int C) {
   const size_t per_slab = (size_t)(C / 4 > 32 ? C / 4 : 32) * 2 * 4;  // max of the two partial layouts
@@ -365,9 +470,19 @@ extern "C" int lfm_groupnorm_f16(const void* x, void* y, const float* gamma, con
   if (!x || !y || !gamma || !beta || !scratch) return LFM_ERR_ARG;
   if (N <= 0 || HW <= 0 || groups <= 0 || groups > 32 || C % groups || C % 8) return LFM_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
+  const int G = groups, cpg = C / G;
+  if (cpg % 8 == 0 && HW <= 4096 && !(lfm_gemm_debug_flags() & 16384)) {  // flag 16384: the three-kernel path (A/B)
+    int gpb = 1;
+    while (gpb * 2 <= G && G % (gpb * 2) == 0 && (long)N * (G / (gpb * 2)) >= 256 && gpb * 2 * cpg <= 2048) gpb *= 2;
+    while (256 / ((gpb * cpg) >> 3) < 1) gpb >>= 1;
+    dim3 grid(G / gpb, N);
+    if (silu) hipLaunchKernelGGL(gn_fused_kernel<true>, grid, dim3(256), 0, st, (const half_t*)x, (half_t*)y, gamma, beta, film, film_stride, HW, C, cpg, gpb, eps);
+    else hipLaunchKernelGGL(gn_fused_kernel<false>, grid, dim3(256), 0, st, (const half_t*)x, (half_t*)y, gamma, beta, film, film_stride, HW, C, cpg, gpb, eps);
+    LFM_CHECK_LAUNCH();
+    return LFM_OK;
+  }
   float* part = (float*)scratch;
   float* ab = (float*)((char*)scratch + gn_part_bytes(N, C));
-  const int G = groups, cpg = C / G;
   int slabs, rows;
   if (cpg % 4 == 0 && C / 8 <= 256) {
     int ppb = HW >= 4096 ? 512 : (HW >= 256 ? 64 : HW);

@@ -91,6 +91,10 @@ def lib():
     V, I, LG, F = C.c_void_p, C.c_int, C.c_long, C.c_float
     L.lfm_conv3x3_f16.restype = I
     L.lfm_conv3x3_f16.argtypes = [V, V, V, V, V, I, I, I, I, I, I, V]
+    L.lfm_conv3x3_workspace_bytes.restype = C.c_size_t
+    L.lfm_conv3x3_workspace_bytes.argtypes = [I, I, I, I, I]
+    L.lfm_conv3x3_f16_ws.restype = I
+    L.lfm_conv3x3_f16_ws.argtypes = [V, V, V, V, V, I, I, I, I, I, I, V, C.c_size_t, V]
     L.lfm_conv3x3_in_f32.restype = I
     L.lfm_conv3x3_in_f32.argtypes = [V, V, V, V, I, I, I, I, I, V]
     L.lfm_conv3x3_out_f32.restype = I

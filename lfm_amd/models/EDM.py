@@ -149,6 +149,7 @@ class DhariwalUNet(nn.Module):
         if before != [(p.data_ptr(), p.dtype, p.device) for p in self.parameters()]:  # only a real move / cast invalidates
             self._packed = None
             self._scratch = None
+            self._conv_ws = None
             self._gen = getattr(self, "_gen", 0) + 1
         return out
 
@@ -223,8 +224,14 @@ class DhariwalUNet(nn.Module):
 
     def _conv(self, x, wb, N, H, W, Cin, Cout, mode=0, resid=None):
         out = torch.empty(N * H * W, Cout, dtype=torch.float16, device=x.device)
-        hip.check(hip.lib().lfm_conv3x3_f16(hip.ptr(x), hip.ptr(wb[0]), hip.ptr(wb[1]), hip.ptr(resid), hip.ptr(out), N, H, W, Cin, Cout, mode,
-                                            hip.stream_ptr(x.device)), "lfm_conv3x3_f16")
+        L = hip.lib()
+        need = L.lfm_conv3x3_workspace_bytes(N, H, W, Cin, Cout)  # split-K slabs of the small-M / huge-K low-resolution levels
+        if need and (getattr(self, "_conv_ws", None) is None or self._conv_ws.numel() < need or self._conv_ws.device != x.device):
+            self._conv_ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+            self._gen += 1
+        ws = self._conv_ws if need else None
+        hip.check(L.lfm_conv3x3_f16_ws(hip.ptr(x), hip.ptr(wb[0]), hip.ptr(wb[1]), hip.ptr(resid), hip.ptr(out), N, H, W, Cin, Cout, mode,
+                                       hip.ptr(ws), ws.numel() if ws is not None else 0, hip.stream_ptr(x.device)), "lfm_conv3x3_f16_ws")
         return out
 
     def _linear(self, x, wb, resid=None):

@@ -131,6 +131,8 @@ class UNetModel(nn.Module):
             p.detach().zero_()
         self._packed = None
         self._scratch = None
+        self._conv_ws = None
+        self._film_all = None
         self._gen = 0  # bumped whenever device buffers a captured graph may point to are replaced
 
     # ---- packing ------------------------------------------------------------------------------------------------------
@@ -140,6 +142,7 @@ class UNetModel(nn.Module):
         if before != [(p.data_ptr(), p.dtype, p.device) for p in self.parameters()]:  # only a real move / cast invalidates
             self._packed = None
             self._scratch = None
+            self._conv_ws = None
             self._gen = getattr(self, "_gen", 0) + 1
         return out
 
@@ -180,6 +183,15 @@ class UNetModel(nn.Module):
                 P[name] = conv3(m.op)
             elif isinstance(m, Upsample):
                 P[name] = conv3(m.conv)
+        # every ResBlock projects the SAME silu(emb) row through its own emb_layers Linear (unet.py:205-207): one GEMM per evaluation over
+        # the concatenated weights (M = batch rows only -- 27 tiny launches otherwise), each block then reads its column slice
+        names = [n for n, m in self.named_modules() if isinstance(m, ResBlock)]
+        P["emb_all"] = (torch.cat([P[n]["emb"][0] for n in names], 0).contiguous(), torch.cat([P[n]["emb"][1] for n in names], 0).contiguous())
+        off = 0
+        for n in names:
+            P[n]["emb_slice"] = (off, P[n]["emb"][0].shape[0])
+            off += P[n]["emb"][0].shape[0]
+            P[n]["emb"] = None  # the per-block copies are not needed on the device
         c0 = self.input_blocks[0][0]
         P["conv_in"] = (f32(c0.weight), f32(c0.bias))
         P["time"] = (f32(self.time_embed[0].weight), f32(self.time_embed[0].bias), f32(self.time_embed[2].weight), f32(self.time_embed[2].bias))
@@ -211,8 +223,14 @@ class UNetModel(nn.Module):
 
     def _conv(self, x, wb, N, H, W, Cin, Cout, mode=0, resid=None):
         out = torch.empty(N * H * W, Cout, dtype=torch.float16, device=x.device)
-        hip.check(hip.lib().lfm_conv3x3_f16(hip.ptr(x), hip.ptr(wb[0]), hip.ptr(wb[1]), hip.ptr(resid), hip.ptr(out), N, H, W, Cin, Cout, mode,
-                                            hip.stream_ptr(x.device)), "lfm_conv3x3_f16")
+        L = hip.lib()
+        need = L.lfm_conv3x3_workspace_bytes(N, H, W, Cin, Cout)  # > 0 for the small-M / huge-K low-resolution levels: split-K slabs
+        if need and (self._conv_ws is None or self._conv_ws.numel() < need or self._conv_ws.device != x.device):
+            self._conv_ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+            self._gen += 1
+        ws = self._conv_ws if need else None
+        hip.check(L.lfm_conv3x3_f16_ws(hip.ptr(x), hip.ptr(wb[0]), hip.ptr(wb[1]), hip.ptr(resid), hip.ptr(out), N, H, W, Cin, Cout, mode,
+                                       hip.ptr(ws), ws.numel() if ws is not None else 0, hip.stream_ptr(x.device)), "lfm_conv3x3_f16_ws")
         return out
 
     def _linear(self, x, wb, resid=None):
@@ -228,7 +246,8 @@ class UNetModel(nn.Module):
         Cin, Cout = m.channels, m.out_channels
         t1 = self._gn(h, N, H * W, Cin, p["gn1"], None, True)
         a = self._conv(t1, p["c1"], N, H, W, Cin, Cout)
-        film = hip.gemm_f16(emb_silu, p["emb"][0], p["emb"][1], epilogue=2)  # fp32 [N, 2*Cout] = [scale | shift]
+        o, wdt = p["emb_slice"]
+        film = self._film_all[:, o:o + wdt]  # fp32 [N, 2*Cout] = [scale | shift], a column slice of the one emb GEMM of this evaluation
         t2 = self._gn(a, N, H * W, Cout, p["gn2"], film, True)
         skip = h if p["skip"] is None else self._linear(h, p["skip"])
         return self._conv(t2, p["c2"], N, H, W, Cout, Cout, resid=skip)
@@ -292,6 +311,8 @@ class UNetModel(nn.Module):
         hip.check(L.lfm_time_embed(hip.ptr(t), t.numel(), hip.ptr(tw[0]), hip.ptr(tw[1]), hip.ptr(tw[2]), hip.ptr(tw[3]),
                                    hip.ptr(self._packed["label"]), hip.ptr(y), n_labels, hip.ptr(h1), hip.ptr(emb), hip.ptr(emb_silu), N, F, E,
                                    hip.stream_ptr(dev)), "lfm_time_embed")
+        ea = self._packed["emb_all"]
+        self._film_all = hip.gemm_f16(emb_silu, ea[0], ea[1], epilogue=2)  # every ResBlock's emb_layers in one launch
         ci = self._packed["conv_in"]
         ch0 = ci[0].shape[0]
         h = torch.empty(N * H * W, ch0, dtype=torch.float16, device=dev)

@@ -82,6 +82,88 @@ def test_building_blocks_against_torch():
     assert rel_l2(out.reshape(N, T, heads * ch).permute(0, 2, 1), ref) < 2e-3
 
 
+@pytest.mark.parametrize("N,HW,C,groups,film_on", [(3, 64, 256, 32, True), (2, 256, 768, 32, True), (32, 16, 1024, 32, False), (2, 4096, 512, 32, True),
+                                                   (2, 64, 64, 16, True)])
+def test_groupnorm_fused_small_path_vs_torch_and_three_kernel_path(N, HW, C, groups, film_on):
+    """cpg % 8 == 0 and HW <= 4096: one fused launch (block per image x group chunk).  Against torch's group_norm and against the
+    three-kernel path (flag 16384) on the same data; both deterministic."""
+    import torch.nn.functional as F
+
+    from lfm_amd import hip
+
+    dev = torch.device("cuda:0")
+    L = hip.lib()
+    g = torch.Generator().manual_seed(N + HW + C)
+    x = (torch.randn(N, HW, C, generator=g) * 1.5 + 0.3).half()
+    gamma, beta = 1 + 0.2 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+    film = torch.randn(N, 2 * C, generator=g) * 0.3 if film_on else None
+    ref = F.group_norm(x.float().permute(0, 2, 1), groups, gamma, beta, eps=1e-5)
+    if film_on:
+        ref = ref * (1 + film[:, :C, None]) + film[:, C:, None]
+    ref = F.silu(ref).permute(0, 2, 1)
+    xin, gd, bd = x.reshape(N * HW, C).to(dev), gamma.to(dev), beta.to(dev)
+    fd = film.to(dev) if film_on else None
+    scr = torch.empty(L.lfm_groupnorm_scratch_bytes(N, C), dtype=torch.uint8, device=dev)
+
+    def run():
+        y = torch.empty_like(xin)
+        hip.check(L.lfm_groupnorm_f16(hip.ptr(xin), hip.ptr(y), hip.ptr(gd), hip.ptr(bd), hip.ptr(fd), 2 * C if film_on else 0, hip.ptr(scr), N, HW, C,
+                                      groups, 1e-5, 1, hip.stream_ptr()), "gn")
+        torch.cuda.synchronize()
+        return y
+
+    fused = run()
+    assert torch.equal(fused, run())
+    hip.gemm_select(16384 << 4)
+    try:
+        three = run()
+    finally:
+        hip.gemm_select(0)
+    assert rel_l2(fused.reshape(N, HW, C), ref) < 2e-3
+    assert rel_l2(three.reshape(N, HW, C), ref) < 2e-3
+    assert rel_l2(fused, three) < 1e-3
+
+
+@pytest.mark.parametrize("N,H,Cin,Cout,mode", [(32, 4, 1024, 1024, 0), (8, 8, 512, 512, 0), (2, 4, 2048, 1024, 0), (4, 8, 512, 512, 2), (4, 8, 512, 256, 1)])
+def test_conv3x3_split_k_small_maps(N, H, Cin, Cout, mode):
+    """Low-resolution UNet levels: small M, K = 9*Cin up to 18432.  With the workspace the K range is sliced (deterministic slab
+    reduction); same result as the unsliced kernel and as torch's conv2d."""
+    import torch.nn.functional as F
+
+    from lfm_amd import hip
+
+    dev = torch.device("cuda:0")
+    L = hip.lib()
+    g = torch.Generator().manual_seed(N + H + Cin + mode)
+    Hi = H * 2 if mode == 2 else (H // 2 if mode == 1 else H)
+    x = torch.randn(N, Cin, Hi, Hi, generator=g).half()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).half()
+    b = torch.randn(Cout, generator=g) * 0.1
+    res = torch.randn(N, Cout, H, H, generator=g).half()
+    xf = x.float()
+    if mode == 1:
+        xf = F.interpolate(xf, scale_factor=2, mode="nearest")
+    ref = F.conv2d(xf, w.float(), b, padding=1, stride=2 if mode == 2 else 1) + res.float()
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()
+    xin, wp, bd, rd = nhwc(x).to(dev), w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(dev), b.to(dev), nhwc(res).to(dev)
+    need = L.lfm_conv3x3_workspace_bytes(N, H, H, Cin, Cout)
+    assert need > 0, "these shapes are the split-K regime"
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+
+    def run(use_ws):
+        out = torch.empty(N * H * H, Cout, dtype=torch.float16, device=dev)
+        hip.check(L.lfm_conv3x3_f16_ws(hip.ptr(xin), hip.ptr(wp), hip.ptr(bd), hip.ptr(rd), hip.ptr(out), N, H, H, Cin, Cout, mode,
+                                       hip.ptr(ws) if use_ws else None, need if use_ws else 0, hip.stream_ptr()), "conv")
+        torch.cuda.synchronize()
+        return out
+
+    split, plain = run(True), run(False)
+    assert torch.equal(split, run(True))
+    got = split.reshape(N, H, H, Cout).permute(0, 3, 1, 2)
+    assert rel_l2(got, ref) < 2e-3
+    assert rel_l2(split, plain) < 1e-3
+
+
 def test_unet_fullsize_vs_oracle_and_fused_sampling():
     """celeb256-ADM-like configuration (nf 256, ch_mult 1 2 2 2, attn at ds 16/8, 4 heads) at reduced depth of batch:
     one velocity evaluation vs the CPU oracle, then a 4-step Euler solve: graph-captured vs eager loop vs oracle."""
