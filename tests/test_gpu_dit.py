@@ -170,8 +170,9 @@ def test_ln_modulate(dev, D, tokens, shared):
     assert rel_l2(got, ref) < 1e-3
 
 
-@pytest.mark.parametrize("T,heads,batch", [(256, 16, 3), (256, 2, 1), (64, 6, 2), (128, 4, 2)])
+@pytest.mark.parametrize("T,heads,batch", [(256, 16, 3), (256, 2, 1), (64, 6, 2), (128, 4, 2), (256, 16, 17), (256, 16, 64), (256, 12, 43)])
 def test_attention(dev, T, heads, batch):
+    """Up to the benchmark's own shape (64 images x 16 heads x 256 tokens); every (image, head) item is checked on its own."""
     from lfm_amd import hip
 
     g = torch.Generator().manual_seed(T + heads)
@@ -186,7 +187,13 @@ def test_attention(dev, T, heads, batch):
     K = k.transpose(1, 2).reshape(batch * T, D).contiguous().to(dev)
     Vt = v.transpose(-1, -2).contiguous().to(dev)  # [b, h, 64, T]
     got = hip.dit_attention(Q, K, Vt, batch, heads, T)
+    got2 = hip.dit_attention(Q, K, Vt, batch, heads, T)
+    torch.cuda.synchronize()
     assert rel_l2(got, ref) < 2e-3
+    assert torch.equal(got, got2)
+    per_item = (got.float().cpu().reshape(batch, T, heads, 64) - ref.reshape(batch, T, heads, 64)).pow(2).sum((1, 3)).sqrt() / \
+        ref.reshape(batch, T, heads, 64).pow(2).sum((1, 3)).sqrt()
+    assert float(per_item.max()) < 4e-3  # no single (image, head) item is off (a stale-buffer bug would hit whole items)
 
 
 # ----------------------------------------------------------------------------- whole model
