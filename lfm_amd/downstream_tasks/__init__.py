@@ -68,13 +68,12 @@ class WrapperCondFlow(nn.Module):
 def sample_from_model(model, x_0, args):
     """Reference downstream_tasks/test_flow_latent_inpainting.py:58-77: integrate from t = 1 (noise) to t = 0; returns the [2, N, 4, h, w]
     end points (callers take [-1]).  Fixed-step Euler on the HIP UNet runs as one captured graph per interval (as the main sampler)."""
-    if getattr(args, "perturb", False):
-        raise NotImplementedError("--perturb (torchdiffeq time perturbation) is not built")
     if not getattr(args, "compute_fid", False) and hasattr(model, "count_nfe"):
         model.count_nfe = True  # reference :65-66
-    if args.method == "euler" and getattr(args, "fused", True) and fused_fixed_grid_available(model, x_0) and not getattr(model, "count_nfe", False):
+    if (args.method == "euler" and getattr(args, "fused", True) and not getattr(args, "perturb", False) and fused_fixed_grid_available(model, x_0)
+            and not getattr(model, "count_nfe", False)):
         x1 = sample_torchdiffeq_euler_fused(model, x_0, args.step_size, {})
         return torch.stack([x_0, x1], 0)
     t = torch.tensor([1.0, 0.0], device=x_0.device)
-    opts = {} if args.method in ADAPTIVE_SOLVER else {"step_size": args.step_size}
+    opts = {} if args.method in ADAPTIVE_SOLVER else {"step_size": args.step_size, "perturb": getattr(args, "perturb", False)}
     return odeint(model, x_0, t, method=args.method, atol=args.atol, rtol=args.rtol, options=opts)

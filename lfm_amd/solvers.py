@@ -70,10 +70,29 @@ def _comb(ks, coefs, dt):
     return acc
 
 
+# Bogacki-Shampine 3(2) ("bosh3") and Heun-Euler 2(1) ("adaptive_heun") as torchdiffeq tabulates them; the midpoint weights feed the
+# same quartic dense-output fit as dopri5.  bosh3's pair is scipy's RK23 (tests/test_ode_ref.py checks the tableau against it).
+_BS_A = (1 / 2, 3 / 4, 1.0)
+_BS_B = ((1 / 2,), (0.0, 3 / 4), (2 / 9, 1 / 3, 4 / 9))
+_BS_E = (2 / 9 - 7 / 24, 1 / 3 - 1 / 4, 4 / 9 - 1 / 3, -1 / 8)
+_BS_MID = (0.0, 0.5, 0.0, 0.0)
+_AH_A = (1.0,)
+_AH_B = ((1.0,),)
+_AH_SOL = (0.5, 0.5)
+_AH_E = (0.5, -0.5)
+_AH_MID = (0.5, 0.0)
+
+
 class Dopri5:
     """Adaptive Dormand-Prince as torchdiffeq runs it: fp64 time, RMS error norm over the WHOLE state tensor (step sizes
-    are batch-coupled), accept iff ratio <= 1, dt *= min(10, max(0.9 ratio^-1/5, 0.2|1)), FSAL, steps not clipped to the end
-    time (the model is queried slightly past it), 4th-order dense output evaluated at the requested time."""
+    are batch-coupled), accept iff ratio <= 1, dt *= min(10, max(0.9 ratio^-1/order, 0.2|1)), FSAL, steps not clipped to the end
+    time (the model is queried slightly past it), 4th-order dense output evaluated at the requested time.
+
+    The same adaptive Runge-Kutta driver runs the other embedded pairs of torchdiffeq's RKAdaptiveStepsizeODESolver through the class
+    attributes below (``Bosh3``, ``AdaptiveHeun``): stage nodes A, stage rows B, solution weights SOL (None = last row of B, FSAL),
+    error weights E, midpoint weights MID, ORDER (exponent of the step controller and of the initial-step heuristic)."""
+
+    A, B, SOL, E, MID, ORDER = _DP_A, _DP_B, None, _DP_E, _DP_MID, 5
 
     def __init__(self, f, y0, t0, rtol, atol, max_num_steps=2 ** 31 - 1):
         self.f, self.rtol, self.atol, self.max_num_steps = f, rtol, atol, max_num_steps
@@ -82,7 +101,7 @@ class Dopri5:
         f0 = f(t0, y0)
         self.y0, self.f0 = y0, f0
         self.t0 = self.t1 = t0
-        self.dt = self._initial_step(t0, y0, f0)
+        self.dt = self._initial_step(t0, y0, f0, order=self.ORDER - 1)
         self.coef = [y0] * 5
 
     def _initial_step(self, t0, y0, f0, order=4):
@@ -103,17 +122,20 @@ class Dopri5:
         t0y, dty, t1y = t0.to(y0.dtype), dt.to(y0.dtype), t1.to(y0.dtype)
         k = [f0]
         yi = y0
-        for a, b in zip(_DP_A, _DP_B):
+        for a, b in zip(self.A, self.B):
             yi = y0 + _comb(k, b, dty)
             k.append(self.f(t1y if a == 1.0 else t0y + a * dty, yi))
-        y1, f1 = yi, k[-1]
-        err = _comb(k, _DP_E, dty)
+        # FSAL pairs: the last stage IS the solution; otherwise (adaptive_heun) the solution is its own combination and -- as in
+        # torchdiffeq's _runge_kutta_step -- the last stage's derivative still serves as f1 of the next step
+        y1 = yi if self.SOL is None else y0 + _comb(k, self.SOL, dty)
+        f1 = k[-1]
+        err = _comb(k, self.E, dty)
         tol = self.atol + self.rtol * torch.max(y0.abs(), y1.abs())
         ratio = _rms(err / tol)  # the one device->host read of the step
         ratio_h = float(ratio)
         self.nfe_steps += 1
         if ratio_h <= 1:
-            y_mid = y0 + _comb(k, _DP_MID, dty)
+            y_mid = y0 + _comb(k, self.MID, dty)
             a = 2 * dty * (f1 - f0) - 8 * (y1 + y0) + 16 * y_mid
             b = dty * (5 * f0 - 3 * f1) + 18 * y0 + 14 * y1 - 32 * y_mid
             c = dty * (f1 - 4 * f0) - 11 * y0 - 5 * y1 + 16 * y_mid
@@ -123,7 +145,7 @@ class Dopri5:
         if ratio_h == 0:
             factor = 10.0
         else:
-            factor = min(10.0, max(0.9 / ratio_h ** 0.2, 1.0 if ratio_h < 1 else 0.2))
+            factor = min(10.0, max(0.9 / ratio_h ** (1.0 / self.ORDER), 1.0 if ratio_h < 1 else 0.2))
         self.dt = dt * factor
 
     def advance(self, t_next):
@@ -141,6 +163,51 @@ class Dopri5:
         return total
 
 
+class Bosh3(Dopri5):
+    A, B, SOL, E, MID, ORDER = _BS_A, _BS_B, None, _BS_E, _BS_MID, 3
+
+
+class AdaptiveHeun(Dopri5):
+    A, B, SOL, E, MID, ORDER = _AH_A, _AH_B, _AH_SOL, _AH_E, _AH_MID, 2
+
+
+_ADAPTIVE = {"dopri5": Dopri5, "bosh3": Bosh3, "adaptive_heun": AdaptiveHeun}
+
+
+def _perturbed(f):
+    """torchdiffeq's _PerturbFunc for the fixed-grid solvers under options['perturb']: the evaluation at the START of a step is taken one
+    ulp after it, the one at the END one ulp before it (so a field that is discontinuous at grid points is sampled inside the step)."""
+
+    def g(t, y, perturb=0):
+        if perturb > 0:
+            t = torch.nextafter(t, t + 1)
+        elif perturb < 0:
+            t = torch.nextafter(t, t - 1)
+        return f(t, y)
+
+    return g
+
+
+def _euler_step_p(f, t0, dt, t1, y0):
+    return dt * f(t0, y0, perturb=1)
+
+
+def _midpoint_step_p(f, t0, dt, t1, y0):
+    half = 0.5 * dt
+    return dt * f(t0 + half, y0 + f(t0, y0, perturb=1) * half)
+
+
+def _rk4_step_p(f, t0, dt, t1, y0):
+    k1 = f(t0, y0, perturb=1)
+    k2 = f(t0 + dt / 3, y0 + dt * k1 / 3)
+    k3 = f(t0 + dt * 2 / 3, y0 + dt * (k2 - k1 / 3))
+    k4 = f(t1, y0 + dt * (k1 - k2 + k3), perturb=-1)
+    return (k1 + 3 * (k2 + k3) + k4) * dt * 0.125
+
+
+_STEP_P = {"euler": _euler_step_p, "midpoint": _midpoint_step_p, "rk4": _rk4_step_p}
+
+
 @torch.no_grad()
 def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, stats=None):
     method = method or "dopri5"
@@ -156,6 +223,8 @@ def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, stat
             raise ValueError("fixed-grid solvers need options['step_size']")
         grid = fixed_grid(t, options["step_size"])
         step = _STEP[method]
+        if options.get("perturb"):
+            g, step = _perturbed(g), _STEP_P[method]
         sol, j = [y0], 1
         tl = t.tolist()
         gl = grid.tolist()
@@ -172,14 +241,15 @@ def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None, stat
                 j += 1
             y0 = y1
         return torch.stack(sol, 0)
-    if method == "dopri5":
+    if method in _ADAPTIVE:
         t = t.to(torch.float64)
-        solver = Dopri5(g, y0, t[0], rtol, atol)
+        solver = _ADAPTIVE[method](g, y0, t[0], rtol, atol)
         sol = [y0] + [solver.advance(t[j]) for j in range(1, len(t))]
         if stats is not None:
-            stats.update(steps=solver.nfe_steps, accepted=solver.accepted, nfe=2 + 6 * solver.nfe_steps)
+            stats.update(steps=solver.nfe_steps, accepted=solver.accepted, nfe=2 + len(solver.A) * solver.nfe_steps)
         return torch.stack(sol, 0)
-    raise NotImplementedError(f"method {method!r}: euler / midpoint / rk4 / dopri5 are built (SURVEY.md §8 a5)")
+    raise NotImplementedError(f"method {method!r}: euler / midpoint / rk4 / dopri5 / bosh3 / adaptive_heun are built; dopri8's 13-stage tableau "
+                              "cannot be restated reliably offline (torchdiffeq is not installable here) and is refused rather than guessed")
 
 
 def torchdiffeq_euler_grid(step_size, device=None):

@@ -72,10 +72,8 @@ def sample_from_model(model, x_0, model_kwargs, args):
             return model.forward_with_cfg(t, x, **model_kwargs)
         return model(t, x, **{k: v for k, v in model_kwargs.items() if k != "cfg_scale"})
 
-    if getattr(args, "perturb", False):
-        raise NotImplementedError("--perturb (torchdiffeq time perturbation) is not built")
     traj = odeint(denoiser, x_0, t, method=args.method, atol=args.atol, rtol=args.rtol,
-                  options={k: v for k, v in options.items() if k in ("step_size",)})
+                  options={k: v for k, v in options.items() if k in ("step_size", "perturb")})
     if count:
         return traj, model.nfe
     return traj

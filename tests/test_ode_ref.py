@@ -199,3 +199,63 @@ def test_known_answers():
                 e.append(float((o - y0 * np.exp(-1.0)).abs().max()))
             errs[method] = np.log2(e[0] / e[1])
             assert abs(errs[method] - order) < 0.25, (method, errs)
+
+
+# ----------------------------------------------------------------------------- the other adaptive pairs and --perturb (product only)
+def test_bosh3_tableau_equals_scipy_rk23_and_orders():
+    from scipy.integrate import RK23
+
+    np.testing.assert_allclose(RK23.C[1:], prod._BS_A[:2], rtol=0, atol=1e-16)
+    np.testing.assert_allclose(RK23.A[1, :1], prod._BS_B[0], atol=1e-16)
+    np.testing.assert_allclose(RK23.A[2, :2], prod._BS_B[1], atol=1e-16)
+    np.testing.assert_allclose(RK23.B, prod._BS_B[2], atol=1e-16)
+    np.testing.assert_allclose(-RK23.E, prod._BS_E, atol=1e-16)  # scipy tabulates (embedded - solution), torchdiffeq (solution - embedded)
+    # order conditions: solution weights 3rd order, embedded (solution - error) weights 2nd order
+    A = np.zeros((4, 4))
+    for i, row in enumerate(prod._BS_B):
+        A[i + 1, : len(row)] = row
+    c = np.array([0.0] + list(prod._BS_A))
+    sol = np.array(list(prod._BS_B[2]) + [0.0])
+    for got, want in _order_sums(sol, A, c)[:4]:
+        assert abs(got - want) < 1e-15
+    emb = sol - np.array(prod._BS_E)
+    for got, want in _order_sums(emb, A, c)[:2]:
+        assert abs(got - want) < 1e-15
+    # Heun-Euler: solution = trapezoid (2nd order), embedded = Euler (1st order)
+    assert prod._AH_SOL == (0.5, 0.5) and tuple(np.array(prod._AH_SOL) - np.array(prod._AH_E)) == (0.0, 1.0)
+
+
+@pytest.mark.parametrize("method,stages,tol", [("bosh3", 3, 1e-6), ("adaptive_heun", 1, 1e-5), ("dopri5", 6, 1e-7)])
+def test_adaptive_pairs_solve_and_count(method, stages, tol):
+    stats = {}
+    y0 = torch.from_numpy(Y0)
+    got = prod.odeint(lambda t, y: -_f_torch(t, y), y0, torch.tensor([1.0, 0.0]), method=method, rtol=tol, atol=tol, stats=stats)[-1].numpy()
+    tight = solve_ivp(lambda t, y: -_f_np(t, y), (1.0, 0.0), Y0, method="DOP853", rtol=1e-12, atol=1e-13).y[:, -1]
+    assert np.abs(got - tight).max() < 300 * tol
+    assert stats["nfe"] == 2 + stages * stats["steps"] and stats["accepted"] <= stats["steps"]
+    if method == "bosh3":  # same pair, same norm as scipy's RK23: comparable step counts
+        n_sci = solve_ivp(lambda t, y: -_f_np(t, y), (1.0, 0.0), Y0, method="RK23", rtol=tol, atol=tol).t.size - 1
+        assert 0.4 * n_sci <= stats["accepted"] <= 2.5 * n_sci
+    with pytest.raises(NotImplementedError):
+        prod.odeint(lambda t, y: -y, y0, torch.tensor([1.0, 0.0]), method="dopri8")
+
+
+def test_perturb_samples_inside_the_step():
+    """options['perturb']: the start-of-step evaluation is one ulp inside the step.  A field that is discontinuous exactly at the grid
+    points tells the two modes apart; on a smooth field they agree to rounding."""
+    seen = []
+
+    def f(t, y):
+        seen.append(float(t))
+        return -y
+
+    y0 = torch.ones(2)
+    a = prod.odeint(f, y0, torch.tensor([0.0, 1.0]), method="euler", options={"step_size": 0.25})[-1]
+    plain = list(seen)
+    seen.clear()
+    b = prod.odeint(f, y0, torch.tensor([0.0, 1.0]), method="euler", options={"step_size": 0.25, "perturb": True})[-1]
+    assert plain == [0.0, 0.25, 0.5, 0.75] and all(p > q for p, q in zip(seen, plain)) and max(p - q for p, q in zip(seen, plain)) < 1e-6
+    torch.testing.assert_close(a, b)
+    seen.clear()
+    prod.odeint(f, y0, torch.tensor([0.0, 1.0]), method="rk4", options={"step_size": 0.5, "perturb": True})
+    assert seen[0] > 0.0 and seen[3] < 0.5 and seen[3] > 0.4999  # k1 just after t0, k4 just before t1
