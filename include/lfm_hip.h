@@ -227,6 +227,9 @@ int lfm_avgpool2_f16(const void* x, void* y, int N, int Ho, int Wo, int C, lfm_s
 int lfm_upsample2_f16(const void* x, void* y, int N, int Ho, int Wo, int C, lfm_stream_t stream);
 /* out[p][0:Ca | Ca:Ca+Cb] = a[p], b[p]   (th.cat([h, hs.pop()], dim=1), unet.py:649) */
 int lfm_concat_channels_f16(const void* a, const void* b, void* out, long pixels, int Ca, int Cb, lfm_stream_t stream);
+/* y = x + e[n][c] broadcast over the pixels of image n (ResBlock without scale-shift norm: h + emb_out[..., None, None], unet.py:233-235);
+ * x, y fp16 NHWC [N*HW, C], e fp32 rows e_stride apart */
+int lfm_add_image_vec_f16(const void* x, const float* e, long e_stride, void* y, int N, int HW, int C, lfm_stream_t stream);
 /* QKVAttentionLegacy (unet.py:310-334): qkv fp16 [N*T, 3C], columns [head][q|k|v][ch]; out fp16 [N*T, C] columns [head][ch] */
 int lfm_attention_small_f16(const void* qkv, void* out, int N, int T, int heads, int ch, lfm_stream_t stream);
 /* emb = time_embed(timestep_embedding(t, F)) (+ label_emb[y]) (nn.py:103-121, unet.py:633-641): fp32 [N,E] and fp16 silu(emb).

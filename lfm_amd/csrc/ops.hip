@@ -556,6 +556,30 @@ extern "C" int lfm_upsample2_f16(const void* x, void* y, int N, int Ho, int Wo, 
   return LFM_OK;
 }
 
+// ------------------------------------------------------------------ h + emb_out[..., None, None] (ResBlock without scale-shift norm, unet.py:233-235)
+__global__ void add_image_vec_kernel(const half8_t* __restrict__ x, const float* __restrict__ e, long e_stride, half8_t* __restrict__ y, int HW,
+                                     int C8, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C8);
+  const long n = i / ((long)C8 * HW);
+  const half8_t v = x[i];
+  const float* ev = e + n * e_stride + c * 8;
+  half8_t o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (half_t)((float)v[j] + ev[j]);
+  y[i] = o;
+}
+extern "C" int lfm_add_image_vec_f16(const void* x, const float* e, long e_stride, void* y, int N, int HW, int C, lfm_stream_t stream) {
+  if (!x || !e || !y) return LFM_ERR_ARG;
+  if (N <= 0 || HW <= 0 || C % 8) return LFM_ERR_SHAPE;
+  const long total = (long)N * HW * (C / 8);
+  hipLaunchKernelGGL(add_image_vec_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const half8_t*)x, e, e_stride, (half8_t*)y, HW,
+                     C / 8, total);
+  LFM_CHECK_LAUNCH();
+  return LFM_OK;
+}
+
 // ------------------------------------------------------------------ channel concat (th.cat([h, skip], dim=1), unet.py:649)
 __global__ void concat_c_kernel(const half8_t* __restrict__ a, const half8_t* __restrict__ b, half8_t* __restrict__ o, long pixels, int Ca8, int Cb8) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -111,6 +111,8 @@ def lib():
     L.lfm_upsample2_f16.argtypes = [V, V, I, I, I, I, V]
     L.lfm_concat_channels_f16.restype = I
     L.lfm_concat_channels_f16.argtypes = [V, V, V, LG, I, I, V]
+    L.lfm_add_image_vec_f16.restype = I
+    L.lfm_add_image_vec_f16.argtypes = [V, V, LG, V, I, I, I, V]
     L.lfm_attention_small_f16.restype = I
     L.lfm_attention_small_f16.argtypes = [V, V, I, I, I, I, V]
     L.lfm_time_embed.restype = I

@@ -47,14 +47,26 @@ class Downsample(nn.Module):  # unet.py:103-128
         self.op = nn.Conv2d(self.channels, self.out_channels, 3, stride=2, padding=1)
 
 
-class ResBlock(nn.Module):  # unet.py:131-238
-    def __init__(self, channels, emb_channels, dropout, out_channels=None, use_scale_shift_norm=False):
+class _Resample(nn.Module):
+    """Parameter-free Upsample / Downsample (use_conv=False) inside a ResBlock(up= / down=): nearest 2x / 2x2 average pool (unet.py:73-128)."""
+
+    def __init__(self, channels, up):
         super().__init__()
-        if not use_scale_shift_norm:
-            raise NotImplementedError("ResBlock without scale-shift norm is not built (the sampler always enables it)")
+        self.channels, self.up = channels, up
+
+
+class ResBlock(nn.Module):  # unet.py:131-238
+    def __init__(self, channels, emb_channels, dropout, out_channels=None, use_scale_shift_norm=False, up=False, down=False):
+        super().__init__()
         self.channels, self.out_channels = channels, out_channels or channels
+        self.use_scale_shift_norm = use_scale_shift_norm
+        self.updown = up or down
         self.in_layers = nn.Sequential(normalization(channels), nn.SiLU(), nn.Conv2d(channels, self.out_channels, 3, padding=1))
-        self.emb_layers = nn.Sequential(nn.SiLU(), nn.Linear(emb_channels, 2 * self.out_channels))
+        if self.updown:  # same attribute names as the reference (they hold no parameters)
+            self.h_upd, self.x_upd = _Resample(channels, up), _Resample(channels, up)
+        else:
+            self.h_upd = self.x_upd = nn.Identity()
+        self.emb_layers = nn.Sequential(nn.SiLU(), nn.Linear(emb_channels, 2 * self.out_channels if use_scale_shift_norm else self.out_channels))
         self.out_layers = nn.Sequential(normalization(self.out_channels), nn.SiLU(), nn.Dropout(p=dropout),
                                         nn.Conv2d(self.out_channels, self.out_channels, 3, padding=1))
         for p in self.out_layers[-1].parameters():  # zero_module (unet.py:198)
@@ -63,9 +75,10 @@ class ResBlock(nn.Module):  # unet.py:131-238
 
 
 class AttentionBlock(nn.Module):  # unet.py:241-287
-    def __init__(self, channels, num_heads=1, num_head_channels=-1):
+    def __init__(self, channels, num_heads=1, num_head_channels=-1, use_new_attention_order=False):
         super().__init__()
         self.channels = channels
+        self.use_new_attention_order = use_new_attention_order
         self.num_heads = num_heads if num_head_channels == -1 else channels // num_head_channels
         assert channels % self.num_heads == 0
         self.norm = normalization(channels)
@@ -85,8 +98,8 @@ class UNetModel(nn.Module):
                  num_heads=1, num_head_channels=-1, num_heads_upsample=-1, use_scale_shift_norm=False, resblock_updown=False,
                  use_new_attention_order=False):
         super().__init__()
-        if dims != 2 or resblock_updown or use_new_attention_order or use_fp16:
-            raise NotImplementedError("only dims=2, resblock_updown=False, use_new_attention_order=False, use_fp16=False are built")
+        if dims != 2 or use_fp16:
+            raise NotImplementedError("only dims=2, use_fp16=False are built (the HIP path computes in fp16 operands / fp32 accumulate by itself)")
         if num_heads_upsample == -1:
             num_heads_upsample = num_heads
         self.image_size, self.in_channels, self.model_channels, self.out_channels = image_size, in_channels, model_channels, out_channels
@@ -103,16 +116,18 @@ class UNetModel(nn.Module):
                 layers = [ResBlock(ch, ted, dropout, out_channels=int(mult * model_channels), use_scale_shift_norm=use_scale_shift_norm)]
                 ch = int(mult * model_channels)
                 if ds in attention_resolutions:
-                    layers.append(AttentionBlock(ch, num_heads=num_heads, num_head_channels=num_head_channels))
+                    layers.append(AttentionBlock(ch, num_heads=num_heads, num_head_channels=num_head_channels, use_new_attention_order=use_new_attention_order))
                 self.input_blocks.append(TimestepEmbedSequential(*layers))
                 chans.append(ch)
             if level != len(channel_mult) - 1:
-                self.input_blocks.append(TimestepEmbedSequential(Downsample(ch, conv_resample, out_channels=ch)))
+                self.input_blocks.append(TimestepEmbedSequential(
+                    ResBlock(ch, ted, dropout, out_channels=ch, use_scale_shift_norm=use_scale_shift_norm, down=True) if resblock_updown
+                    else Downsample(ch, conv_resample, out_channels=ch)))
                 chans.append(ch)
                 ds *= 2
         self.middle_block = TimestepEmbedSequential(
             ResBlock(ch, ted, dropout, use_scale_shift_norm=use_scale_shift_norm),
-            AttentionBlock(ch, num_heads=num_heads, num_head_channels=num_head_channels),
+            AttentionBlock(ch, num_heads=num_heads, num_head_channels=num_head_channels, use_new_attention_order=use_new_attention_order),
             ResBlock(ch, ted, dropout, use_scale_shift_norm=use_scale_shift_norm))
         self.output_blocks = nn.ModuleList([])
         for level, mult in list(enumerate(channel_mult))[::-1]:
@@ -121,9 +136,11 @@ class UNetModel(nn.Module):
                 layers = [ResBlock(ch + ich, ted, dropout, out_channels=int(model_channels * mult), use_scale_shift_norm=use_scale_shift_norm)]
                 ch = int(model_channels * mult)
                 if ds in attention_resolutions:
-                    layers.append(AttentionBlock(ch, num_heads=num_heads_upsample, num_head_channels=num_head_channels))
+                    layers.append(AttentionBlock(ch, num_heads=num_heads_upsample, num_head_channels=num_head_channels,
+                                                 use_new_attention_order=use_new_attention_order))
                 if level and i == num_res_blocks:
-                    layers.append(Upsample(ch, conv_resample, out_channels=ch))
+                    layers.append(ResBlock(ch, ted, dropout, out_channels=ch, use_scale_shift_norm=use_scale_shift_norm, up=True) if resblock_updown
+                                  else Upsample(ch, conv_resample, out_channels=ch))
                     ds //= 2
                 self.output_blocks.append(TimestepEmbedSequential(*layers))
         self.out = nn.Sequential(normalization(ch), nn.SiLU(), nn.Conv2d(input_ch, out_channels, 3, padding=1))
@@ -177,7 +194,14 @@ class UNetModel(nn.Module):
                                skip=None if isinstance(m.skip_connection, nn.Identity) else
                                (f16(m.skip_connection.weight.reshape(m.out_channels, -1)), f32(m.skip_connection.bias)))
             elif isinstance(m, AttentionBlock):
-                P[name] = dict(gn=(f32(m.norm.weight), f32(m.norm.bias)), qkv=(f16(m.qkv.weight.reshape(3 * m.channels, -1)), f32(m.qkv.bias)),
+                qw, qb = m.qkv.weight.reshape(3 * m.channels, -1), m.qkv.bias
+                if m.use_new_attention_order:
+                    # QKVAttention (unet.py:341-369) chunks [q | k | v] first and heads second; the kernel reads QKVAttentionLegacy's
+                    # [head][q | k | v][ch] rows: a one-time row permutation of qkv.weight / bias makes the two the same computation
+                    H, Cc = m.num_heads, m.channels // m.num_heads
+                    perm = torch.arange(3 * m.channels, device=qw.device).reshape(3, H, Cc).permute(1, 0, 2).reshape(-1)
+                    qw, qb = qw[perm], qb[perm]
+                P[name] = dict(gn=(f32(m.norm.weight), f32(m.norm.bias)), qkv=(f16(qw), f32(qb)),
                                proj=(f16(m.proj_out.weight.reshape(m.channels, -1)), f32(m.proj_out.bias)))
             elif isinstance(m, Downsample):
                 P[name] = conv3(m.op)
@@ -245,12 +269,28 @@ class UNetModel(nn.Module):
         p = self._packed[name]
         Cin, Cout = m.channels, m.out_channels
         t1 = self._gn(h, N, H * W, Cin, p["gn1"], None, True)
+        if m.updown:  # in_rest -> h_upd / x_upd -> in_conv (unet.py:219-224): nearest 2x or 2x2 mean on both branches
+            H2, W2 = (H * 2, W * 2) if m.h_upd.up else (H // 2, W // 2)
+            t1, h = self._resample(t1, N, H2, W2, Cin, m.h_upd.up), self._resample(h, N, H2, W2, Cin, m.h_upd.up)
+            H, W = H2, W2
         a = self._conv(t1, p["c1"], N, H, W, Cin, Cout)
         o, wdt = p["emb_slice"]
-        film = self._film_all[:, o:o + wdt]  # fp32 [N, 2*Cout] = [scale | shift], a column slice of the one emb GEMM of this evaluation
-        t2 = self._gn(a, N, H * W, Cout, p["gn2"], film, True)
+        emb_out = self._film_all[:, o:o + wdt]  # a column slice of the one emb GEMM of this evaluation
+        if m.use_scale_shift_norm:  # fp32 [N, 2*Cout] = [scale | shift] folded into the GroupNorm affine (unet.py:228-232)
+            t2 = self._gn(a, N, H * W, Cout, p["gn2"], emb_out, True)
+        else:                       # h = h + emb_out[..., None, None]; out_layers(h)  (unet.py:233-235)
+            a2 = torch.empty_like(a)
+            hip.check(hip.lib().lfm_add_image_vec_f16(hip.ptr(a), hip.ptr(emb_out), emb_out.stride(0), hip.ptr(a2), N, H * W, Cout,
+                                                      hip.stream_ptr(a.device)), "lfm_add_image_vec_f16")
+            t2 = self._gn(a2, N, H * W, Cout, p["gn2"], None, True)
         skip = h if p["skip"] is None else self._linear(h, p["skip"])
         return self._conv(t2, p["c2"], N, H, W, Cout, Cout, resid=skip)
+
+    def _resample(self, x, N, Ho, Wo, C, up):
+        y = torch.empty(N * Ho * Wo, C, dtype=torch.float16, device=x.device)
+        fn = hip.lib().lfm_upsample2_f16 if up else hip.lib().lfm_avgpool2_f16
+        hip.check(fn(hip.ptr(x), hip.ptr(y), N, Ho, Wo, C, hip.stream_ptr(x.device)), "resample")
+        return y
 
     def _attention(self, name, m, h, N, H, W):
         p = self._packed[name]
@@ -267,6 +307,8 @@ class UNetModel(nn.Module):
             name = f"{prefix}.{j}"
             if isinstance(layer, ResBlock):
                 h = self._resblock(name, layer, h, N, H, W, emb_silu)
+                if layer.updown:
+                    H, W = (H * 2, W * 2) if layer.h_upd.up else (H // 2, W // 2)
             elif isinstance(layer, AttentionBlock):
                 h = self._attention(name, layer, h, N, H, W)
             elif isinstance(layer, Downsample):

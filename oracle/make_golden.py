@@ -181,6 +181,35 @@ def golden_unet():
     return out
 
 
+def golden_unet_opts():
+    """The three UNetModel options no shipped test_args file turns on (unet.py:131-238,341-369): plain emb-add ResBlocks
+    (use_scale_shift_norm=False), ResBlock up/down sampling (resblock_updown=True), QKVAttention's channel order
+    (use_new_attention_order=True) -- all on at once, and the up/down ResBlocks with the default FiLM conditioning."""
+    sys.path.insert(0, REF)
+    from models.guided_diffusion.unet import UNetModel
+
+    out = {}
+    g = torch.Generator().manual_seed(41)
+    base = dict(image_size=16, in_channels=4, model_channels=64, out_channels=4, num_res_blocks=1, dropout=0.0, conv_resample=True, dims=2,
+                use_checkpoint=False, use_fp16=False, num_head_channels=-1, num_heads_upsample=-1, attention_resolutions=(2,), channel_mult=(1, 1),
+                num_classes=None, num_heads=2)  # 64 channels throughout: the fixture stays ~1.5 MB per configuration
+    for name, opt in {"all": (False, True, True), "updown": (True, True, False)}.items():  # every option on; up/down ResBlocks with FiLM and the legacy order
+        kw = dict(base, use_scale_shift_norm=opt[0], resblock_updown=opt[1], use_new_attention_order=opt[2])
+        torch.manual_seed(0)
+        m = UNetModel(**kw).eval()
+        _dezero_module(m, 555)
+        sd = m.state_dict()
+        for k in sd:
+            sd[k].copy_(sd[k].half().float())
+        m.load_state_dict(sd)
+        x = torch.randn(2, 4, 16, 16, generator=g)
+        t = torch.tensor([0.6, 0.3])
+        with torch.no_grad():
+            v = m(t, x)
+        out[name] = {"cfg": kw, "state_dict": {k: v_.clone().half() for k, v_ in m.state_dict().items()}, "x": x, "t": t, "v": v}
+    return out
+
+
 def golden_inpaint():
     """The conditional velocity field of the downstream samplers: the unmodified reference UNetModel with 9 input channels behind the
     reference's WrapperCondFlow (downstream_tasks/test_flow_latent_inpainting.py:80-88 -- restated here in three lines because that file
@@ -282,6 +311,7 @@ def main():
     torch.save(golden_unet(), os.path.join(OUT, "unet_tiny.pt"))
     torch.save(golden_edm(), os.path.join(OUT, "edm_tiny.pt"))
     torch.save(golden_inpaint(), os.path.join(OUT, "inpaint_tiny.pt"))
+    torch.save(golden_unet_opts(), os.path.join(OUT, "unet_opts.pt"))
     torch.save(golden_fid(), os.path.join(OUT, "fid.pt"))
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -229,3 +229,19 @@ def test_graphed_solve_replayed_after_the_device_went_idle():
     assert bool(torch.isfinite(second).all()) and bool(torch.isfinite(third).all()) and bool(torch.isfinite(eager).all())
     assert torch.equal(second, third)  # deterministic replays
     assert rel_l2(second, eager.cpu()) < 1e-5 and rel_l2(third, eager.cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("which", ["all", "updown"])
+def test_unet_options_match_reference_golden(golden_dir, which):
+    """use_scale_shift_norm=False / resblock_updown=True / use_new_attention_order=True (unet.py:131-238,341-369), all together and up/down alone, against
+    outputs of the unmodified reference UNetModel (tests/golden/unet_opts.pt)."""
+    from lfm_amd.models.unet import UNetModel
+
+    rec = torch.load(os.path.join(golden_dir, "unet_opts.pt"), map_location="cpu", weights_only=False)[which]
+    dev = torch.device("cuda:0")
+    m = UNetModel(**rec["cfg"])
+    m.load_state_dict({k: v.float() for k, v in rec["state_dict"].items()}, strict=True)
+    m = m.to(dev).eval()
+    got = m(rec["t"].to(dev), rec["x"].to(dev))
+    assert float(rec["v"].abs().mean()) > 1e-2
+    assert rel_l2(got, rec["v"]) < 3e-3
