@@ -39,7 +39,7 @@ typedef struct lfm_dit_shape {
   int depth;      /* number of DiTBlocks */
   int hidden;     /* D */
   int heads;      /* D / heads must be 64 */
-  int patch;      /* p */
+  int patch;      /* p: 2 (register patch-embed kernel), 4 or 8 (p*p*C % 64 == 0: patch embedding on the MFMA GEMM) */
   int in_ch;      /* C (4 for f8 latents) */
   int res;        /* latent side R = image_size / f */
   int mlp_hidden; /* int(D * mlp_ratio) */
@@ -71,6 +71,7 @@ typedef struct lfm_dit_weights {
   const float* fc2_b;     /* [depth, D]                                                               */
   const float* final_w;   /* [p*p*C, D]        final_layer.linear.weight                              */
   const float* final_b;   /* [p*p*C]                                                                  */
+  const void* patch_w16;  /* fp16 [D, C*p*p]: x_embedder.proj.weight as a GEMM operand; needed when p*p*C > 16 (DiT-x/4, x/8), else may be NULL */
 } lfm_dit_weights;
 
 /* One evaluation of the velocity field, with the solver update optionally fused into the last kernel. */

@@ -122,6 +122,23 @@ __global__ __launch_bounds__(320) void patch_embed_kernel(const float* __restric
   }
 }
 
+// Patch sizes with p*p*C > 16 (DiT-*/4, */8): the patch embedding is a real GEMM (K = p*p*C = 64 / 256).  This kernel gathers the patches
+// into the fp16 A operand Ap[m][k], k = (c, pp, q) as x_embedder.proj.weight flattens, and pre-fills the residual stream with the
+// position embedding; the GEMM then adds  1 * (patches W^T + bias)  through the gated-residual epilogue (gate = a row of ones).
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ x, const float* __restrict__ pos, half_t* __restrict__ Ap,
+                                                       float* __restrict__ X, float* __restrict__ ones, int M, int xmod, int C, int R, int p, int D) {
+  const int grid = R / p, T = grid * grid, KK = C * p * p;
+  const long m = blockIdx.x;
+  const int tok = (int)(m % T), n = (int)(m / T) % xmod;
+  for (int k = threadIdx.x; k < KK; k += 256) {
+    const int c = k / (p * p), pp = (k / p) % p, q = k % p;
+    Ap[m * KK + k] = (half_t)x[(((long)n * C + c) * R + (tok / grid) * p + pp) * R + (tok % grid) * p + q];
+  }
+  for (int j = threadIdx.x; j < D; j += 256) X[m * D + j] = pos[(long)tok * D + j];
+  if (m == 0)
+    for (int j = threadIdx.x; j < D; j += 256) ones[j] = 1.0f;
+}
+
 // ------------------------------------------------------------------ LayerNorm + modulate -> fp16 (DiT.py:20-21,119,129-130)
 // one wave per token row; the row stays in registers (<= 5 float4 per lane => D <= 1280).
 #define LN_MAXV 5
@@ -352,7 +369,7 @@ __global__ __launch_bounds__((T / (32 * JQ)) * 64, (T / (32 * JQ)) / 2) void dit
 // One wave owns FOUR token rows (under CFG: two conditional tokens and their two unconditional twins), so every row of the
 // output matrix Wf is fetched once per four tokens; the 4 x 16 per-lane partial dot products are then reduced with a 6-step
 // butterfly reduce-scatter (63 exchanges) that leaves lane l with the finished value of (row l>>4, output l&15).
-#define FIN_MAXO 16
+#define FIN_MAXO 256  // outputs per token p*p*C, processed 16 per pass
 template <bool CFG>
 __global__ __launch_bounds__(256) void final_layer_kernel(const float* __restrict__ X, int M, int D, int tokens, const float* __restrict__ shift,
                                                           const float* __restrict__ scale, long mod_stride, const float* __restrict__ Wf,
@@ -404,51 +421,54 @@ __global__ __launch_bounds__(256) void final_layer_kernel(const float* __restric
       if (c < nv) v[r][i] = v[r][i] * rstd * (1.0f + sc[c]) + sh[c];
     }
   }
-  float part[64];  // [r][o]
-#pragma unroll
-  for (int o = 0; o < 16; ++o) {
-    f32x4 w4[LN_MAXV];
-#pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      const int c = lane + 64 * i;
-      w4[i] = (o < NO && c < nv) ? ((const f32x4*)(Wf + (long)o * D))[c] : (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float a = 0.f;
-#pragma unroll
-      for (int i = 0; i < LN_MAXV; ++i)
-        if (lane + 64 * i < nv) a += v[r][i].x * w4[i].x + v[r][i].y * w4[i].y + v[r][i].z * w4[i].z + v[r][i].w * w4[i].w;
-      part[r * 16 + o] = a;
-    }
-  }
-  // reduce-scatter: at step s the lane bit (32 >> s) picks the upper/lower half of the remaining index range
-#pragma unroll
-  for (int s = 0; s < 6; ++s) {
-    const int half_w = 32 >> s, mask = 32 >> s;
-    const bool upper = (lane & mask) != 0;
-#pragma unroll
-    for (int k = 0; k < half_w; ++k) {
-      const float keep = upper ? part[k + half_w] : part[k];
-      const float send = upper ? part[k] : part[k + half_w];
-      part[k] = keep + __shfl_xor(send, mask, 64);
-    }
-  }
-  const int r = lane >> 4, o = lane & 15;
-  float val = part[0] + (o < NO ? bf[o] : 0.f);
-  if (CFG) {  // rows 0,1 conditional, rows 2,3 their unconditional twins: lane ^ 32 holds the twin's value
-    const float other = xhalf(val);
-    const float cond = r < 2 ? val : other, uncond = r < 2 ? other : val;
-    val = uncond + cfg_scale * (cond - uncond);
-  }
+  const int r = lane >> 4, ol = lane & 15;
   const long m = CFG ? mfirst + (r & 1) + (long)(r >> 1) * Mh : mfirst + r;
-  if (o < NO && m < M && (CFG || m < Mh)) {
-    const int grid = R / p;
-    const int n = (int)(m / tokens), tok = (int)(m % tokens);
-    const int pp = o / (p * C), qq = (o / C) % p, c = o % C;
-    const long off = (((long)n * C + c) * R + (tok / grid) * p + pp) * R + (tok % grid) * p + qq;
-    if (base) out[off] = base[off] + (*dt_ptr) * val;
-    else out[off] = val;
+  for (int o0 = 0; o0 < NO; o0 += 16) {  // 16 outputs per pass: p*p*C = 16 (patch 2) is one pass, 64 / 256 (patch 4 / 8) four / sixteen
+    float part[64];  // [r][o]
+#pragma unroll
+    for (int o = 0; o < 16; ++o) {
+      f32x4 w4[LN_MAXV];
+#pragma unroll
+      for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        w4[i] = (o0 + o < NO && c < nv) ? ((const f32x4*)(Wf + (long)(o0 + o) * D))[c] : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i)
+          if (lane + 64 * i < nv) a += v[rr][i].x * w4[i].x + v[rr][i].y * w4[i].y + v[rr][i].z * w4[i].z + v[rr][i].w * w4[i].w;
+        part[rr * 16 + o] = a;
+      }
+    }
+    // reduce-scatter: at step s the lane bit (32 >> s) picks the upper/lower half of the remaining index range
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+      const int half_w = 32 >> s, mask = 32 >> s;
+      const bool upper = (lane & mask) != 0;
+#pragma unroll
+      for (int k = 0; k < half_w; ++k) {
+        const float keep = upper ? part[k + half_w] : part[k];
+        const float send = upper ? part[k] : part[k + half_w];
+        part[k] = keep + __shfl_xor(send, mask, 64);
+      }
+    }
+    const int o = o0 + ol;
+    float val = part[0] + (o < NO ? bf[o] : 0.f);
+    if (CFG) {  // rows 0,1 conditional, rows 2,3 their unconditional twins: lane ^ 32 holds the twin's value
+      const float other = xhalf(val);
+      const float cond = r < 2 ? val : other, uncond = r < 2 ? other : val;
+      val = uncond + cfg_scale * (cond - uncond);
+    }
+    if (o < NO && m < M && (CFG || m < Mh)) {
+      const int grid = R / p;
+      const int n = (int)(m / tokens), tok = (int)(m % tokens);
+      const int pp = o / (p * C), qq = (o / C) % p, c = o % C;
+      const long off = (((long)n * C + c) * R + (tok / grid) * p + pp) * R + (tok % grid) * p + qq;
+      if (base) out[off] = base[off] + (*dt_ptr) * val;
+      else out[off] = val;
+    }
   }
 }
 
@@ -489,6 +509,7 @@ struct DitWs {
   float* temb_h;  // [B, D] hidden layer of the t-MLP
   half_t* c_half; // [B, D]
   float* mod;     // [B, J]
+  float* ones;    // [D] of 1.0f: gate row of the patch-embedding GEMM (large patches)
   float* slab;    // split-K partial tiles (small M only, else null)
   size_t slab_bytes;
   size_t total;
@@ -513,6 +534,7 @@ static DitWs carve(const lfm_dit_shape* s, int B, void* ws, bool sizing = false)
   w.temb_h = (float*)take((size_t)B * D * 4);
   w.c_half = (half_t*)take((size_t)B * D * 2);
   w.mod = (float*)take((size_t)B * J * 4);
+  w.ones = (float*)take(D * 4);
   // latency mode: room for up to 4 K slices of the widest GEMM output (fc1), when the token count is small
   // (when SIZING for a maximum batch, reserve the slabs of the largest small batch too, so that the requirement is monotone in the
   // batch and a workspace sized for max_batch serves every smaller batch)
@@ -532,7 +554,8 @@ static int check_shape(const lfm_dit_shape* s) {
   const int T = (s->res / s->patch) * (s->res / s->patch);
   if (T != 64 && T != 128 && T != 256) return LFM_ERR_SHAPE;
   if (s->hidden % 64 || s->hidden > 256 * LN_MAXV || s->mlp_hidden % 64) return LFM_ERR_SHAPE;
-  if (s->patch * s->patch * s->in_ch > FIN_MAXO || s->patch * s->patch * s->in_ch > PE_MAXK) return LFM_ERR_SHAPE;
+  const int kk = s->patch * s->patch * s->in_ch;
+  if (kk > FIN_MAXO || (kk > PE_MAXK && (kk % 64))) return LFM_ERR_SHAPE;  // small patches: register kernel; large: GEMM (K % 64 == 0)
   if (s->label_rows <= 0) return LFM_ERR_SHAPE;
   return LFM_OK;
 }
@@ -703,9 +726,20 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
   rc = launch_gemm_tn(ASrcRowMajor{ws.c_half, D, rows, 0}, (const half_t*)w->ada_w, D, rows, (int)J, D, EpiBiasF32{ws.mod, J, w->ada_b}, st);
   if (rc) return rc;
 
-  hipLaunchKernelGGL(patch_embed_kernel, dim3(cdiv(M, PE_TOK)), dim3(D / 4), 0, st, c->x, w->patch_w, w->patch_b, w->pos_embed, ws.X, M,
-                     cfg ? B / 2 : B, s->in_ch, s->res, s->patch, D);
-  LFM_CHECK_LAUNCH();
+  const int KK = s->in_ch * s->patch * s->patch;
+  if (KK <= PE_MAXK) {
+    hipLaunchKernelGGL(patch_embed_kernel, dim3(cdiv(M, PE_TOK)), dim3(D / 4), 0, st, c->x, w->patch_w, w->patch_b, w->pos_embed, ws.X, M,
+                       cfg ? B / 2 : B, s->in_ch, s->res, s->patch, D);
+    LFM_CHECK_LAUNCH();
+  } else {  // DiT-*/4, */8: patches -> fp16 A operand (in the LN buffer, free at this point), X = pos_embed, then X += patches W^T + bias on MFMA
+    if (!w->patch_w16) return LFM_ERR_ARG;
+    hipLaunchKernelGGL(patchify_kernel, dim3(M), dim3(256), 0, st, c->x, w->pos_embed, ws.A, ws.X, ws.ones, M, cfg ? B / 2 : B, s->in_ch, s->res,
+                       s->patch, D);
+    LFM_CHECK_LAUNCH();
+    rc = launch_gemm_auto(ASrcRowMajor{ws.A, KK, M, 0}, (const half_t*)w->patch_w16, KK, M, D, KK,
+                          EpiGateResidF32{ws.X, D, w->patch_b, ws.ones, 0, T}, st);
+    if (rc) return rc;
+  }
 
   half_t* Qb = ws.QKVH;
   half_t* Kb = Qb + (size_t)M * D;

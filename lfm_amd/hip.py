@@ -18,7 +18,7 @@ class DitShape(C.Structure):
 
 
 _DIT_WEIGHT_FIELDS = ("pos_embed", "patch_w", "patch_b", "t_w0", "t_b0", "t_w2", "t_b2", "y_table", "ada_w", "ada_b",
-                      "qkv_w", "qkv_b", "proj_w", "proj_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "final_w", "final_b")
+                      "qkv_w", "qkv_b", "proj_w", "proj_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "final_w", "final_b", "patch_w16")
 
 
 class DitWeights(C.Structure):

@@ -180,6 +180,7 @@ class DiT(nn.Module):
             "fc1_w": f16(torch.stack([b.mlp.fc1.weight for b in B])), "fc1_b": f32(torch.stack([b.mlp.fc1.bias for b in B])),
             "fc2_w": f16(torch.stack([b.mlp.fc2.weight for b in B])), "fc2_b": f32(torch.stack([b.mlp.fc2.bias for b in B])),
             "final_w": f32(self.final_layer.linear.weight), "final_b": f32(self.final_layer.linear.bias),
+            "patch_w16": f16(self.x_embedder.proj.weight.reshape(self.hidden_size, -1)),  # GEMM operand of the patch embedding (patch 4 / 8)
         }
         w = hip.DitWeights(**{k: v.data_ptr() for k, v in keep.items()})
         self._packed = (w, keep, self.shape_struct())

@@ -83,6 +83,31 @@ def golden_dit(ref_dit):
     return out
 
 
+def golden_dit_p4(ref_dit):
+    """Patch size 4 (the DiT-x/4 family, models/DiT.py:358-371): 64 tokens of 4x4x4 = 64 inputs each; forward and forward_with_cfg."""
+    g = torch.Generator().manual_seed(52)
+    kw = dict(num_classes=10, label_dropout=0.1)
+    torch.manual_seed(0)
+    m = ref_dit.DiT(img_resolution=32, patch_size=4, in_channels=4, hidden_size=128, depth=1, num_heads=2, **kw).eval()
+    nz = _dezero_module(m, 4321)
+    sd = m.state_dict()
+    for k in sd:
+        if k.endswith(".bias"):
+            sd[k].copy_(torch.randn(sd[k].shape, generator=g) * 0.02)
+    m.load_state_dict(sd)
+    x = torch.randn(3, 4, 32, 32, generator=g)
+    y = torch.tensor([3, 0, 9])
+    rec = {"cfg": dict(depth=1, hidden=128, patch=4, heads=2, img_resolution=32, in_channels=4, **kw),
+           "state_dict": {k: v.clone() for k, v in m.state_dict().items()}, "x": x, "y": y, "dezeroed": nz}
+    with torch.no_grad():
+        rec["v_tN"] = m(torch.tensor([0.9, 0.5, 0.02]), x, y)
+        x2 = torch.cat([x[:2], x[:2]], 0)
+        y2 = torch.tensor([3, 7, 10, 10])
+        rec["x_cfg"], rec["y_cfg"], rec["cfg_scale"] = x2, y2, 1.5
+        rec["v_cfg"] = m.forward_with_cfg(torch.tensor(0.37), x2, y2, cfg_scale=1.5)
+    return rec
+
+
 def golden_karras(ref_karras, ref_rand):
     """sample_euler / sample_heun on a cheap nonlinear field; includes the steps=40 quirk."""
     g = torch.Generator().manual_seed(7)
@@ -305,6 +330,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     ref_dit, ref_karras, ref_rand = _import_reference()
     torch.save(golden_dit(ref_dit), os.path.join(OUT, "dit_tiny.pt"))
+    torch.save(golden_dit_p4(ref_dit), os.path.join(OUT, "dit_p4.pt"))
     torch.save(golden_karras(ref_karras, ref_rand), os.path.join(OUT, "karras.pt"))
     torch.save(golden_karras_rng(ref_karras, ref_rand), os.path.join(OUT, "karras_rng.pt"))
     torch.save(golden_randgen(ref_rand), os.path.join(OUT, "randgen.pt"))

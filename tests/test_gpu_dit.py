@@ -222,6 +222,31 @@ def test_dit_matches_reference_golden(dev, golden_dir, which):
         assert rel_l2(got, rec["v_cfg"]) < 2e-3
 
 
+def test_dit_patch4_matches_reference_golden(dev, golden_dir):
+    """DiT-x/4 family: the patch embedding runs on the MFMA GEMM (K = 64), the final layer emits 64 outputs per token in four passes.
+    Golden from the unmodified reference (tests/golden/dit_p4.pt); then DiT-S/4 and DiT-B/4 at full size against the oracle."""
+    rec = _load(golden_dir, "dit_p4.pt")
+    m = _model_from_state(rec["cfg"], rec["state_dict"], dev)
+    x, y = rec["x"].to(dev), rec["y"].to(dev)
+    assert rel_l2(m(torch.tensor([0.9, 0.5, 0.02], device=dev), x, y), rec["v_tN"]) < 2e-3
+    got = m.forward_with_cfg(torch.tensor(0.37, device=dev), rec["x_cfg"].to(dev), rec["y_cfg"].to(dev), cfg_scale=rec["cfg_scale"])
+    assert rel_l2(got, rec["v_cfg"]) < 2e-3
+    from lfm_amd.models import DiT_models
+
+    for name, batch in (("DiT-S/4", 5), ("DiT-B/4", 2)):
+        kw = dict(num_classes=10, label_dropout=0.1)
+        cfg = dit_ref.DiTCfg.named(name, **kw)
+        sd = dit_ref.make_dit_state(cfg, seed=4)
+        mm = DiT_models[name](img_resolution=32, in_channels=4, **kw)
+        mm.load_state_dict(sd, strict=True)
+        mm = mm.to(dev).eval()
+        g = torch.Generator().manual_seed(8)
+        xx = torch.randn(batch, 4, 32, 32, generator=g)
+        yy = torch.randint(0, 10, (batch,), generator=g)
+        t = torch.linspace(0.2, 0.9, batch)
+        assert rel_l2(mm(t.to(dev), xx.to(dev), yy.to(dev)), dit_ref.dit_forward(sd, cfg, t, xx, yy)) < 2e-3, name
+
+
 @pytest.mark.parametrize("name,batch,kw", [
     ("DiT-B/2", 4, dict(num_classes=1, label_dropout=0.0)),      # BASELINE config 1 shape
     ("DiT-B/2", 6, dict(num_classes=1000, label_dropout=0.1)),   # config 4 shape (class-conditional)
