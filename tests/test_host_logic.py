@@ -303,3 +303,14 @@ def test_flow_matching_pair_defines_the_sampled_ode():
     torch.testing.assert_close((zt2 - zt) / eps, u, rtol=1e-2, atol=1e-3)
     loss = flow_matching_loss(lambda t, x, y: torch.zeros_like(x), z0, generator=torch.Generator().manual_seed(1))
     assert float(loss) > 0
+
+
+def test_unbuilt_dit_shapes_are_refused_at_construction():
+    from lfm_amd.models import DiT_models
+
+    with pytest.raises(NotImplementedError):
+        DiT_models["DiT-XL/2"](img_resolution=32, in_channels=4, num_classes=1, label_dropout=0.0)   # head_dim 72
+    with pytest.raises(NotImplementedError):
+        DiT_models["DiT-B/8"](img_resolution=32, in_channels=4, num_classes=1, label_dropout=0.0)    # 16 tokens
+    DiT_models["DiT-S/4"](img_resolution=32, in_channels=4, num_classes=1, label_dropout=0.0)        # 64 tokens, K = 64: built
+    DiT_models["DiT-S/8"](img_resolution=64, in_channels=4, num_classes=1, label_dropout=0.0)        # 64 tokens, K = 256: built
