@@ -154,12 +154,14 @@ def test_gemm_rejects_bad_shapes(dev):
         hip.gemm_f16(A, W)
 
 
-@pytest.mark.parametrize("D,tokens,shared", [(1024, 256, False), (768, 256, True), (384, 64, False), (128, 256, False)])
-def test_ln_modulate(dev, D, tokens, shared):
+@pytest.mark.parametrize("D,tokens,shared,n_img", [(1024, 256, False, 3), (768, 256, True, 3), (384, 64, False, 3), (128, 256, False, 3),
+                                                   (1024, 256, True, 20), (384, 100, False, 43), (1152, 64, False, 70)])
+def test_ln_modulate(dev, D, tokens, shared, n_img):
+    """Two rows per wave; up to 5120 rows and a ragged last block.  (A row-walking variant -- 8 rows per wave with the next row's loads in
+    flight -- measured 22.5 us vs 21.4 us at the benchmark shape and was not kept.)"""
     from lfm_amd import hip
 
     g = torch.Generator().manual_seed(D)
-    n_img = 3
     X = torch.randn(n_img * tokens, D, generator=g) * 2 + 0.3
     rows = 1 if shared else n_img
     shift, scale = torch.randn(rows, D, generator=g) * 0.2, torch.randn(rows, D, generator=g) * 0.2

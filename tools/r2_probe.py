@@ -56,5 +56,8 @@ for vn, sel in variants:
     print(f"attention b={Bh} h={heads} T={T} {vn:14s}: {ms*1e3:.1f} us  {4*Bh*heads*T*T*64/ms/1e9:.0f} TFLOP/s  {4*Bh*T*1024*2/ms/1e6:.0f} GB/s", flush=True)
 hip.gemm_select(0)
 X = torch.randn(Bh * T, 1024, device=dev); sh = torch.randn(1, 1024, device=dev); sc = torch.randn(1, 1024, device=dev)
-ms = statistics.median([timeit(lambda: hip.ln_modulate(X, sh, sc, T, 0), n=20) for _ in range(3)])
-print(f"ln_modulate M={Bh*T} D=1024: {ms*1e3:.1f} us  {Bh*T*1024*6/ms/1e6:.0f} GB/s")
+for vn, sel in variants:
+    hip.gemm_select(sel)
+    ms = statistics.median([timeit(lambda: hip.ln_modulate(X, sh, sc, T, 0), n=20) for _ in range(3)])
+    print(f"ln_modulate M={Bh*T} D=1024 {vn:14s}: {ms*1e3:.1f} us  {Bh*T*1024*6/ms/1e6:.0f} GB/s", flush=True)
+hip.gemm_select(0)
