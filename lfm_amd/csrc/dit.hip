@@ -1,7 +1,7 @@
 // DiT velocity field on gfx950: the kernels around the MFMA GEMMs and the per-call driver.
 // Reference behaviour: /root/reference/models/DiT.py (cited per kernel).
 #include "../../include/lfm_hip.h"
-#include "gemm256q_kernel.h"
+#include "gemm_dispatch.h"
 
 static int g_gemm_sel = 0;
 int lfm_gemm_selected() { return g_gemm_sel; }
@@ -17,8 +17,8 @@ int lfm_gemm_prefers_v4(int M, int N, int K) {
   if (g_gemm_dbg & 8192) return 1;
   return 0;
 }
-extern "C" int lfm_gemm_select(int which) {  // low 4 bits: kernel choice (0 auto, 1..4); bits 4+: ablation flags (measurement only)
-  if ((which & 15) > 4 || which < 0) return LFM_ERR_ARG;
+extern "C" int lfm_gemm_select(int which) {  // low 4 bits: kernel choice (0 auto, 1..5); bits 4+: ablation flags (measurement only)
+  if ((which & 15) > 5 || which < 0) return LFM_ERR_ARG;
   g_gemm_sel = which & 15;
   g_gemm_dbg = which >> 4;
   return LFM_OK;

@@ -1,0 +1,414 @@
+// 256x256 quadrant-phased MFMA GEMM on v_mfma_f32_16x16x32_f16 (v5):  C[m][n] = sum_k A[m][k] * W[n][k]  (+ fused epilogue).
+//
+// Why (tools/ubench/mfma_shape.hip, profiles/r02_mfma_shape.txt): the GEMMs of this path run under the board POWER cap, not under an
+// issue or bandwidth limit -- and on random fp16 operands a pure stream of 16x16x32 MFMAs sustains 1930 TFLOP/s where the 32x32x16
+// stream that v1-v4 use sustains 1660 (both 2450 on zeros): the small shape moves 20 % fewer register-file bytes per flop (4
+// accumulator registers per instruction instead of 16).  Energy per flop is the lever under a power cap, so this generation keeps
+// v3's structure unchanged -- LDS image, piece-granular LDS-DMA ring, quadrant phases, one barrier per phase, counted waits,
+// ping-pong wave groups, tile order (gemm256q_kernel.h) -- and changes only the instruction and what follows from its fragment maps:
+//
+//   operand fragments  lane l holds 8 consecutive k of row (l & 15) at k-group (l >> 4): one ds_read_b128 of logical chunk
+//                      4*ks + (l >> 4) of a 128-byte LDS row (ks = 0, 1 per 64-deep K-tile); the same 12 / 4 / 8 / 0 reads per phase as v3;
+//   accumulators       a wave's 128 x 64 block = 8 (m) x 4 (n) tiles of f32x4; issued with W as the A operand, so lane l owns
+//                      C[m = 16 i + (l & 15)][n = 16 j + 4 (l >> 4) + r], r = 0..3: four consecutive n per lane as before;
+//   epilogue           the same LDS-transposed row-major hand-over (shared Epi interface), with the scratch filled from the new map.
+#pragma once
+#include "gemm256q_kernel.h"
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// ---- epilogue for the 16x16 accumulator map.  acc[i][j]: tile i (16 rows) x j (16 columns) of the wave's 128 x 64 block.
+// fill32(I, scr): rows 32 I .. 32 I + 31 of the block -> scratch [32][64 + pad] fp32, row stride 272 B (as g256_epilogue_rows)
+template <int BN, class Epi>
+__device__ __forceinline__ void g256h_epilogue_rows(f32x4_t (&acc)[8][4], char* smem, const Epi& epi, int m0, int n0, int M, int N, int g, int wn,
+                                                    int lane, int wave, bool narrow) {
+  char* scr = smem + wave * (32 * 272);
+  const bool interior = (m0 + G256_BM <= M) && (n0 + BN <= N);
+  const int l15 = lane & 15, l4 = lane >> 4;
+  auto fill32 = [&](int I) {
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *(f32x4_t*)(scr + (h2 * 16 + l15) * 272 + (j * 16 + l4 * 4) * 4) = acc[2 * I + h2][j];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  if constexpr (epi_has_store8<Epi>::value) {
+    if (!narrow && epi.wide_ok()) {
+      const int rrow = lane >> 3, rcol = lane & 7;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fill32(i);
+        f32x4 lo[4], hi[4];
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+          lo[ps] = *(const f32x4*)(scr + (ps * 8 + rrow) * 272 + rcol * 32);
+          hi[ps] = *(const f32x4*)(scr + (ps * 8 + rrow) * 272 + rcol * 32 + 16);
+        }
+        const int mb = m0 + g * 128 + i * 32 + rrow, n = n0 + wn * 64 + rcol * 8;
+        if (interior) {
+          typename Epi::Aux al[4], ah[4];
+#pragma unroll
+          for (int ps = 0; ps < 4; ++ps) {
+            al[ps] = epi.load(mb + ps * 8, n);
+            ah[ps] = epi.load(mb + ps * 8, n + 4);
+          }
+#pragma unroll
+          for (int ps = 0; ps < 4; ++ps) epi.store8(mb + ps * 8, n, lo[ps], hi[ps], al[ps], ah[ps]);
+        } else {
+#pragma unroll
+          for (int ps = 0; ps < 4; ++ps) {
+            const int m = mb + ps * 8;
+            if (m >= M) continue;
+            if (n + 7 < N) epi.store8(m, n, lo[ps], hi[ps], epi.load(m, n), epi.load(m, n + 4));
+            else if (n + 3 < N) epi.store(m, n, lo[ps], epi.load(m, n));
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      return;
+    }
+  }
+  const int rrow = lane >> 4, rcol = lane & 15;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    fill32(i);
+    f32x4 v[8];
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) v[ps] = *(const f32x4*)(scr + (ps * 4 + rrow) * 272 + rcol * 16);
+    const int mb = m0 + g * 128 + i * 32 + rrow, n = n0 + wn * 64 + rcol * 4;
+    if (interior) {
+      typename Epi::Aux aux[8];
+#pragma unroll
+      for (int ps = 0; ps < 8; ++ps) aux[ps] = epi.load(mb + ps * 4, n);
+#pragma unroll
+      for (int ps = 0; ps < 8; ++ps) epi.store(mb + ps * 4, n, v[ps], aux[ps]);
+    } else if (n + 3 < N) {
+#pragma unroll
+      for (int ps = 0; ps < 8; ++ps)
+        if (mb + ps * 4 < M) epi.store(mb + ps * 4, n, v[ps], epi.load(mb + ps * 4, n));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+template <int BN, class Epi>
+__device__ __forceinline__ void g256h_epilogue(f32x4_t (&acc)[8][4], char* smem, Epi& epi, int m0, int n0, int M, int N, int g, int wn, int lane,
+                                               int wave, int bz, long bsC, int dbg, bool swapped) {
+  epi_batch(epi, bz, bsC, 0);
+  if (dbg & 4) return;  // ablation: no epilogue
+  const int l15 = lane & 15, l4 = lane >> 4;
+  if constexpr (epi_has_transposed<Epi>::value) {
+    // The K loop ran this tile with the MFMA operands swapped: acc[i][j][r] = C[m = 16 i + 4 l4 + r][n = 16 j + l15], FOUR CONSECUTIVE m per
+    // lane.  Scratch rows = 32 columns n (tiles 2 J, 2 J + 1), scratch columns = 64 rows m (tiles 4 ih .. 4 ih + 3); read back row-major:
+    // a lane gets 8 (or 4) consecutive m of one n -> epi.store_t8 / store_t.
+    if (swapped) {
+      char* scr = smem + wave * (32 * 272);
+      const bool wide = !(dbg & 1024) && epi.wide_t_ok();
+#pragma unroll
+      for (int J = 0; J < 2; ++J) {
+#pragma unroll
+        for (int ih = 0; ih < 2; ++ih) {
+#pragma unroll
+          for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4)
+              *(f32x4_t*)(scr + (j2 * 16 + l15) * 272 + (i4 * 16 + l4 * 4) * 4) = acc[4 * ih + i4][2 * J + j2];
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (wide) {
+            const int rrow = lane >> 3, rcol = lane & 7;
+            const int nb = n0 + wn * 64 + J * 32 + rrow, m = m0 + g * 128 + ih * 64 + rcol * 8;
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+              const f32x4 lo = *(const f32x4*)(scr + (ps * 8 + rrow) * 272 + rcol * 32);
+              const f32x4 hi = *(const f32x4*)(scr + (ps * 8 + rrow) * 272 + rcol * 32 + 16);
+              const int n = nb + ps * 8;
+              if (n >= N) continue;
+              const float b = epi.load_t(n);
+              if (m + 7 < M) epi.store_t8(n, m, lo, hi, b);
+              else if (m + 3 < M) epi.store_t(n, m, lo, b);
+            }
+          } else {
+            const int rrow = lane >> 4, rcol = lane & 15;
+            const int nb = n0 + wn * 64 + J * 32 + rrow, m = m0 + g * 128 + ih * 64 + rcol * 4;
+#pragma unroll
+            for (int ps = 0; ps < 8; ++ps) {
+              const f32x4 v = *(const f32x4*)(scr + (ps * 4 + rrow) * 272 + rcol * 16);
+              const int n = nb + ps * 4;
+              if (n < N && m + 3 < M) epi.store_t(n, m, v, epi.load_t(n));
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+      }
+      return;
+    }
+  }
+  if (epi_direct(epi, n0, 0)) {  // epilogues that want the fragment layout: (m, n..n+3) per lane straight from the accumulators
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + g * 128 + i * 16 + l15;
+      if (m >= M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + l4 * 4;
+        if (n + 3 < N) {
+          f32x4 v = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+          epi.store(m, n, v, epi.load(m, n));
+        }
+      }
+    }
+    return;
+  }
+  if constexpr (epi_has_plain<Epi>::value) {
+    if (epi.plain_tile(n0, BN)) {
+      auto pe = epi.plain(n0);
+      g256h_epilogue_rows<BN>(acc, smem, pe, m0, n0, M, N, g, wn, lane, wave, (dbg & 1024) != 0);
+      return;
+    }
+  }
+  g256h_epilogue_rows<BN>(acc, smem, epi, m0, n0, M, N, g, wn, lane, wave, (dbg & 1024) != 0);
+}
+
+template <class ASrc, class Epi>
+__global__ __launch_bounds__(512) void gemm256h_tn_kernel(ASrc asrc, const half_t* __restrict__ W, long ldw, int M, int N, int K, int tiles_n,
+                                                           Epi epi, long bsA, long bsW, long bsC, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = wave >> 2, wn = wave & 3;
+
+  int tile_m, tile_n;
+  g256_tile_order(blockIdx.x, gridDim.x, tiles_n, dbg, tile_m, tile_n);
+  const int m0 = tile_m * G256_BM, n0 = tile_n * G256_BN;
+  bool swapped = false;
+  if constexpr (epi_has_transposed<Epi>::value) swapped = epi.transposed(n0);
+  const int bz = blockIdx.y;
+  asrc.init(bz, bsA);
+  W += (long)bz * bsW;
+
+  // ---- DMA sources: identical to v3 (piece = 128 local rows x 128 B; thread tid stages chunks tid and 512 + tid)
+  typename ASrc::Row arow[2][2];  // [sub][pass]
+  const half_t* wrow[2][2];
+  const int cswz = ((tid & 7) ^ ((tid >> 4) & 7)) * 8;
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      arow[s][p] = asrc.row(m0 + p * 128 + s * 64 + (tid >> 3));
+      const int n = n0 + (p * 2 + (tid >> 8)) * 64 + s * 32 + ((tid >> 3) & 31);
+      wrow[s][p] = W + (long)(n < N ? n : N - 1) * ldw + cswz;
+    }
+  const int nk = K / G256Q_BK;
+  const int dma_off = wave * 1024;
+  auto issue_a = [&](int s, char* slot) {
+    glds16(asrc.ptr(arow[s][0], cswz), slot + dma_off);
+    glds16(asrc.ptr(arow[s][1], cswz), slot + 8192 + dma_off);
+  };
+  auto issue_b = [&](int s, int kt, char* slot) {
+    glds16(wrow[s][0] + kt * G256Q_BK, slot + dma_off);
+    glds16(wrow[s][1] + kt * G256Q_BK, slot + 8192 + dma_off);
+  };
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  // fragment reads: lane (r = lane&15, q = lane>>4) reads logical chunk 4*ks + q of local row base + r; key(row) = (row>>1)&7 and the
+  // 16-row tile bases are multiples of 16, so the key depends on the lane only
+  const int rkey = ((lane & 15) >> 1) & 7, q4 = lane >> 4;
+  int a_addr[2], w_addr[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    a_addr[ks] = (g * 64 + (lane & 15)) * 128 + (((ks * 4 + q4) ^ rkey) << 4);   // + i4 * 2048 (16 rows)
+    w_addr[ks] = (wn * 32 + (lane & 15)) * 128 + (((ks * 4 + q4) ^ rkey) << 4);  // + j2 * 2048
+  }
+  half8_t af[4][2], wf[4][2];  // A: [16-row tile of the current sub][k32 step];  W: [16-column tile 0..3 (sub0: 0,1; sub1: 2,3)][k32 step]
+  auto lds_read = [&](half8_t& dst, int addr, auto OFFC) {
+    constexpr int OFF = decltype(OFFC)::value;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+  };
+#define G256H_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define G256H_LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
+
+  // LOAD part of phase PH of K-tile t: fragment reads in consumption order (k32-step major), one piece staged, counted wait (v3, SCHED 1)
+  auto load_part = [&](auto PHC, auto BUFC, int t, bool s1, bool s2) {
+    constexpr int PH = decltype(PHC)::value, BUF = decltype(BUFC)::value, HI = BUF * G256Q_BUF_BYTES;
+    char* cur = smem + BUF * G256Q_BUF_BYTES;
+    char* oth = smem + (BUF ^ 1) * G256Q_BUF_BYTES;
+    if constexpr (PH == 0) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        lds_read(wf[0][ks], w_addr[ks] + HI, g256q_ic<G256Q_SLOT_B0>{});
+        lds_read(wf[1][ks], w_addr[ks] + HI, g256q_ic<G256Q_SLOT_B0 + 2048>{});
+        lds_read(af[0][ks], a_addr[ks] + HI, g256q_ic<G256Q_SLOT_A0>{});
+        lds_read(af[1][ks], a_addr[ks] + HI, g256q_ic<G256Q_SLOT_A0 + 2048>{});
+        lds_read(af[2][ks], a_addr[ks] + HI, g256q_ic<G256Q_SLOT_A0 + 4096>{});
+        lds_read(af[3][ks], a_addr[ks] + HI, g256q_ic<G256Q_SLOT_A0 + 6144>{});
+      }
+    } else if constexpr (PH == 1) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        lds_read(wf[2][ks], w_addr[ks] + HI, g256q_ic<G256Q_SLOT_B1>{});
+        lds_read(wf[3][ks], w_addr[ks] + HI, g256q_ic<G256Q_SLOT_B1 + 2048>{});
+      }
+    } else if constexpr (PH == 2) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        lds_read(af[0][ks], a_addr[ks] + HI, g256q_ic<G256Q_SLOT_A1>{});
+        lds_read(af[1][ks], a_addr[ks] + HI, g256q_ic<G256Q_SLOT_A1 + 2048>{});
+        lds_read(af[2][ks], a_addr[ks] + HI, g256q_ic<G256Q_SLOT_A1 + 4096>{});
+        lds_read(af[3][ks], a_addr[ks] + HI, g256q_ic<G256Q_SLOT_A1 + 6144>{});
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (PH == 0) {
+      if (s1) issue_b(1, t + 1, oth + G256Q_SLOT_B1);
+    } else if constexpr (PH == 1) {
+      if (s1) issue_a(1, oth + G256Q_SLOT_A1);
+    } else if constexpr (PH == 2) {
+      if (s2) {
+        asrc.begin_tile(t + 2, G256Q_BK);
+        issue_a(0, cur + G256Q_SLOT_A0);
+      }
+    } else {
+      if (s2) issue_b(0, t + 2, cur + G256Q_SLOT_B0);
+    }
+    if (s2) G256H_VMCNT(6);  // pieces allowed in flight: 3 3 3 3 | 3 3 2 1 | 0 0 0 0
+    else if (s1) {
+      if constexpr (PH < 2) G256H_VMCNT(6);
+      else if constexpr (PH == 2) G256H_VMCNT(4);
+      else G256H_VMCNT(2);
+    } else G256H_VMCNT(0);
+  };
+  // MFMA part of phase PH: one 64 x 32 quadrant x K = 64 = 16 MFMAs of 16x16x32, every group of 2 behind a counted lgkmcnt
+  auto mfma_part = [&](auto PHC, auto SWC) {
+    constexpr int PH = decltype(PHC)::value;
+    constexpr bool SW = decltype(SWC)::value != 0;
+    constexpr int I0 = (PH >= 2) ? 4 : 0, J0 = (PH == 1 || PH == 2) ? 2 : 0;
+    if (!(dbg & 8)) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i4 = 0; i4 < 4; ++i4) {
+        if constexpr (PH == 0) {  // 12 reads, per k32 step: W0 W1 A0 A1 A2 A3
+          if (ks == 0) {
+            if (i4 == 0) G256H_LGKM(9);
+            else if (i4 == 1) G256H_LGKM(8);
+            else if (i4 == 2) G256H_LGKM(7);
+            else G256H_LGKM(6);
+          } else {
+            if (i4 == 0) G256H_LGKM(3);
+            else if (i4 == 1) G256H_LGKM(2);
+            else if (i4 == 2) G256H_LGKM(1);
+            else G256H_LGKM(0);
+          }
+        } else if constexpr (PH == 1) {  // 4 reads: W2 W3 (ks 0), W2 W3 (ks 1)
+          if (i4 == 0) {
+            if (ks == 0) G256H_LGKM(2);
+            else G256H_LGKM(0);
+          }
+        } else if constexpr (PH == 2) {  // 8 reads: A0..A3 (ks 0), A0..A3 (ks 1)
+          if (ks == 0) {
+            if (i4 == 0) G256H_LGKM(7);
+            else if (i4 == 1) G256H_LGKM(6);
+            else if (i4 == 2) G256H_LGKM(5);
+            else G256H_LGKM(4);
+          } else {
+            if (i4 == 0) G256H_LGKM(3);
+            else if (i4 == 1) G256H_LGKM(2);
+            else if (i4 == 2) G256H_LGKM(1);
+            else G256H_LGKM(0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j2 = 0; j2 < 2; ++j2) {
+          if constexpr (SW) acc[I0 + i4][J0 + j2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i4][ks], wf[J0 + j2][ks], acc[I0 + i4][J0 + j2], 0, 0, 0);
+          else acc[I0 + i4][J0 + j2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[J0 + j2][ks], af[i4][ks], acc[I0 + i4][J0 + j2], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // ---- prologue: pieces A0(0) B0(0) B1(0) A1(0) [A0(1) B0(1)]
+  asrc.begin_tile(0, G256Q_BK);
+  issue_a(0, smem + G256Q_SLOT_A0);
+  issue_b(0, 0, smem + G256Q_SLOT_B0);
+  issue_b(1, 0, smem + G256Q_SLOT_B1);
+  issue_a(1, smem + G256Q_SLOT_A1);
+  if (nk > 1) {
+    asrc.begin_tile(1, G256Q_BK);
+    issue_a(0, smem + G256Q_BUF_BYTES + G256Q_SLOT_A0);
+    issue_b(0, 1, smem + G256Q_BUF_BYTES + G256Q_SLOT_B0);
+  }
+  if (nk > 1) G256H_VMCNT(6);
+  else G256H_VMCNT(2);
+  G256_BARRIER();
+  // ONE barrier per phase: group 0 runs MFMA(p), LOAD(p+1); group 1 runs LOAD(p), MFMA(p) (hazard analysis: gemm256q_kernel.h)
+  auto run = [&](auto GC, auto SWC) {
+    constexpr int G = decltype(GC)::value;
+    if constexpr (G == 0) load_part(g256q_ic<0>{}, g256q_ic<0>{}, 0, 1 < nk, 2 < nk);
+    G256_BARRIER();
+    auto tile = [&](auto BUFC, int t) {
+      constexpr int BUF = decltype(BUFC)::value;
+      const bool s1 = t + 1 < nk, s2 = t + 2 < nk, s3 = t + 3 < nk;
+      auto phase = [&](auto PHC) {
+        constexpr int PH = decltype(PHC)::value;
+        if constexpr (G == 0) {
+          mfma_part(PHC, SWC);
+          if constexpr (PH < 3) load_part(g256q_ic<PH + 1>{}, BUFC, t, s1, s2);
+          else if (s1) load_part(g256q_ic<0>{}, g256q_ic<(BUF ^ 1)>{}, t + 1, s2, s3);
+        } else {
+          load_part(PHC, BUFC, t, s1, s2);
+          mfma_part(PHC, SWC);
+        }
+        G256_BARRIER();
+      };
+      phase(g256q_ic<0>{});
+      phase(g256q_ic<1>{});
+      phase(g256q_ic<2>{});
+      phase(g256q_ic<3>{});
+    };
+    int t = 0;
+    for (; t + 1 < nk; t += 2) {
+      tile(g256q_ic<0>{}, t);
+      tile(g256q_ic<1>{}, t + 1);
+    }
+    if (t < nk) tile(g256q_ic<0>{}, t);
+  };
+  if constexpr (epi_has_transposed<Epi>::value) {
+    if (swapped) {
+      if (g == 0) run(g256q_ic<0>{}, g256q_ic<1>{});
+      else run(g256q_ic<1>{}, g256q_ic<1>{});
+    } else {
+      if (g == 0) run(g256q_ic<0>{}, g256q_ic<0>{});
+      else run(g256q_ic<1>{}, g256q_ic<0>{});
+    }
+  } else {
+    if (g == 0) run(g256q_ic<0>{}, g256q_ic<0>{});
+    else run(g256q_ic<1>{}, g256q_ic<0>{});
+  }
+#undef G256H_VMCNT
+#undef G256H_LGKM
+  g256h_epilogue<G256_BN>(acc, smem, epi, m0, n0, M, N, g, wn, lane, wave, bz, bsC, dbg, swapped);
+}
+
+template <class ASrc, class Epi>
+static inline int launch_gemm256h_tn(const ASrc& asrc, const half_t* W, long ldw, int M, int N, int K, const Epi& epi, hipStream_t stream,
+                                     int batch = 1, long bsA = 0, long bsW = 0, long bsC = 0) {
+  if (M <= 0 || N <= 0 || K <= 0 || (K % G256Q_BK) != 0 || (N % 4) != 0) return LFM_ERR_SHAPE;
+  if ((ldw % 8) != 0 || ((uintptr_t)W & 15)) return LFM_ERR_ALIGN;
+  const int tm = cdiv(M, G256_BM), tn = cdiv(N, G256_BN);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm256h_tn_kernel<ASrc, Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, G256Q_LDS_BYTES) != hipSuccess)
+      return LFM_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm256h_tn_kernel<ASrc, Epi>), dim3(tm * tn, batch), dim3(512), G256Q_LDS_BYTES, stream, asrc, W, ldw, M, N, K, tn, epi, bsA,
+                     bsW, bsC, lfm_gemm_debug_flags());
+  LFM_CHECK_LAUNCH();
+  return LFM_OK;
+}

@@ -3,7 +3,7 @@
 // implicit-GEMM 3x3 convolution (same / nearest-2x-upsampled input / stride 2), 1x1 convolution / linear with residual,
 // general GroupNorm(32) with optional FiLM scale-shift and SiLU, channel concat, small-T attention, timestep embedding.
 #include "../../include/lfm_hip.h"
-#include "gemm256q_kernel.h"
+#include "gemm_dispatch.h"
 
 // ------------------------------------------------------------------ implicit-GEMM A source, NHWC fp16, 3x3, pad 1
 // MODE 0: same size.  MODE 1: input is nearest-2x upsampled on the fly (Upsample, unet.py:73-100).

@@ -5,7 +5,7 @@
 // k = tap*Cin + ci; the A-tile gather (shifted pixel rows, zero padding, optional nearest-2x upsample) is done
 // by the per-lane LDS-DMA source address.  GroupNorm statistics / apply+SiLU are bandwidth-bound side kernels.
 #include "../../include/lfm_hip.h"
-#include "gemm256q_kernel.h"
+#include "gemm_dispatch.h"
 
 // ------------------------------------------------------------------ implicit-GEMM A source: 3x3 conv, pad 1, NHWC
 // UPS=1: the convolution runs on the nearest-2x upsampled image (diffusers Upsample2D) without materialising it.

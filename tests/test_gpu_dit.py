@@ -59,10 +59,10 @@ def test_gemm_epilogues(dev, M, N, K, epi):
                                    (512, 256, 192), (256, 512, 320), (768, 512, 576), (512, 128, 96), (384, 132, 160), (256, 128, 32),
                                    (65536, 128, 1152)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
-@pytest.mark.parametrize("kernel", [2, 3, 3 | (1 << 4), 4, 4 | (1024 << 4)])
+@pytest.mark.parametrize("kernel", [2, 3, 3 | (1 << 4), 4, 4 | (1024 << 4), 5, 5 | (1024 << 4)])
 def test_gemm256_kernels(dev, M, N, K, epi, kernel):
     """Same checks with a 256-row kernel forced (lfm_gemm_select: 2 = ping-pong, 3 = quadrant-phased, 3 | 1<<4 = its two-barrier schedule, 4 = the
-    256x128 two-workgroups-per-CU kernel, 4 | 1024<<4 = with the 8-byte-store epilogue; K covers 1, 2, 3, 5, odd and even numbers of 64- and
+    256x128 two-workgroups-per-CU kernel, 4 | 1024<<4 = with the 8-byte-store epilogue, 5 = the quadrant-phased kernel on 16x16x32 MFMAs (the default for chip-filling shapes); K covers 1, 2, 3, 5, odd and even numbers of 64- and
     32-deep K-tiles, i.e. every prologue / tail path; N = 128 / 132 the narrow shapes); repeated launches screen for races."""
     if (kernel & 15) != 4 and M > 8192 and N == 128:
         pytest.skip("the narrow-N convolution shape is the 256x128 kernel's")
@@ -97,7 +97,7 @@ def test_gemm256_kernels(dev, M, N, K, epi, kernel):
         assert torch.equal(o, outs[0])  # deterministic across launches (no data race on the LDS stages)
 
 
-@pytest.mark.parametrize("kernel", [2, 3, 4])
+@pytest.mark.parametrize("kernel", [2, 3, 4, 5])
 def test_gemm256_detects_transpose(dev, kernel):
     from lfm_amd import hip
 
@@ -111,7 +111,7 @@ def test_gemm256_detects_transpose(dev, kernel):
     assert torch.equal(got.cpu(), W.float().t())
 
 
-@pytest.mark.parametrize("kernel", [1, 2, 3, 3 | (1 << 4), 3 | (1024 << 4), 4])
+@pytest.mark.parametrize("kernel", [1, 2, 3, 3 | (1 << 4), 3 | (1024 << 4), 4, 5, 5 | (1024 << 4)])
 @pytest.mark.parametrize("batch,tokens,D,hd", [(3, 256, 384, 64), (8, 64, 512, 64), (2, 256, 1024, 64)])
 def test_gemm_qkv_split(dev, batch, tokens, D, hd, kernel):
     """Fused QKV projection: Q, K row-major, V transposed per head (timm Attention's qkv + reshape + permute, DiT.py:120), with
@@ -274,7 +274,7 @@ def test_dit_matches_oracle_fullsize(dev, name, batch, kw):
         assert rel_l2(got, ref) < 2e-3, (name, t)
 
 
-@pytest.mark.parametrize("kernel", [1, 2, 3, 3 | (1 << 4), 4])
+@pytest.mark.parametrize("kernel", [1, 2, 3, 3 | (1 << 4), 4, 5])
 @pytest.mark.parametrize("name,batch", [("DiT-S/2", 5), ("DiT-B/2", 3)])
 def test_dit_with_every_gemm_kernel(dev, name, batch, kernel):
     """The same forward with each GEMM kernel forced (auto picks by size, so small test batches would never reach the 256x256
