@@ -19,7 +19,20 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 // ---- epilogue for the 16x16 accumulator map.  acc[i][j]: tile i (16 rows) x j (16 columns) of the wave's 128 x 64 block.
 // fill32(I, scr): rows 32 I .. 32 I + 31 of the block -> scratch [32][64 + pad] fp32, row stride 272 B (as g256_epilogue_rows)
-template <int BN, class Epi>
+// Measurement only (lfm_gemm_select flag 2 with kernel 5): waves 0 and 4 of block 0 stamp s_memtime at the end of the K loop and after the
+// scratch fill / read-back / store issue of each of the four 32-row blocks of the row-major epilogue (g256q_trace, lfm_gemm_trace_read).
+template <bool TRACE>
+__device__ __forceinline__ void g256h_stamp(int g, int wn, int lane, int slot) {
+  if constexpr (TRACE) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && wn == 0 && lane == 0) {
+      unsigned long long t;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+      g256q_trace[g][slot] = t;
+    }
+  }
+}
+
+template <int BN, bool TRACE = false, class Epi>
 __device__ __forceinline__ void g256h_epilogue_rows(f32x4_t (&acc)[8][4], char* smem, const Epi& epi, int m0, int n0, int M, int N, int g, int wn,
                                                     int lane, int wave, bool narrow) {
   char* scr = smem + wave * (32 * 272);
@@ -38,11 +51,16 @@ __device__ __forceinline__ void g256h_epilogue_rows(f32x4_t (&acc)[8][4], char* 
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         fill32(i);
+        g256h_stamp<TRACE>(g, wn, lane, 1 + 4 * i);
         f32x4 lo[4], hi[4];
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
           lo[ps] = *(const f32x4*)(scr + (ps * 8 + rrow) * 272 + rcol * 32);
           hi[ps] = *(const f32x4*)(scr + (ps * 8 + rrow) * 272 + rcol * 32 + 16);
+        }
+        if constexpr (TRACE) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          g256h_stamp<TRACE>(g, wn, lane, 2 + 4 * i);
         }
         const int mb = m0 + g * 128 + i * 32 + rrow, n = n0 + wn * 64 + rcol * 8;
         if (interior) {
@@ -52,8 +70,13 @@ __device__ __forceinline__ void g256h_epilogue_rows(f32x4_t (&acc)[8][4], char* 
             al[ps] = epi.load(mb + ps * 8, n);
             ah[ps] = epi.load(mb + ps * 8, n + 4);
           }
+          if constexpr (TRACE) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (trace build only) the auxiliary loads have returned
+            g256h_stamp<TRACE>(g, wn, lane, 3 + 4 * i);
+          }
 #pragma unroll
           for (int ps = 0; ps < 4; ++ps) epi.store8(mb + ps * 8, n, lo[ps], hi[ps], al[ps], ah[ps]);
+          g256h_stamp<TRACE>(g, wn, lane, 4 + 4 * i);
         } else {
 #pragma unroll
           for (int ps = 0; ps < 4; ++ps) {
@@ -91,10 +114,11 @@ __device__ __forceinline__ void g256h_epilogue_rows(f32x4_t (&acc)[8][4], char* 
   }
 }
 
-template <int BN, class Epi>
+template <int BN, bool TRACE = false, class Epi>
 __device__ __forceinline__ void g256h_epilogue(f32x4_t (&acc)[8][4], char* smem, Epi& epi, int m0, int n0, int M, int N, int g, int wn, int lane,
                                                int wave, int bz, long bsC, int dbg, bool swapped) {
   epi_batch(epi, bz, bsC, 0);
+  g256h_stamp<TRACE>(g, wn, lane, 0);
   if (dbg & 4) return;  // ablation: no epilogue
   const int l15 = lane & 15, l4 = lane >> 4;
   if constexpr (epi_has_transposed<Epi>::value) {
@@ -162,14 +186,15 @@ __device__ __forceinline__ void g256h_epilogue(f32x4_t (&acc)[8][4], char* smem,
   if constexpr (epi_has_plain<Epi>::value) {
     if (epi.plain_tile(n0, BN)) {
       auto pe = epi.plain(n0);
-      g256h_epilogue_rows<BN>(acc, smem, pe, m0, n0, M, N, g, wn, lane, wave, (dbg & 1024) != 0);
+      g256h_epilogue_rows<BN, TRACE>(acc, smem, pe, m0, n0, M, N, g, wn, lane, wave, (dbg & 1024) != 0);
       return;
     }
   }
-  g256h_epilogue_rows<BN>(acc, smem, epi, m0, n0, M, N, g, wn, lane, wave, (dbg & 1024) != 0);
+  g256h_epilogue_rows<BN, TRACE>(acc, smem, epi, m0, n0, M, N, g, wn, lane, wave, (dbg & 1024) != 0);
+  g256h_stamp<TRACE>(g, wn, lane, 17);
 }
 
-template <class ASrc, class Epi>
+template <class ASrc, class Epi, bool TRACE = false>
 __global__ __launch_bounds__(512) void gemm256h_tn_kernel(ASrc asrc, const half_t* __restrict__ W, long ldw, int M, int N, int K, int tiles_n,
                                                            Epi epi, long bsA, long bsW, long bsC, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -392,10 +417,10 @@ __global__ __launch_bounds__(512) void gemm256h_tn_kernel(ASrc asrc, const half_
   }
 #undef G256H_VMCNT
 #undef G256H_LGKM
-  g256h_epilogue<G256_BN>(acc, smem, epi, m0, n0, M, N, g, wn, lane, wave, bz, bsC, dbg, swapped);
+  g256h_epilogue<G256_BN, TRACE>(acc, smem, epi, m0, n0, M, N, g, wn, lane, wave, bz, bsC, dbg, swapped);
 }
 
-template <class ASrc, class Epi>
+template <class ASrc, class Epi, bool TRACE = false>
 static inline int launch_gemm256h_tn(const ASrc& asrc, const half_t* W, long ldw, int M, int N, int K, const Epi& epi, hipStream_t stream,
                                      int batch = 1, long bsA = 0, long bsW = 0, long bsC = 0) {
   if (M <= 0 || N <= 0 || K <= 0 || (K % G256Q_BK) != 0 || (N % 4) != 0) return LFM_ERR_SHAPE;
@@ -403,11 +428,11 @@ static inline int launch_gemm256h_tn(const ASrc& asrc, const half_t* W, long ldw
   const int tm = cdiv(M, G256_BM), tn = cdiv(N, G256_BN);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm256h_tn_kernel<ASrc, Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, G256Q_LDS_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemm256h_tn_kernel<ASrc, Epi, TRACE>, hipFuncAttributeMaxDynamicSharedMemorySize, G256Q_LDS_BYTES) != hipSuccess)
       return LFM_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm256h_tn_kernel<ASrc, Epi>), dim3(tm * tn, batch), dim3(512), G256Q_LDS_BYTES, stream, asrc, W, ldw, M, N, K, tn, epi, bsA,
+  hipLaunchKernelGGL((gemm256h_tn_kernel<ASrc, Epi, TRACE>), dim3(tm * tn, batch), dim3(512), G256Q_LDS_BYTES, stream, asrc, W, ldw, M, N, K, tn, epi, bsA,
                      bsW, bsC, lfm_gemm_debug_flags());
   LFM_CHECK_LAUNCH();
   return LFM_OK;

@@ -20,6 +20,6 @@ pmc fc1_fetch "FETCH_SIZE" 0 16384 4096 1024 1 5 randn
 pmc fc1_write "WRITE_SIZE" 0 16384 4096 1024 1 5 randn
 pmc fc2_mfma "$C0" 0 16384 1024 4096 3 5 randn
 pmc proj_mfma "$C0" 0 16384 1024 1024 3 5 randn
-cd $R && python tools/pmc_parse.py $O gemm256q > $O/pmc_summary.txt 2>&1
+cd $R && python tools/pmc_parse.py $O gemm256 > $O/pmc_summary.txt 2>&1
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv 2>/dev/null
 tail -60 $O/pmc_summary.txt; head -30 $O/kernel_stats.csv | cut -c1-200
