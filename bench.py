@@ -35,7 +35,7 @@ MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense fp16/bf16 (MI355X_MICROARCH.md)
 # passes of the shipped kernel: FETCH_SIZE x 2 (gfx950 correction for 16-B-per-lane streams, MI355X_MICROARCH.md) + WRITE_SIZE, KiB.
 # These are fabric-side request counters: Infinity-Cache hits are INCLUDED (the whole working set of this GEMM fits the 256 MiB cache),
 # so this is an upper bound on HBM bytes, not HBM bytes.  Source file named in `traffic_source`.
-FC1_TRAFFIC = {"fetch_kib": 100694.4, "write_kib": 135168.0, "source": "profiles/r02_gemm_pmc.txt (fc1_fetch / fc1_write passes)"}
+FC1_TRAFFIC = {"fetch_kib": 99674.2, "write_kib": 133120.0, "source": "profiles/r02_gemm_pmc.txt (fc1_fetch / fc1_write passes)"}
 
 
 def parse():
@@ -183,7 +183,7 @@ def build_workload(a, dev, rank):
 
 
 def roofline_dit(model, lat, rows, dev):
-    """Dominant kernel of the DiT configurations: the fc1 MFMA GEMM + GELU epilogue (gemm256q_tn_kernel<ASrcRowMajor, EpiBiasGeluF16>).
+    """Dominant kernel of the DiT configurations: the fc1 MFMA GEMM + GELU epilogue (gemm256h_tn_kernel<ASrcRowMajor, EpiBiasGeluF16>).
     Timed LIVE and IN SITU: eager forwards of the real model on the solver's latents with one HIP event pair recorded around every
     block's fc1 launch on the launching stream (lfm_profile_fc1; a captured graph cannot be bracketed)."""
     import ctypes as C
@@ -210,7 +210,7 @@ def roofline_dit(model, lat, rows, dev):
     ach = 2.0 * M * H * D / dur / 1e12
     r = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
          "algorithmic_bytes": 2.0 * (M * D + H * D + M * H), "algorithmic_flop": 2.0 * M * H * D,
-         "kernel": "gemm256q_tn_kernel<ASrcRowMajor,EpiBiasGeluF16> (DiT fc1 + GELU)", "shape": {"M": M, "N": H, "K": D}, "avg_launch_us": dur * 1e6,
+         "kernel": "gemm256h_tn_kernel<ASrcRowMajor,EpiBiasGeluF16> (DiT fc1 + GELU)", "shape": {"M": M, "N": H, "K": D}, "avg_launch_us": dur * 1e6,
          "launches_timed": len(durs)}
     if (M, H, D) == (16384, 4096, 1024):
         r["traffic"] = (2 * FC1_TRAFFIC["fetch_kib"] + FC1_TRAFFIC["write_kib"]) * 1024
@@ -249,7 +249,7 @@ def roofline_adm(B, dev):
     ach = 2.0 * M * Cout * K / dur / 1e12
     return {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
             "algorithmic_bytes": 2.0 * (M * Cin + Cout * K + M * Cout), "algorithmic_flop": 2.0 * M * Cout * K,
-            "kernel": "gemm256q_tn_kernel<ASrcConv<0>,EpiResidF16> (3x3 conv 256->256 at 64x64, implicit GEMM)", "shape": {"M": M, "N": Cout, "K": K},
+            "kernel": "gemm256h_tn_kernel<ASrcConv<0>,EpiResidF16> (3x3 conv 256->256 at 64x64, implicit GEMM)", "shape": {"M": M, "N": Cout, "K": K},
             "avg_launch_us": dur * 1e6, "launches_timed": 10}
 
 

@@ -60,6 +60,19 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
   const float z = x * (c0 + c1 * x * x);
   return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-z));
 }
+// Two elements at a time on the packed-fp32 VALU (v_pk_mul / v_pk_fma / v_pk_add_f32: two lanes' worth of fp32 per issue slot).  The GELU
+// epilogue of fc1 is VALU-bound (profiles/r02_epilogue_trace.txt: ~1900 of the ~2900 cycles per 32-row block); per pair this is 5 packed
+// ops + 4 transcendentals instead of 12 plain + 4 (1900 -> 1500 cycles per block).  Measured and not kept: the 16 pairs of a read-back pass
+// software-pipelined by hand so that every v_exp / v_rcp is followed by packed ops of other pairs (1550-1590 cycles, fc1 127.0 vs 125.5 us).  Same operation order per element as gelu_tanh_f.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t gelu_tanh_pk(f32x2_t x) {
+  const f32x2_t c0 = {2.3022081985f, 2.3022081985f}, c1 = {0.1029432397f, 0.1029432397f}, one = {1.0f, 1.0f};
+  const f32x2_t z = x * __builtin_elementwise_fma(x * x, c1, c0);
+  const f32x2_t e = {__builtin_amdgcn_exp2f(-z.x), __builtin_amdgcn_exp2f(-z.y)};
+  const f32x2_t d = one + e;
+  const f32x2_t r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  return x * r;
+}
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

@@ -103,13 +103,20 @@ __global__ __launch_bounds__(320) void patch_embed_kernel(const float* __restric
 #pragma unroll
     for (int k = 0; k < PE_MAXK; ++k) wr[i][k] = (k < KK) ? w[(long)(j + i) * KK + k] : 0.f;
   const f32x4 bias = *(const f32x4*)(b + j);
+  // every position-embedding row of the block's tokens is fetched BEFORE the first store: vmcnt counts stores too and returns in order, so a
+  // load issued behind a store waits for that store's round trip (58 us per launch with the load inside the token loop)
+  f32x4 pv[PE_TOK];
+#pragma unroll
+  for (int tt = 0; tt < PE_TOK; ++tt) {
+    const long m = (m_begin + tt < M) ? m_begin + tt : M - 1;
+    pv[tt] = *(const f32x4*)(pos + (long)(m % T) * D + j);
+  }
   __syncthreads();
-#pragma unroll 4
+#pragma unroll
   for (int tt = 0; tt < PE_TOK; ++tt) {
     const long m = m_begin + tt;
     if (m >= M) break;
-    const int tok = (int)(m % T);
-    f32x4 acc = bias + *(const f32x4*)(pos + (long)tok * D + j);
+    f32x4 acc = bias + pv[tt];
 #pragma unroll
     for (int k = 0; k < PE_MAXK; ++k) {
       const float xv = xs[tt][k];
@@ -190,6 +197,68 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
       if (c < nv) {
         const f32x4 o = v[r][i] * rstd * (1.0f + sc[c]) + sh[c];
         half4_t h = {(half_t)o.x, (half_t)o.y, (half_t)o.z, (half_t)o.w};
+        ar[c] = h;
+      }
+    }
+  }
+}
+
+// Same computation with 16-byte stores: lane l owns EIGHT consecutive columns 8 (l + 64 i) .. + 7 (two adjacent float4 loads), so a row
+// of the fp16 output goes out as 16 B per lane instead of 8 (the GEMM epilogues gained 3-4 % from the same change).  D % 8 == 0.
+#define LN_MAXP 3  // column octets per lane: D <= 1536
+__global__ __launch_bounds__(256) void ln_modulate8_kernel(const float* __restrict__ X, half_t* __restrict__ A, int M, int D, int tokens,
+                                                           const float* __restrict__ shift, const float* __restrict__ scale, long mod_stride) {
+  const int lane = threadIdx.x & 63;
+  const long m0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_ROWS;
+  if (m0 >= M) return;
+  const int np = D >> 3;
+  f32x4 v[LN_ROWS][LN_MAXP][2];
+  float s[LN_ROWS];
+#pragma unroll
+  for (int r = 0; r < LN_ROWS; ++r) {
+    const long m = (m0 + r < M) ? m0 + r : M - 1;
+    const f32x4* xr = (const f32x4*)(X + m * D);
+    s[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXP; ++i) {
+      const int c = lane + 64 * i;
+      if (c < np) {
+        v[r][i][0] = xr[2 * c];
+        v[r][i][1] = xr[2 * c + 1];
+        const f32x4 t = v[r][i][0] + v[r][i][1];
+        s[r] += (t.x + t.y) + (t.z + t.w);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < LN_ROWS; ++r) {
+    const long m = m0 + r;
+    if (m >= M) break;
+    const float mean = wave_sum(s[r]) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXP; ++i) {
+      if (lane + 64 * i < np) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          v[r][i][h] -= mean;
+          const f32x4 t = v[r][i][h] * v[r][i][h];
+          q += (t.x + t.y) + (t.z + t.w);
+        }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + 1e-6f);
+    const long mo = (m / tokens) * mod_stride;
+    const f32x4* sh = (const f32x4*)(shift + mo);
+    const f32x4* sc = (const f32x4*)(scale + mo);
+    half8_t* ar = (half8_t*)(A + m * D);
+#pragma unroll
+    for (int i = 0; i < LN_MAXP; ++i) {
+      const int c = lane + 64 * i;
+      if (c < np) {
+        const f32x4 lo = v[r][i][0] * rstd * (1.0f + sc[2 * c]) + sh[2 * c];
+        const f32x4 hi = v[r][i][1] * rstd * (1.0f + sc[2 * c + 1]) + sh[2 * c + 1];
+        half8_t h = {(half_t)lo.x, (half_t)lo.y, (half_t)lo.z, (half_t)lo.w, (half_t)hi.x, (half_t)hi.y, (half_t)hi.z, (half_t)hi.w};
         ar[c] = h;
       }
     }
@@ -615,6 +684,11 @@ extern "C" int lfm_dit_attention(const void* Q, const void* K, const void* Vt, v
 static int ln_modulate_launch(const float* X, half_t* A, int M, int D, int tokens, const float* shift, const float* scale, long stride,
                               hipStream_t st) {
   if (D % 4 || D > 256 * LN_MAXV) return LFM_ERR_SHAPE;
+  if (D % 8 == 0 && !(((uintptr_t)A | (uintptr_t)X) & 15) && !(lfm_gemm_debug_flags() & 32768)) {  // flag 32768: the 8-byte-store kernel (A/B)
+    hipLaunchKernelGGL(ln_modulate8_kernel, dim3(cdiv(M, 4 * LN_ROWS)), dim3(256), 0, st, X, A, M, D, tokens, shift, scale, stride);
+    LFM_CHECK_LAUNCH();
+    return LFM_OK;
+  }
   hipLaunchKernelGGL(ln_modulate_kernel, dim3(cdiv(M, 4 * LN_ROWS)), dim3(256), 0, st, X, A, M, D, tokens, shift, scale, stride);
   LFM_CHECK_LAUNCH();
   return LFM_OK;
@@ -638,6 +712,8 @@ extern "C" int lfm_gemm_f16(const void* A, long lda, const void* W, long ldw, vo
       if (g_gemm_sel == 3 && (g_gemm_dbg & 2) && K % G256Q_BK == 0)  // measurement: the time-stamped build of the quadrant-phased kernel
         return (g_gemm_dbg & 1) ? launch_gemm256q_tn<ASrcRowMajor, EpiBiasF16, true, 0>(a, (const half_t*)W, ldw, M, N, K, EpiBiasF16{(half_t*)C, ldc, bias}, st)
                                 : launch_gemm256q_tn<ASrcRowMajor, EpiBiasF16, true, 1>(a, (const half_t*)W, ldw, M, N, K, EpiBiasF16{(half_t*)C, ldc, bias}, st);
+      if (g_gemm_sel == 5 && (g_gemm_dbg & 2) && K % G256Q_BK == 0)  // measurement: the epilogue-stamped build of the 16x16x32 kernel
+        return launch_gemm256h_tn<ASrcRowMajor, EpiBiasF16, true>(a, (const half_t*)W, ldw, M, N, K, EpiBiasF16{(half_t*)C, ldc, bias}, st);
       return launch_gemm_auto(a, (const half_t*)W, ldw, M, N, K, EpiBiasF16{(half_t*)C, ldc, bias}, st);
     case 1:
       if (!bias) return LFM_ERR_ARG;
@@ -647,6 +723,9 @@ extern "C" int lfm_gemm_f16(const void* A, long lda, const void* W, long ldw, vo
     case 2: return launch_gemm_auto(a, (const half_t*)W, ldw, M, N, K, EpiBiasF32{(float*)C, ldc, bias}, st);
     case 3:
       if (!bias || !gate || tokens <= 0) return LFM_ERR_ARG;
+      if (g_gemm_sel == 5 && (g_gemm_dbg & 2) && K % G256Q_BK == 0)
+        return launch_gemm256h_tn<ASrcRowMajor, EpiGateResidF32, true>(a, (const half_t*)W, ldw, M, N, K,
+                                                                       EpiGateResidF32{(float*)C, ldc, bias, gate, gate_stride, tokens}, st);
       return launch_gemm_auto(a, (const half_t*)W, ldw, M, N, K, EpiGateResidF32{(float*)C, ldc, bias, gate, gate_stride, tokens}, st);
   }
   return LFM_ERR_ARG;
@@ -684,6 +763,10 @@ extern "C" int lfm_gemm_qkv_f16(const void* A, long lda, const void* W, long ldw
   if (!A || !W || !Q || !Kout || !Vt || !bias) return LFM_ERR_ARG;
   if ((lda % 8) || ((uintptr_t)A & 15)) return LFM_ERR_ALIGN;
   if (head_dim <= 0 || tokens <= 0 || (D % head_dim) || (head_dim % 32) || (tokens % 4) || (M % tokens)) return LFM_ERR_SHAPE;
+  if (g_gemm_sel == 5 && (g_gemm_dbg & 2) && K % G256Q_BK == 0)
+    return launch_gemm256h_tn<ASrcRowMajor, EpiQKV, true>(ASrcRowMajor{(const half_t*)A, lda, M, 0}, (const half_t*)W, ldw, M, 3 * D, K,
+                                                          EpiQKV::make((half_t*)Q, (half_t*)Kout, (half_t*)Vt, bias, D, head_dim, tokens),
+                                                          (hipStream_t)stream);
   return launch_gemm_auto(ASrcRowMajor{(const half_t*)A, lda, M, 0}, (const half_t*)W, ldw, M, 3 * D, K,
                           EpiQKV::make((half_t*)Q, (half_t*)Kout, (half_t*)Vt, bias, D, head_dim, tokens), (hipStream_t)stream);
 }

@@ -60,6 +60,18 @@ struct epi_has_store8<Epi, decltype((void)&Epi::store8)> {
   static constexpr bool value = true;
 };
 
+// epilogues whose auxiliary operand depends on the column only (a bias row) say so with  static constexpr bool column_aux = true :
+// kernels may then load it once per tile, AHEAD of the first store (vmcnt counts stores too and returns in order, so a bias load issued
+// after a block's stores waits for those stores to drain -- profiles/r02_epilogue_trace.txt, the "aux" column of the bias epilogues)
+template <class Epi, class = void>
+struct epi_column_aux {
+  static constexpr bool value = false;
+};
+template <class Epi>
+struct epi_column_aux<Epi, decltype((void)Epi::column_aux)> {
+  static constexpr bool value = Epi::column_aux;
+};
+
 // The row-major path of the epilogue: each wave transposes its accumulators through a private LDS scratch, see g256_epilogue.
 // fp16 outputs (store8): a lane re-reads EIGHT consecutive columns of a row (two ds_read_b128) and issues ONE 16-byte store, so a
 // store instruction covers 8 rows x one full 128-B line -- half the store instructions of the 4-column form.  The fp16 epilogues

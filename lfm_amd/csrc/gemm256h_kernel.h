@@ -19,12 +19,12 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 // ---- epilogue for the 16x16 accumulator map.  acc[i][j]: tile i (16 rows) x j (16 columns) of the wave's 128 x 64 block.
 // fill32(I, scr): rows 32 I .. 32 I + 31 of the block -> scratch [32][64 + pad] fp32, row stride 272 B (as g256_epilogue_rows)
-// Measurement only (lfm_gemm_select flag 2 with kernel 5): waves 0 and 4 of block 0 stamp s_memtime at the end of the K loop and after the
+// Measurement only (lfm_gemm_select flag 2 with kernel 5): waves 0 and 4 of the tile at row 0, column (flags >> 21) & 15 stamp s_memtime at the end of the K loop and after the
 // scratch fill / read-back / store issue of each of the four 32-row blocks of the row-major epilogue (g256q_trace, lfm_gemm_trace_read).
 template <bool TRACE>
-__device__ __forceinline__ void g256h_stamp(int g, int wn, int lane, int slot) {
+__device__ __forceinline__ void g256h_stamp(bool tr, int g, int wn, int lane, int slot) {
   if constexpr (TRACE) {
-    if (blockIdx.x == 0 && blockIdx.y == 0 && wn == 0 && lane == 0) {
+    if (tr && wn == 0 && lane == 0) {
       unsigned long long t;
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
       g256q_trace[g][slot] = t;
@@ -34,9 +34,10 @@ __device__ __forceinline__ void g256h_stamp(int g, int wn, int lane, int slot) {
 
 template <int BN, bool TRACE = false, class Epi>
 __device__ __forceinline__ void g256h_epilogue_rows(f32x4_t (&acc)[8][4], char* smem, const Epi& epi, int m0, int n0, int M, int N, int g, int wn,
-                                                    int lane, int wave, bool narrow) {
+                                                    int lane, int wave, bool narrow, bool tr = false) {
   char* scr = smem + wave * (32 * 272);
   const bool interior = (m0 + G256_BM <= M) && (n0 + BN <= N);
+  constexpr bool COL = epi_column_aux<Epi>::value;  // bias-only auxiliary operand: loaded once per tile, ahead of the first store
   const int l15 = lane & 15, l4 = lane >> 4;
   auto fill32 = [&](int I) {
 #pragma unroll
@@ -48,10 +49,17 @@ __device__ __forceinline__ void g256h_epilogue_rows(f32x4_t (&acc)[8][4], char* 
   if constexpr (epi_has_store8<Epi>::value) {
     if (!narrow && epi.wide_ok()) {
       const int rrow = lane >> 3, rcol = lane & 7;
+      typename Epi::Aux cl, ch;
+      if constexpr (COL) {
+        if (interior) {
+          cl = epi.load(m0, n0 + wn * 64 + rcol * 8);
+          ch = epi.load(m0, n0 + wn * 64 + rcol * 8 + 4);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         fill32(i);
-        g256h_stamp<TRACE>(g, wn, lane, 1 + 4 * i);
+        g256h_stamp<TRACE>(tr, g, wn, lane, 1 + 4 * i);
         f32x4 lo[4], hi[4];
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
@@ -60,10 +68,17 @@ __device__ __forceinline__ void g256h_epilogue_rows(f32x4_t (&acc)[8][4], char* 
         }
         if constexpr (TRACE) {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          g256h_stamp<TRACE>(g, wn, lane, 2 + 4 * i);
+          g256h_stamp<TRACE>(tr, g, wn, lane, 2 + 4 * i);
         }
         const int mb = m0 + g * 128 + i * 32 + rrow, n = n0 + wn * 64 + rcol * 8;
-        if (interior) {
+        if (COL && interior) {
+          if constexpr (COL) {
+            g256h_stamp<TRACE>(tr, g, wn, lane, 3 + 4 * i);
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) epi.store8(mb + ps * 8, n, lo[ps], hi[ps], cl, ch);
+            g256h_stamp<TRACE>(tr, g, wn, lane, 4 + 4 * i);
+          }
+        } else if (interior) {
           typename Epi::Aux al[4], ah[4];
 #pragma unroll
           for (int ps = 0; ps < 4; ++ps) {
@@ -72,11 +87,11 @@ __device__ __forceinline__ void g256h_epilogue_rows(f32x4_t (&acc)[8][4], char* 
           }
           if constexpr (TRACE) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (trace build only) the auxiliary loads have returned
-            g256h_stamp<TRACE>(g, wn, lane, 3 + 4 * i);
+            g256h_stamp<TRACE>(tr, g, wn, lane, 3 + 4 * i);
           }
 #pragma unroll
           for (int ps = 0; ps < 4; ++ps) epi.store8(mb + ps * 8, n, lo[ps], hi[ps], al[ps], ah[ps]);
-          g256h_stamp<TRACE>(g, wn, lane, 4 + 4 * i);
+          g256h_stamp<TRACE>(tr, g, wn, lane, 4 + 4 * i);
         } else {
 #pragma unroll
           for (int ps = 0; ps < 4; ++ps) {
@@ -92,19 +107,39 @@ __device__ __forceinline__ void g256h_epilogue_rows(f32x4_t (&acc)[8][4], char* 
     }
   }
   const int rrow = lane >> 4, rcol = lane & 15;
+  typename Epi::Aux cx;
+  if constexpr (COL) {
+    if (interior) cx = epi.load(m0, n0 + wn * 64 + rcol * 4);
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     fill32(i);
+    g256h_stamp<TRACE>(tr, g, wn, lane, 1 + 4 * i);
     f32x4 v[8];
 #pragma unroll
     for (int ps = 0; ps < 8; ++ps) v[ps] = *(const f32x4*)(scr + (ps * 4 + rrow) * 272 + rcol * 16);
+    if constexpr (TRACE) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      g256h_stamp<TRACE>(tr, g, wn, lane, 2 + 4 * i);
+    }
     const int mb = m0 + g * 128 + i * 32 + rrow, n = n0 + wn * 64 + rcol * 4;
-    if (interior) {
+    if (COL && interior) {
+      if constexpr (COL) {
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) epi.store(mb + ps * 4, n, v[ps], cx);
+        g256h_stamp<TRACE>(tr, g, wn, lane, 4 + 4 * i);
+      }
+    } else if (interior) {
       typename Epi::Aux aux[8];
 #pragma unroll
       for (int ps = 0; ps < 8; ++ps) aux[ps] = epi.load(mb + ps * 4, n);
+      if constexpr (TRACE) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        g256h_stamp<TRACE>(tr, g, wn, lane, 3 + 4 * i);
+      }
 #pragma unroll
       for (int ps = 0; ps < 8; ++ps) epi.store(mb + ps * 4, n, v[ps], aux[ps]);
+      g256h_stamp<TRACE>(tr, g, wn, lane, 4 + 4 * i);
     } else if (n + 3 < N) {
 #pragma unroll
       for (int ps = 0; ps < 8; ++ps)
@@ -117,8 +152,9 @@ __device__ __forceinline__ void g256h_epilogue_rows(f32x4_t (&acc)[8][4], char* 
 template <int BN, bool TRACE = false, class Epi>
 __device__ __forceinline__ void g256h_epilogue(f32x4_t (&acc)[8][4], char* smem, Epi& epi, int m0, int n0, int M, int N, int g, int wn, int lane,
                                                int wave, int bz, long bsC, int dbg, bool swapped) {
+  const bool tr = TRACE && m0 == 0 && n0 == ((dbg >> 21) & 15) * BN && bz == 0;  // the stamped tile: row 0, column (flags >> 21) & 15
   epi_batch(epi, bz, bsC, 0);
-  g256h_stamp<TRACE>(g, wn, lane, 0);
+  g256h_stamp<TRACE>(tr, g, wn, lane, 0);
   if (dbg & 4) return;  // ablation: no epilogue
   const int l15 = lane & 15, l4 = lane >> 4;
   if constexpr (epi_has_transposed<Epi>::value) {
@@ -128,6 +164,17 @@ __device__ __forceinline__ void g256h_epilogue(f32x4_t (&acc)[8][4], char* smem,
     if (swapped) {
       char* scr = smem + wave * (32 * 272);
       const bool wide = !(dbg & 1024) && epi.wide_t_ok();
+      // the per-column bias of every pass, loaded ahead of the first store (a load issued after stores waits for them: vmcnt is in order)
+      float bt[2][4];
+      if (wide) {
+#pragma unroll
+        for (int J = 0; J < 2; ++J)
+#pragma unroll
+          for (int ps = 0; ps < 4; ++ps) {
+            const int n = n0 + wn * 64 + J * 32 + (lane >> 3) + ps * 8;
+            bt[J][ps] = n < N ? epi.load_t(n) : 0.f;
+          }
+      }
 #pragma unroll
       for (int J = 0; J < 2; ++J) {
 #pragma unroll
@@ -138,7 +185,25 @@ __device__ __forceinline__ void g256h_epilogue(f32x4_t (&acc)[8][4], char* smem,
             for (int i4 = 0; i4 < 4; ++i4)
               *(f32x4_t*)(scr + (j2 * 16 + l15) * 272 + (i4 * 16 + l4 * 4) * 4) = acc[4 * ih + i4][2 * J + j2];
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          if (wide) {
+          g256h_stamp<TRACE>(tr, g, wn, lane, 1 + 4 * (2 * J + ih));
+          if (wide && m0 + G256_BM <= M && n0 + BN <= N) {  // interior tile: no per-store bounds checks
+            const int rrow = lane >> 3, rcol = lane & 7;
+            const int nb = n0 + wn * 64 + J * 32 + rrow, m = m0 + g * 128 + ih * 64 + rcol * 8;
+            f32x4 lo[4], hi[4];
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+              lo[ps] = *(const f32x4*)(scr + (ps * 8 + rrow) * 272 + rcol * 32);
+              hi[ps] = *(const f32x4*)(scr + (ps * 8 + rrow) * 272 + rcol * 32 + 16);
+            }
+            if constexpr (TRACE) {
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+              g256h_stamp<TRACE>(tr, g, wn, lane, 2 + 4 * (2 * J + ih));
+            }
+            if (!(TRACE && (dbg & 131072))) {  // (trace build, flag 131072: the pass without its stores)
+#pragma unroll
+              for (int ps = 0; ps < 4; ++ps) epi.store_t8(nb + ps * 8, m, lo[ps], hi[ps], bt[J][ps]);
+            }
+          } else if (wide) {
             const int rrow = lane >> 3, rcol = lane & 7;
             const int nb = n0 + wn * 64 + J * 32 + rrow, m = m0 + g * 128 + ih * 64 + rcol * 8;
 #pragma unroll
@@ -147,7 +212,7 @@ __device__ __forceinline__ void g256h_epilogue(f32x4_t (&acc)[8][4], char* smem,
               const f32x4 hi = *(const f32x4*)(scr + (ps * 8 + rrow) * 272 + rcol * 32 + 16);
               const int n = nb + ps * 8;
               if (n >= N) continue;
-              const float b = epi.load_t(n);
+              const float b = bt[J][ps];
               if (m + 7 < M) epi.store_t8(n, m, lo, hi, b);
               else if (m + 3 < M) epi.store_t(n, m, lo, b);
             }
@@ -162,8 +227,10 @@ __device__ __forceinline__ void g256h_epilogue(f32x4_t (&acc)[8][4], char* smem,
             }
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          g256h_stamp<TRACE>(tr, g, wn, lane, 4 + 4 * (2 * J + ih));
         }
       }
+      g256h_stamp<TRACE>(tr, g, wn, lane, 17);
       return;
     }
   }
@@ -186,12 +253,12 @@ __device__ __forceinline__ void g256h_epilogue(f32x4_t (&acc)[8][4], char* smem,
   if constexpr (epi_has_plain<Epi>::value) {
     if (epi.plain_tile(n0, BN)) {
       auto pe = epi.plain(n0);
-      g256h_epilogue_rows<BN, TRACE>(acc, smem, pe, m0, n0, M, N, g, wn, lane, wave, (dbg & 1024) != 0);
+      g256h_epilogue_rows<BN, TRACE>(acc, smem, pe, m0, n0, M, N, g, wn, lane, wave, (dbg & 1024) != 0, tr);
       return;
     }
   }
-  g256h_epilogue_rows<BN, TRACE>(acc, smem, epi, m0, n0, M, N, g, wn, lane, wave, (dbg & 1024) != 0);
-  g256h_stamp<TRACE>(g, wn, lane, 17);
+  g256h_epilogue_rows<BN, TRACE>(acc, smem, epi, m0, n0, M, N, g, wn, lane, wave, (dbg & 1024) != 0, tr);
+  g256h_stamp<TRACE>(tr, g, wn, lane, 17);
 }
 
 template <class ASrc, class Epi, bool TRACE = false>

@@ -56,6 +56,7 @@ struct EpiBiasF16 {  // C = acc + bias  -> fp16
   long ldc;
   const float* bias;  // may be null
   typedef f32x4 Aux;
+  static constexpr bool column_aux = true;
   __device__ __forceinline__ Aux load(int, int n) const { return bias ? *(const f32x4*)(bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f}; }
   __device__ __forceinline__ void store(int m, int n, f32x4 v, const Aux& b) const {
     v += b;
@@ -76,18 +77,21 @@ struct EpiBiasGeluF16 {  // C = gelu_tanh(acc + bias) -> fp16   (timm Mlp fc1, D
   long ldc;
   const float* bias;
   typedef f32x4 Aux;
+  static constexpr bool column_aux = true;
   __device__ __forceinline__ Aux load(int, int n) const { return *(const f32x4*)(bias + n); }
   __device__ __forceinline__ void store(int m, int n, f32x4 v, const Aux& b) const {
     v += b;
-    half4_t h = {(half_t)gelu_tanh_f(v.x), (half_t)gelu_tanh_f(v.y), (half_t)gelu_tanh_f(v.z), (half_t)gelu_tanh_f(v.w)};
+    const f32x2_t a = gelu_tanh_pk((f32x2_t){v.x, v.y}), c = gelu_tanh_pk((f32x2_t){v.z, v.w});
+    half4_t h = {(half_t)a.x, (half_t)a.y, (half_t)c.x, (half_t)c.y};
     *(half4_t*)(C + (long)m * ldc + n) = h;
   }
   __device__ __forceinline__ bool wide_ok() const { return (ldc & 7) == 0 && ((uintptr_t)C & 15) == 0; }  // 16-byte stores are aligned
   __device__ __forceinline__ void store8(int m, int n, f32x4 lo, f32x4 hi, const Aux& bl, const Aux& bh) const {
     lo += bl;
     hi += bh;
-    half8_t h = {(half_t)gelu_tanh_f(lo.x), (half_t)gelu_tanh_f(lo.y), (half_t)gelu_tanh_f(lo.z), (half_t)gelu_tanh_f(lo.w),
-                 (half_t)gelu_tanh_f(hi.x), (half_t)gelu_tanh_f(hi.y), (half_t)gelu_tanh_f(hi.z), (half_t)gelu_tanh_f(hi.w)};
+    const f32x2_t a = gelu_tanh_pk((f32x2_t){lo.x, lo.y}), c = gelu_tanh_pk((f32x2_t){lo.z, lo.w});
+    const f32x2_t e = gelu_tanh_pk((f32x2_t){hi.x, hi.y}), g = gelu_tanh_pk((f32x2_t){hi.z, hi.w});
+    half8_t h = {(half_t)a.x, (half_t)a.y, (half_t)c.x, (half_t)c.y, (half_t)e.x, (half_t)e.y, (half_t)g.x, (half_t)g.y};
     *(half8_t*)(C + (long)m * ldc + n) = h;
   }
 };
@@ -97,6 +101,7 @@ struct EpiBiasF32 {  // C = acc + bias -> fp32   (adaLN modulation table)
   long ldc;
   const float* bias;
   typedef f32x4 Aux;
+  static constexpr bool column_aux = true;
   __device__ __forceinline__ Aux load(int, int n) const { return bias ? *(const f32x4*)(bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f}; }
   __device__ __forceinline__ void store(int m, int n, f32x4 v, const Aux& b) const { *(f32x4*)(C + (long)m * ldc + n) = v + b; }
 };
@@ -154,10 +159,10 @@ struct EpiQKV {
   }
   typedef f32x4 Aux;
   __device__ __forceinline__ half_t* vt_ptr(int n, int m) const {  // &Vt[img][head][d][tok] for column n (>= 2D) and row m
+    // ((img * heads + head) * hd + d) * tokens + tok  with  head * hd + d = c  and  heads * hd = D:  no head / d split is needed
     const int c = n - 2 * D;
-    const int head = hd_sh >= 0 ? (c >> hd_sh) : c / hd, d = c - head * hd;
     const int img = tok_sh >= 0 ? (m >> tok_sh) : m / tokens, tok = m - img * tokens;
-    return Vt + (((long)img * (D / hd) + head) * hd + d) * tokens + tok;
+    return Vt + ((long)img * D + c) * tokens + tok;
   }
   __device__ __forceinline__ bool direct(int n0) const { return n0 >= 2 * D; }  // V tiles: 32 consecutive tokens per lane group
   __device__ __forceinline__ Aux load(int, int n) const { return *(const f32x4*)(bias + n); }
