@@ -1,0 +1,305 @@
+// Attention core of a DiT block (timm Attention as called at /root/reference/models/DiT.py:120): O = softmax(Q K^T * hd^-0.5) V
+// per (image, head), head_dim HD = 64 (DiT-S / B / L) or 72 (DiT-XL: 1152 / 16).
+//
+// One workgroup per (head, image); T / (32 JQ) waves, each owning JQ blocks of 32 queries (processed together so every K / V^T
+// fragment read from LDS feeds JQ MFMAs).
+// K [T][HD] and V^T [HD][T] of the head are staged once into LDS by LDS-DMA.  K rows are HD * 2 bytes: 128-B rows (hd 64) are
+// XOR-swizzled at the DMA source (chunk' = chunk ^ ((row>>1)&7)); 144-B rows (hd 72) need no swizzle -- 36 dwords per row put 16
+// consecutive rows on 16 disjoint groups of four banks.  V^T rows (2T bytes) are swizzled by row (chunk' = chunk ^ (row & VKEY)).
+// S^T = K Q^T on v_mfma_f32_32x32x16_f16: a lane then holds, for ONE query (lane&31), the scores of
+// keys kb*32 + 8g + 4*(lane>>5) + r -- row max / row sum are in-lane plus one lane^32 exchange, and the
+// fp32->fp16 packed P registers are directly the B-operand of O^T = V^T P^T (the key order inside an
+// MFMA k-slot is the same permutation on both operands, so no shuffle is needed).
+// hd 72 = 4.5 k-slots of 16: the fifth slot's upper half (dims 72..79) is fed zeros on BOTH operands (LDS past a row end is
+// another row or stale bytes, possibly NaN patterns); O^T has 2.25 blocks of 32 rows: the third block computes 8 live rows.
+// Keys are consumed in 32-key blocks with an online softmax (running max m, running sum l), which keeps
+// the live state at S 32 + P 16 + O 64 + Q 32 registers for hd 64, JQ 2 (2 waves / SIMD).
+#pragma once
+#include "common.h"
+
+int lfm_gemm_debug_flags();
+
+template <int T, int JQ, int HD>
+__global__ __launch_bounds__((T / (32 * JQ)) * 64, HD == 64 ? (T / (32 * JQ)) / 2 : 2) void dit_attention_kernel(
+    const half_t* __restrict__ Q, const half_t* __restrict__ K, const half_t* __restrict__ Vt, half_t* __restrict__ O, int D, int heads,
+    float scale_log2e) {
+  static_assert(HD % 8 == 0 && HD >= 32 && HD <= 128, "head_dim: whole 16-byte chunks");
+  constexpr int NKB = T / 32;         // 32-key blocks
+  constexpr int NW = T / (32 * JQ);   // waves: each owns JQ blocks of 32 queries
+  constexpr int NTHR = NW * 64;
+  constexpr int KS = (HD + 15) / 16;  // k-slots of the S MFMAs (the last one half empty when HD % 16 == 8)
+  constexpr int NDB = (HD + 31) / 32; // 32-row blocks of O^T
+  constexpr int KCH = HD / 8;         // 16-B chunks per K row
+  constexpr int KROW = KCH * 16;      // bytes per K row in LDS
+  constexpr bool KSWZ = HD == 64;     // 128-B rows: XOR swizzle; rows of an odd number of chunks are conflict-free as they are
+  constexpr int VKEY = (T / 8 - 1) < 15 ? (T / 8 - 1) : 15;  // V^T swizzle key mask (stays inside the row)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;             // [T][HD] halves
+  char* Vs = smem + T * KROW;  // [HD][T] halves, 2T-B rows
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int head = blockIdx.x, img = blockIdx.y;
+  const half_t* Kg = K + (long)img * T * D + head * HD;
+  const half_t* Vg = Vt + ((long)img * heads + head) * HD * T;
+
+  // ---- stage K, fetch this wave's Q fragments, then stage V^T.  Issue order = completion order for loads, so
+  // vmcnt(VMIN) below means "K and Q are here, V^T may still be flying"; V^T is awaited before the first PV.
+  // T * HD / 8 slots of 16 B over NTHR lanes: 8 or 4 full passes for hd 64, 4.5 for hd 72 (the last pass is issued by the lower
+  // half of the waves only: whole waves, so the DMA's implicit lane*16 destination stays dense).
+  constexpr int SLOTS = T * KCH;
+  constexpr int NPASS = (SLOTS + NTHR - 1) / NTHR;
+  constexpr int VMIN = SLOTS / NTHR;  // V^T DMAs every wave issues
+  static_assert(VMIN == 8 || VMIN == 4, "the counted wait below is vmcnt(VMIN)");
+  static_assert(SLOTS % NTHR == 0 || (SLOTS % NTHR) % 64 == 0, "a partial pass is made of whole waves");
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p) {
+    const int s = p * NTHR + tid;
+    if (SLOTS % NTHR == 0 || p + 1 < NPASS || s < SLOTS) {
+      const int row = s / KCH, ch = s - row * KCH;
+      const int c = KSWZ ? (ch ^ ((row >> 1) & 7)) : ch;
+      glds16(Kg + (long)row * D + c * 8, Ks + (p * NTHR + wave * 64) * 16);
+    }
+  }
+  const int q0 = wave * 32 * JQ;
+  const int hsel = lane >> 5, l31 = lane & 31;
+  const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  half8_t qf[JQ][KS];
+#pragma unroll
+  for (int jq = 0; jq < JQ; ++jq)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const half_t* qp = Q + ((long)img * T + q0 + jq * 32 + l31) * D + head * HD;
+      if (ks * 16 + 16 <= HD) qf[jq][ks] = *(const half8_t*)(qp + ks * 16 + hsel * 8);
+      else qf[jq][ks] = hsel ? zero8 : *(const half8_t*)(qp + ks * 16);
+    }
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p) {
+    const int s = p * NTHR + tid;
+    if (SLOTS % NTHR == 0 || p + 1 < NPASS || s < SLOTS) {
+      constexpr int CPR = T / 8;  // 16-B chunks per V^T row
+      const int row = s / CPR, c = (s % CPR) ^ (row & VKEY);
+      glds16(Vg + (long)row * T + c * 8, Vs + (p * NTHR + wave * 64) * 16);
+    }
+  }
+
+  f32x16 Oa[JQ][NDB];  // [jq][db]
+#pragma unroll
+  for (int jq = 0; jq < JQ; ++jq)
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) Oa[jq][db][e] = 0.f;
+  float mrun[JQ], lrun[JQ];
+#pragma unroll
+  for (int jq = 0; jq < JQ; ++jq) {
+    mrun[jq] = -3.0e38f;
+    lrun[jq] = 0.f;
+  }
+
+  if (VMIN == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // raw barrier: __syncthreads() would drain the in-flight V^T DMAs
+  asm volatile("" ::: "memory");
+
+  f32x16 zero16;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) zero16[e] = 0.f;
+  // S^T block kb: 32 keys x 32 JQ queries (the first MFMA takes a shared all-zero C: no per-block accumulator clears)
+  auto qk = [&](f32x16 (&S)[JQ], int kb) {
+    const int row = kb * 32 + l31;
+    const int key = KSWZ ? ((row >> 1) & 7) : 0;
+    const char* kp = Ks + row * KROW;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      half8_t kf;
+      if (ks * 16 + 16 <= HD) kf = *(const half8_t*)(kp + (((ks * 2 + hsel) ^ key) << 4));
+      else {  // half slot: the upper 8 dims do not exist
+        kf = *(const half8_t*)(kp + (ks * 2 << 4));
+        kf = hsel ? zero8 : kf;
+      }
+#pragma unroll
+      for (int jq = 0; jq < JQ; ++jq) S[jq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[jq][ks], ks == 0 ? zero16 : S[jq], 0, 0, 0);
+    }
+  };
+  // online softmax update for the queries this lane owns, then O^T[d][q] += sum_key V^T[d][key] P[q][key].
+  // VALU diet (the kernel is VALU-issue-bound: ~1.9k VALU per wave vs 128 MFMAs): 3-input max, packed fp32 FMA / ADD on
+  // register pairs, one v_permlane32_swap instead of a ds_bpermute round trip for the lane^32 exchange.
+  auto softmax_pv = [&](f32x16 (&S)[JQ], int kb) {
+    half8_t P[JQ][2];
+#pragma unroll
+    for (int jq = 0; jq < JQ; ++jq) {
+      float mx = fmaxf(fmaxf(S[jq][0], S[jq][1]), S[jq][2]);
+#pragma unroll
+      for (int e = 3; e < 15; e += 2) mx = fmaxf(fmaxf(mx, S[jq][e]), S[jq][e + 1]);
+      mx = fmaxf(mx, S[jq][15]);
+      mx = fmaxf(mx, xhalf(mx));
+      const float mnew = fmaxf(mrun[jq], mx);
+      const float alpha = __builtin_amdgcn_exp2f((mrun[jq] - mnew) * scale_log2e);
+      mrun[jq] = mnew;
+      const f32x2 sc2 = {scale_log2e, scale_log2e};
+      const float mbs = mnew * scale_log2e;
+      const f32x2 mb2 = {mbs, mbs};
+      f32x2 sum2 = {0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 16; e += 2) {
+        const f32x2 s2 = {S[jq][e], S[jq][e + 1]};
+        const f32x2 a2 = s2 * sc2 - mb2;  // v_pk_fma_f32
+        const f32x2 p2 = {__builtin_amdgcn_exp2f(a2.x), __builtin_amdgcn_exp2f(a2.y)};
+        sum2 += p2;  // v_pk_add_f32
+        P[jq][e >> 3][e & 7] = (half_t)p2.x;
+        P[jq][e >> 3][(e & 7) + 1] = (half_t)p2.y;
+      }
+      lrun[jq] = lrun[jq] * alpha + (sum2.x + sum2.y);
+      if (!__all(alpha == 1.0f)) {  // wave-uniform: most key blocks do not raise any query's running max
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) Oa[jq][db] *= alpha;
+      }
+    }
+    if (kb == 0) {  // V^T was issued after K and Q: only now must it have landed (every wave's share)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int db = 0; db < NDB; ++db) {
+        // rows past HD (third block of hd 72) re-read row HD-1: finite values into accumulator rows nobody stores
+        const int d = (db * 32 + 32 <= HD) ? db * 32 + l31 : (db * 32 + l31 < HD ? db * 32 + l31 : HD - 1);
+        const int vkey = d & VKEY;
+        const int c0 = kb * 4 + 2 * s;
+        const char* rowp = Vs + d * (2 * T) + hsel * 8;
+        const half4_t lo = *(const half4_t*)(rowp + ((c0 ^ vkey) << 4));
+        const half4_t hi = *(const half4_t*)(rowp + (((c0 + 1) ^ vkey) << 4));
+        const half8_t vf = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int jq = 0; jq < JQ; ++jq) Oa[jq][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, P[jq][s], Oa[jq][db], 0, 0, 0);
+      }
+    }
+  };
+  // software pipeline over the key blocks: the S MFMAs of block kb+1 are issued BEFORE the softmax VALU of block kb, so
+  // the matrix pipe works underneath the VALU-heavy part instead of the wave idling on the MFMA -> max -> exp -> MFMA chain
+  f32x16 Sa[JQ], Sb[JQ];
+  qk(Sa, 0);
+#pragma unroll 1
+  for (int kb = 0; kb < NKB; kb += 2) {
+    qk(Sb, kb + 1);
+    softmax_pv(Sa, kb);
+    if (kb + 2 < NKB) qk(Sa, kb + 2);
+    softmax_pv(Sb, kb + 1);
+  }
+  // ---- normalise and store: lane owns query q, d = db*32 + 8g + 4*hsel + r
+#pragma unroll
+  for (int jq = 0; jq < JQ; ++jq) {
+    const float inv = 1.0f / (lrun[jq] + xhalf(lrun[jq]));
+    half_t* orow = O + ((long)img * T + q0 + jq * 32 + l31) * D + head * HD;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (db * 32 + 8 * g >= HD) continue;  // HD % 8 == 0: an 8-row group is live or dead as a whole
+        half4_t h = {(half_t)(Oa[jq][db][4 * g] * inv), (half_t)(Oa[jq][db][4 * g + 1] * inv), (half_t)(Oa[jq][db][4 * g + 2] * inv),
+                     (half_t)(Oa[jq][db][4 * g + 3] * inv)};
+        *(half4_t*)(orow + db * 32 + 8 * g + 4 * hsel) = h;
+      }
+  }
+}
+
+// 16 tokens (the DiT-x/8 family on 32x32 latents, models/DiT.py:362-415): 256 scores per (image, head) -- no MFMA tile to fill, and
+// 16 rows of hd halves are served by the L1/L2 as they are.  One lane per query, four (image, head) items per wave; the lanes of an item
+// read the same K row / V^T row at the same time (one broadcast fetch).  Same arithmetic as the tiled kernel: fp32 scores, exp2 of the
+// scaled difference to the row maximum, P rounded to fp16 before P V, the row sum taken from the unrounded values, fp32 accumulation.
+template <int HD>
+__global__ __launch_bounds__(64) void dit_attention_t16_kernel(const half_t* __restrict__ Q, const half_t* __restrict__ K, const half_t* __restrict__ Vt,
+                                                               half_t* __restrict__ O, int D, int heads, int items, float scale_log2e) {
+  constexpr int T = 16, NC = HD / 8;
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 4), q = threadIdx.x & 15;
+  if (item >= items) return;
+  const int img = item / heads, head = item - img * heads;
+  const half_t* qp = Q + ((long)img * T + q) * D + head * HD;
+  const half_t* kp = K + (long)img * T * D + head * HD;
+  const half_t* vp = Vt + ((long)img * heads + head) * HD * T;
+  half8_t qf[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) qf[c] = *(const half8_t*)(qp + c * 8);
+  float s[T];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int k = 0; k < T; ++k) {
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const half8_t kf = *(const half8_t*)(kp + (long)k * D + c * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += (float)qf[c][e] * (float)kf[e];
+    }
+    s[k] = acc;
+    mx = fmaxf(mx, acc);
+  }
+  float l = 0.f;
+  half_t ph[T];
+#pragma unroll
+  for (int k = 0; k < T; ++k) {
+    const float p = __builtin_amdgcn_exp2f((s[k] - mx) * scale_log2e);
+    l += p;
+    ph[k] = (half_t)p;
+  }
+  const float inv = 1.0f / l;
+  half_t* op = O + ((long)img * T + q) * D + head * HD;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    half8_t o8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const half8_t v0 = *(const half8_t*)(vp + (c * 8 + e) * T);
+      const half8_t v1 = *(const half8_t*)(vp + (c * 8 + e) * T + 8);
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc += (float)ph[k] * (float)v0[k] + (float)ph[k + 8] * (float)v1[k];
+      o8[e] = (half_t)(acc * inv);
+    }
+    *(half8_t*)(op + c * 8) = o8;
+  }
+}
+
+// Q, K: [batch*T, heads*hd] token-major; Vt: [batch][heads*hd][T]; O: [batch*T, heads*hd].  hd 64 / 72; T in {16, 64, 128, 256}.
+static int attention_launch(const half_t* Q, const half_t* K, const half_t* Vt, half_t* O, int batch, int heads, int hd, int T, hipStream_t st) {
+  if (hd != 64 && hd != 72) return LFM_ERR_SHAPE;
+  const int D = heads * hd;
+  const float sl2 = (hd == 64 ? 0.125f : 0.11785113019775793f) * 1.4426950408889634f;  // hd^-0.5 * log2(e)
+  const size_t lds = (size_t)T * hd * 4;  // K + V^T, 2 bytes each
+  dim3 grid(heads, batch);
+  // A/B switch (measurement only): 8 waves x 32 queries (4 waves/SIMD) measured 44.3 us vs 40.2 us for 4 waves x 64 queries --
+  // the kernel moves Q,K,V^T,O = 134 MB per launch (3.4 TB/s): more waves do not help
+  const bool narrow = T == 256 && (lfm_gemm_debug_flags() & 256);
+  if (T == 16) {
+    const int items = batch * heads;
+    if (hd == 64) hipLaunchKernelGGL(dit_attention_t16_kernel<64>, dim3((items + 3) / 4), dim3(64), 0, st, Q, K, Vt, O, D, heads, items, sl2);
+    else hipLaunchKernelGGL(dit_attention_t16_kernel<72>, dim3((items + 3) / 4), dim3(64), 0, st, Q, K, Vt, O, D, heads, items, sl2);
+    LFM_CHECK_LAUNCH();
+    return LFM_OK;
+  }
+#define ATT_CASE(TT, JQ, HD)                                                                                                             \
+  {                                                                                                                                     \
+    static bool set = false;                                                                                                            \
+    if (!set) {                                                                                                                         \
+      (void)hipFuncSetAttribute((const void*)dit_attention_kernel<TT, JQ, HD>, hipFuncAttributeMaxDynamicSharedMemorySize, TT * HD * 4); \
+      set = true;                                                                                                                       \
+    }                                                                                                                                   \
+    hipLaunchKernelGGL((dit_attention_kernel<TT, JQ, HD>), grid, dim3((TT / (32 * JQ)) * 64), lds, st, Q, K, Vt, O, D, heads, sl2);       \
+  }
+  if (hd == 64) {
+    if (T == 64) ATT_CASE(64, 2, 64)
+    else if (T == 128) ATT_CASE(128, 2, 64)
+    else if (T == 256 && narrow) ATT_CASE(256, 1, 64)
+    else if (T == 256) ATT_CASE(256, 2, 64)
+    else return LFM_ERR_SHAPE;
+  } else {  // hd 72: one query block per wave (48 accumulator + 20 Q registers per block)
+    if (T == 64) ATT_CASE(64, 1, 72)
+    else if (T == 128) ATT_CASE(128, 1, 72)
+    else if (T == 256) ATT_CASE(256, 1, 72)
+    else return LFM_ERR_SHAPE;
+  }
+#undef ATT_CASE
+  LFM_CHECK_LAUNCH();
+  return LFM_OK;
+}

@@ -265,172 +265,7 @@ __global__ __launch_bounds__(256) void ln_modulate8_kernel(const float* __restri
   }
 }
 
-// ------------------------------------------------------------------ attention (timm Attention core, DiT.py:120)
-// One workgroup per (head, image); T/64 waves, each owning 64 queries (two 32-query blocks, processed
-// together so every K / V^T fragment read from LDS feeds two MFMAs).
-// K [T][64] and V^T [64][T] of the head are staged once into LDS by LDS-DMA (XOR-swizzled source).
-// S^T = K Q^T on v_mfma_f32_32x32x16_f16: a lane then holds, for ONE query (lane&31), the scores of
-// keys kb*32 + 8g + 4*(lane>>5) + r -- row max / row sum are in-lane plus one lane^32 exchange, and the
-// fp32->fp16 packed P registers are directly the B-operand of O^T = V^T P^T (the key order inside an
-// MFMA k-slot is the same permutation on both operands, so no shuffle is needed).
-// Keys are consumed in 32-key blocks with an online softmax (running max m, running sum l), which keeps
-// the live state at S 32 + P 16 + O 64 + Q 32 registers (2 waves / SIMD).
-template <int T, int JQ>
-__global__ __launch_bounds__((T / (32 * JQ)) * 64, (T / (32 * JQ)) / 2) void dit_attention_kernel(const half_t* __restrict__ Q, const half_t* __restrict__ K,
-                                                            const half_t* __restrict__ Vt, half_t* __restrict__ O, int D, int heads,
-                                                            float scale_log2e) {
-  constexpr int NKB = T / 32;  // 32-key blocks
-  constexpr int NW = T / (32 * JQ);  // waves: each owns JQ blocks of 32 queries
-  constexpr int VKEY = (T / 8 - 1) < 15 ? (T / 8 - 1) : 15;  // V^T swizzle key mask (stays inside the row)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Ks = smem;             // [T][64] halves, 128-B rows, chunk' = chunk ^ ((row>>1)&7)
-  char* Vs = smem + T * 128;   // [64][T] halves, 2T-B rows, chunk' = chunk ^ (row&VKEY)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int head = blockIdx.x, img = blockIdx.y;
-  const half_t* Kg = K + (long)img * T * D + head * 64;
-  const half_t* Vg = Vt + ((long)img * heads + head) * 64 * T;
-
-  // ---- stage K (8 DMAs per thread), fetch this wave's Q fragments, then stage V^T (8 DMAs).  Issue order = completion
-  // order for loads, so vmcnt(8) below means "K and Q are here, V^T may still be flying"; V^T is awaited before the first PV.
-  constexpr int NPASS = (T * 8) / (NW * 64);
-  static_assert(NPASS == 8 || NPASS == 4, "the counted wait below is vmcnt(NPASS)");
-#pragma unroll
-  for (int p = 0; p < NPASS; ++p) {
-    const int s = p * (NW * 64) + tid;
-    const int row = s >> 3, c = (s & 7) ^ ((row >> 1) & 7);
-    glds16(Kg + (long)row * D + c * 8, Ks + (p * NW * 64 + wave * 64) * 16);
-  }
-  const int q0 = wave * 32 * JQ;
-  const int hsel = lane >> 5, l31 = lane & 31;
-  half8_t qf[JQ][4];
-#pragma unroll
-  for (int jq = 0; jq < JQ; ++jq)
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-      qf[jq][ks] = *(const half8_t*)(Q + ((long)img * T + q0 + jq * 32 + l31) * D + head * 64 + ks * 16 + hsel * 8);
-#pragma unroll
-  for (int p = 0; p < NPASS; ++p) {
-    const int s = p * (NW * 64) + tid;
-    constexpr int CPR = T / 8;  // 16-B chunks per V^T row
-    const int row = s / CPR, c = (s % CPR) ^ (row & VKEY);
-    glds16(Vg + (long)row * T + c * 8, Vs + (p * NW * 64 + wave * 64) * 16);
-  }
-
-  f32x16 Oa[JQ][2];  // [jq][db]
-#pragma unroll
-  for (int jq = 0; jq < JQ; ++jq)
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) Oa[jq][db][e] = 0.f;
-  float mrun[JQ], lrun[JQ];
-#pragma unroll
-  for (int jq = 0; jq < JQ; ++jq) {
-    mrun[jq] = -3.0e38f;
-    lrun[jq] = 0.f;
-  }
-
-  if (NPASS == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  __builtin_amdgcn_s_barrier();  // raw barrier: __syncthreads() would drain the in-flight V^T DMAs
-  asm volatile("" ::: "memory");
-
-  const int vkey = l31 & VKEY;  // rows d and d+32 share the key (VKEY <= 15)
-  f32x16 zero16;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) zero16[e] = 0.f;
-  // S^T block kb: 32 keys x 64 queries (the first MFMA takes a shared all-zero C: no per-block accumulator clears)
-  auto qk = [&](f32x16 (&S)[JQ], int kb) {
-    const int row = kb * 32 + l31;
-    const int key = (row >> 1) & 7;
-    const char* kp = Ks + row * 128;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const half8_t kf = *(const half8_t*)(kp + (((ks * 2 + hsel) ^ key) << 4));
-#pragma unroll
-      for (int jq = 0; jq < JQ; ++jq) S[jq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[jq][ks], ks == 0 ? zero16 : S[jq], 0, 0, 0);
-    }
-  };
-  // online softmax update for the two queries this lane owns, then O^T[d][q] += sum_key V^T[d][key] P[q][key].
-  // VALU diet (the kernel is VALU-bound: ~2.3k VALU per wave vs 128 MFMAs): 3-input max, packed fp32 FMA / ADD on
-  // register pairs, one v_permlane32_swap instead of a ds_bpermute round trip for the lane^32 exchange.
-  auto softmax_pv = [&](f32x16 (&S)[JQ], int kb) {
-    half8_t P[JQ][2];
-#pragma unroll
-    for (int jq = 0; jq < JQ; ++jq) {
-      float mx = fmaxf(fmaxf(S[jq][0], S[jq][1]), S[jq][2]);
-#pragma unroll
-      for (int e = 3; e < 15; e += 2) mx = fmaxf(fmaxf(mx, S[jq][e]), S[jq][e + 1]);
-      mx = fmaxf(mx, S[jq][15]);
-      mx = fmaxf(mx, xhalf(mx));
-      const float mnew = fmaxf(mrun[jq], mx);
-      const float alpha = __builtin_amdgcn_exp2f((mrun[jq] - mnew) * scale_log2e);
-      mrun[jq] = mnew;
-      const f32x2 sc2 = {scale_log2e, scale_log2e};
-      const float mbs = mnew * scale_log2e;
-      const f32x2 mb2 = {mbs, mbs};
-      f32x2 sum2 = {0.f, 0.f};
-#pragma unroll
-      for (int e = 0; e < 16; e += 2) {
-        const f32x2 s2 = {S[jq][e], S[jq][e + 1]};
-        const f32x2 a2 = s2 * sc2 - mb2;  // v_pk_fma_f32
-        const f32x2 p2 = {__builtin_amdgcn_exp2f(a2.x), __builtin_amdgcn_exp2f(a2.y)};
-        sum2 += p2;  // v_pk_add_f32
-        P[jq][e >> 3][e & 7] = (half_t)p2.x;
-        P[jq][e >> 3][(e & 7) + 1] = (half_t)p2.y;
-      }
-      lrun[jq] = lrun[jq] * alpha + (sum2.x + sum2.y);
-      if (!__all(alpha == 1.0f)) {  // wave-uniform: most key blocks do not raise any query's running max
-#pragma unroll
-        for (int db = 0; db < 2; ++db) Oa[jq][db] *= alpha;
-      }
-    }
-    if (kb == 0) {  // V^T was issued after K and Q: only now must it have landed (every wave's share)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-    }
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-#pragma unroll
-      for (int db = 0; db < 2; ++db) {
-        const int d = db * 32 + l31;
-        const int c0 = kb * 4 + 2 * s;
-        const char* rowp = Vs + d * (2 * T) + hsel * 8;
-        const half4_t lo = *(const half4_t*)(rowp + ((c0 ^ vkey) << 4));
-        const half4_t hi = *(const half4_t*)(rowp + (((c0 + 1) ^ vkey) << 4));
-        const half8_t vf = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-#pragma unroll
-        for (int jq = 0; jq < JQ; ++jq) Oa[jq][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, P[jq][s], Oa[jq][db], 0, 0, 0);
-      }
-    }
-  };
-  // software pipeline over the key blocks: the S MFMAs of block kb+1 are issued BEFORE the softmax VALU of block kb, so
-  // the matrix pipe works underneath the VALU-heavy part instead of the wave idling on the MFMA -> max -> exp -> MFMA chain
-  f32x16 Sa[JQ], Sb[JQ];
-  qk(Sa, 0);
-#pragma unroll 1
-  for (int kb = 0; kb < NKB; kb += 2) {
-    qk(Sb, kb + 1);
-    softmax_pv(Sa, kb);
-    if (kb + 2 < NKB) qk(Sa, kb + 2);
-    softmax_pv(Sb, kb + 1);
-  }
-  // ---- normalise and store: lane owns query q, d = db*32 + 8g + 4*hsel + r
-#pragma unroll
-  for (int jq = 0; jq < JQ; ++jq) {
-    const float inv = 1.0f / (lrun[jq] + xhalf(lrun[jq]));
-    half_t* orow = O + ((long)img * T + q0 + jq * 32 + l31) * D + head * 64;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        half4_t h = {(half_t)(Oa[jq][db][4 * g] * inv), (half_t)(Oa[jq][db][4 * g + 1] * inv), (half_t)(Oa[jq][db][4 * g + 2] * inv),
-                     (half_t)(Oa[jq][db][4 * g + 3] * inv)};
-        *(half4_t*)(orow + db * 32 + 8 * g + 4 * hsel) = h;
-      }
-  }
-}
+#include "attention_kernel.h"  // dit_attention_kernel<T, JQ, HD> + attention_launch
 
 // ------------------------------------------------------------------ final layer + unpatchify + solver update
 // (DiT.py:134-149,230-243,270-271; CFG combine :285-287; Euler update test_flow_latent.py:61-73 via torchdiffeq)
@@ -618,10 +453,12 @@ static DitWs carve(const lfm_dit_shape* s, int B, void* ws, bool sizing = false)
 static int check_shape(const lfm_dit_shape* s) {
   if (!s) return LFM_ERR_ARG;
   if (s->depth <= 0 || s->hidden <= 0 || s->heads <= 0 || s->patch <= 0 || s->in_ch <= 0 || s->res <= 0) return LFM_ERR_SHAPE;
-  if (s->hidden % s->heads || s->hidden / s->heads != 64) return LFM_ERR_SHAPE;  // hd must be 64 (S/B/L; XL has 72)
+  if (s->hidden % s->heads) return LFM_ERR_SHAPE;
+  const int hd = s->hidden / s->heads;
+  if (hd != 64 && hd != 72) return LFM_ERR_SHAPE;  // S / B / L: 64; XL: 1152 / 16 = 72
   if (s->res % s->patch) return LFM_ERR_SHAPE;
   const int T = (s->res / s->patch) * (s->res / s->patch);
-  if (T != 64 && T != 128 && T != 256) return LFM_ERR_SHAPE;
+  if (T != 16 && T != 64 && T != 128 && T != 256) return LFM_ERR_SHAPE;  // attention kernels: LDS-resident K / V^T up to 256 tokens
   if (s->hidden % 64 || s->hidden > 256 * LN_MAXV || s->mlp_hidden % 64) return LFM_ERR_SHAPE;
   const int kk = s->patch * s->patch * s->in_ch;
   if (kk > FIN_MAXO || (kk > PE_MAXK && (kk % 64))) return LFM_ERR_SHAPE;  // small patches: register kernel; large: GEMM (K % 64 == 0)
@@ -647,38 +484,15 @@ extern "C" size_t lfm_dit_workspace_bytes(const lfm_dit_shape* shape, int max_ba
   return carve(shape, max_batch, nullptr, true).total;
 }
 
-int lfm_gemm_debug_flags();
-static int attention_launch(const half_t* Q, const half_t* K, const half_t* Vt, half_t* O, int batch, int heads, int T, hipStream_t st) {
-  const int D = heads * 64;
-  const float sl2 = 0.125f * 1.4426950408889634f;  // hd^-0.5 * log2(e)
-  const size_t lds = (size_t)T * 256;
-  dim3 grid(heads, batch);
-  // A/B switch (measurement only): 8 waves x 32 queries (4 waves/SIMD) measured 44.3 us vs 40.2 us for 4 waves x 64 queries --
-  // the kernel moves Q,K,V^T,O = 134 MB per launch (3.4 TB/s): it is HBM-bound, not latency-bound, so more waves do not help
-  const bool narrow = T == 256 && (lfm_gemm_debug_flags() & 256);
-#define ATT_CASE(TT, JQ)                                                                                                          \
-  {                                                                                                                              \
-    static bool set = false;                                                                                                     \
-    if (!set) {                                                                                                                  \
-      (void)hipFuncSetAttribute((const void*)dit_attention_kernel<TT, JQ>, hipFuncAttributeMaxDynamicSharedMemorySize, TT * 256); \
-      set = true;                                                                                                                \
-    }                                                                                                                            \
-    hipLaunchKernelGGL((dit_attention_kernel<TT, JQ>), grid, dim3((TT / (32 * JQ)) * 64), lds, st, Q, K, Vt, O, D, heads, sl2);    \
-  }
-  if (T == 64) ATT_CASE(64, 2)
-  else if (T == 128) ATT_CASE(128, 2)
-  else if (T == 256 && narrow) ATT_CASE(256, 1)
-  else if (T == 256) ATT_CASE(256, 2)
-  else return LFM_ERR_SHAPE;
-#undef ATT_CASE
-  LFM_CHECK_LAUNCH();
-  return LFM_OK;
-}
-
-extern "C" int lfm_dit_attention(const void* Q, const void* K, const void* Vt, void* O, int batch, int heads, int T, lfm_stream_t stream) {
+extern "C" int lfm_dit_attention_hd(const void* Q, const void* K, const void* Vt, void* O, int batch, int heads, int head_dim, int T,
+                                    lfm_stream_t stream) {
   if (!Q || !K || !Vt || !O) return LFM_ERR_ARG;
   if (batch <= 0 || heads <= 0) return LFM_ERR_SHAPE;
-  return attention_launch((const half_t*)Q, (const half_t*)K, (const half_t*)Vt, (half_t*)O, batch, heads, T, (hipStream_t)stream);
+  if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)Vt | (uintptr_t)O) & 15) return LFM_ERR_ALIGN;
+  return attention_launch((const half_t*)Q, (const half_t*)K, (const half_t*)Vt, (half_t*)O, batch, heads, head_dim, T, (hipStream_t)stream);
+}
+extern "C" int lfm_dit_attention(const void* Q, const void* K, const void* Vt, void* O, int batch, int heads, int T, lfm_stream_t stream) {
+  return lfm_dit_attention_hd(Q, K, Vt, O, batch, heads, 64, T, stream);
 }
 
 static int ln_modulate_launch(const float* X, half_t* A, int M, int D, int tokens, const float* shift, const float* scale, long stride,
@@ -762,7 +576,7 @@ extern "C" int lfm_gemm_qkv_f16(const void* A, long lda, const void* W, long ldw
                                 const float* bias, int head_dim, int tokens, lfm_stream_t stream) {
   if (!A || !W || !Q || !Kout || !Vt || !bias) return LFM_ERR_ARG;
   if ((lda % 8) || ((uintptr_t)A & 15)) return LFM_ERR_ALIGN;
-  if (head_dim <= 0 || tokens <= 0 || (D % head_dim) || (head_dim % 32) || (tokens % 4) || (M % tokens)) return LFM_ERR_SHAPE;
+  if (head_dim <= 0 || tokens <= 0 || (D % head_dim) || (head_dim % 8) || (tokens % 4) || (M % tokens)) return LFM_ERR_SHAPE;
   if (g_gemm_sel == 5 && (g_gemm_dbg & 2) && K % G256Q_BK == 0)
     return launch_gemm256h_tn<ASrcRowMajor, EpiQKV, true>(ASrcRowMajor{(const half_t*)A, lda, M, 0}, (const half_t*)W, ldw, M, 3 * D, K,
                                                           EpiQKV::make((half_t*)Q, (half_t*)Kout, (half_t*)Vt, bias, D, head_dim, tokens),
@@ -833,11 +647,11 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
     const float* mod = ws.mod + (long)i * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
     rc = ln_modulate_launch(ws.X, ws.A, M, D, T, mod, mod + D, mstride, st);
     if (rc) return rc;
-    const EpiQKV e_qkv = EpiQKV::make(Qb, Kb, Vb, w->qkv_b + (size_t)i * 3 * D, D, 64, T);
+    const EpiQKV e_qkv = EpiQKV::make(Qb, Kb, Vb, w->qkv_b + (size_t)i * 3 * D, D, D / s->heads, T);
     rc = launch_gemm_splitk(ws.A, D, (const half_t*)w->qkv_w + (size_t)i * 3 * D * D, D, M, 3 * D, D, e_qkv, ws.slab, ws.slab_bytes, st);
     if (rc == 1) rc = launch_gemm_auto(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->qkv_w + (size_t)i * 3 * D * D, D, M, 3 * D, D, e_qkv, st);
     if (rc) return rc;
-    rc = attention_launch(Qb, Kb, Vb, ws.A, B, s->heads, T, st);
+    rc = attention_launch(Qb, Kb, Vb, ws.A, B, s->heads, D / s->heads, T, st);
     if (rc) return rc;
     const EpiGateResidF32 e_proj{ws.X, D, w->proj_b + (size_t)i * D, mod + 2 * D, mstride, T};
     rc = launch_gemm_splitk(ws.A, D, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D, e_proj, ws.slab, ws.slab_bytes, st);

@@ -74,6 +74,8 @@ def lib():
     L.lfm_ln_modulate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
     L.lfm_dit_attention.restype = C.c_int
     L.lfm_dit_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.lfm_dit_attention_hd.restype = C.c_int
+    L.lfm_dit_attention_hd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.lfm_grid_advance.restype = C.c_int
     L.lfm_grid_advance.argtypes = [C.c_void_p] * 7
     L.lfm_lincomb.restype = C.c_int
@@ -200,10 +202,11 @@ def ln_modulate(X, shift, scale, tokens, mod_stride):
     return A
 
 
-def dit_attention(Q, K, Vt, batch, heads, T):
+def dit_attention(Q, K, Vt, batch, heads, T, head_dim=64):
+    """Q, K, O: fp16 [batch*T, heads*head_dim]; Vt: fp16 [batch, heads, head_dim, T].  head_dim 64 or 72 (DiT-XL)."""
     require_gpu(Q, "dit_attention")
     O = torch.empty_like(Q)
-    check(lib().lfm_dit_attention(ptr(Q), ptr(K), ptr(Vt), ptr(O), batch, heads, T, stream_ptr()), "lfm_dit_attention")
+    check(lib().lfm_dit_attention_hd(ptr(Q), ptr(K), ptr(Vt), ptr(O), batch, heads, head_dim, T, stream_ptr()), "lfm_dit_attention_hd")
     return O
 
 

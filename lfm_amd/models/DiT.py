@@ -96,11 +96,11 @@ class DiT(nn.Module):
         # what the HIP kernels are built for (csrc/dit.hip::check_shape) -- refuse at construction, not at the first forward
         tokens = (img_resolution // patch_size) ** 2 if patch_size and img_resolution % patch_size == 0 else 0
         kk = patch_size * patch_size * in_channels
-        if hidden_size % num_heads or hidden_size // num_heads != 64:
-            raise NotImplementedError(f"DiT with head_dim {hidden_size / num_heads:g} (DiT-XL: 1152 / 16 = 72): the LDS-resident attention kernel is "
-                                      "built for head_dim 64 (DiT-S / B / L, every configuration the reference ships)")
-        if tokens not in (64, 128, 256) or (kk > 16 and kk % 64) or kk > 256 or hidden_size % 64 or hidden_size > 1280:
-            raise NotImplementedError(f"DiT shape not built: {tokens} tokens (need 64 / 128 / 256), patch inputs {kk} (need <= 16 or a multiple of 64 up "
+        if hidden_size % num_heads or hidden_size // num_heads not in (64, 72):
+            raise NotImplementedError(f"DiT with head_dim {hidden_size / num_heads:g}: the LDS-resident attention kernel is built for head_dim 64 "
+                                      "(DiT-S / B / L) and 72 (DiT-XL: 1152 / 16)")
+        if tokens not in (16, 64, 128, 256) or (kk > 16 and kk % 64) or kk > 256 or hidden_size % 64 or hidden_size > 1280:
+            raise NotImplementedError(f"DiT shape not built: {tokens} tokens (need 16 / 64 / 128 / 256), patch inputs {kk} (need <= 16 or a multiple of 64 up "
                                       f"to 256), hidden {hidden_size} (multiple of 64, <= 1280)")
         self.learn_sigma = learn_sigma
         self.in_channels = in_channels

@@ -3,6 +3,7 @@
 Tolerances (SURVEY.md §8c rule 4; fp16 operands, fp32 accumulate, fp32 residual stream):
   per-forward velocity rel-L2 <= 2e-3 against the fp32 oracle.
 """
+import functools
 import os
 
 import pytest
@@ -55,19 +56,9 @@ def test_gemm_epilogues(dev, M, N, K, epi):
     assert rel_l2(got, ref) < (2e-3 if epi in (0, 1) else 2e-4)
 
 
-@pytest.mark.parametrize("M,N,K", [(512, 512, 128), (1024, 768, 1024), (300, 260, 64), (4096, 1024, 4096), (8192, 3072, 1024),
-                                   (512, 256, 192), (256, 512, 320), (768, 512, 576), (512, 128, 96), (384, 132, 160), (256, 128, 32),
-                                   (65536, 128, 1152)])
-@pytest.mark.parametrize("epi", [0, 1, 2, 3])
-@pytest.mark.parametrize("kernel", [2, 3, 3 | (1 << 4), 4, 4 | (1024 << 4), 5, 5 | (1024 << 4)])
-def test_gemm256_kernels(dev, M, N, K, epi, kernel):
-    """Same checks with a 256-row kernel forced (lfm_gemm_select: 2 = ping-pong, 3 = quadrant-phased, 3 | 1<<4 = its two-barrier schedule, 4 = the
-    256x128 two-workgroups-per-CU kernel, 4 | 1024<<4 = with the 8-byte-store epilogue, 5 = the quadrant-phased kernel on 16x16x32 MFMAs (the default for chip-filling shapes); K covers 1, 2, 3, 5, odd and even numbers of 64- and
-    32-deep K-tiles, i.e. every prologue / tail path; N = 128 / 132 the narrow shapes); repeated launches screen for races."""
-    if (kernel & 15) != 4 and M > 8192 and N == 128:
-        pytest.skip("the narrow-N convolution shape is the 256x128 kernel's")
-    from lfm_amd import hip
-
+@functools.lru_cache(maxsize=64)
+def _gemm_case(M, N, K, epi):
+    """Host operands and the fp32 reference of one (shape, epilogue) case: shared by every kernel the case is run with."""
     g = torch.Generator().manual_seed(M + N * 3 + K + epi)
     A = (torch.randn(M, K, generator=g) * 0.5).half()
     W = (torch.randn(N, K, generator=g) / K ** 0.5).half()
@@ -81,6 +72,24 @@ def test_gemm256_kernels(dev, M, N, K, epi, kernel):
         X = torch.randn(M, N, generator=g)
         gate = torch.randn(M // tokens, N, generator=g)
         ref = X + gate.repeat_interleave(tokens, 0) * ref
+    return A, W, bias, X, gate, ref, tokens
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 512, 128), (1024, 768, 1024), (300, 260, 64), (4096, 1024, 4096), (8192, 3072, 1024),
+                                   (512, 256, 192), (256, 512, 320), (768, 512, 576), (512, 128, 96), (384, 132, 160), (256, 128, 32),
+                                   (65536, 128, 1152)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+@pytest.mark.parametrize("kernel", [2, 3, 3 | (1 << 4), 4, 4 | (1024 << 4), 5, 5 | (1024 << 4)])
+def test_gemm256_kernels(dev, M, N, K, epi, kernel):
+    """Same checks with a 256-row kernel forced (lfm_gemm_select: 2 = ping-pong, 3 = quadrant-phased, 3 | 1<<4 = its two-barrier schedule, 4 = the
+    256x128 two-workgroups-per-CU kernel, 4 | 1024<<4 = with the 8-byte-store epilogue, 5 = the quadrant-phased kernel on 16x16x32 MFMAs (the default for chip-filling shapes); K covers 1, 2, 3, 5, odd and even numbers of 64- and
+    32-deep K-tiles, i.e. every prologue / tail path; N = 128 / 132 the narrow shapes); repeated launches screen for races."""
+    if (kernel & 15) != 4 and M > 8192 and N == 128:
+        pytest.skip("the narrow-N convolution shape is the 256x128 kernel's")
+    from lfm_amd import hip
+
+    A, W, bias, X, gate, ref, tokens = _gemm_case(M, N, K, epi)
+    if gate is not None:
         gate = gate.to(dev)
     hip.gemm_select(kernel)
     try:
@@ -111,19 +120,24 @@ def test_gemm256_detects_transpose(dev, kernel):
     assert torch.equal(got.cpu(), W.float().t())
 
 
-@pytest.mark.parametrize("kernel", [1, 2, 3, 3 | (1 << 4), 3 | (1024 << 4), 4, 5, 5 | (1024 << 4)])
-@pytest.mark.parametrize("batch,tokens,D,hd", [(3, 256, 384, 64), (8, 64, 512, 64), (2, 256, 1024, 64)])
-def test_gemm_qkv_split(dev, batch, tokens, D, hd, kernel):
-    """Fused QKV projection: Q, K row-major, V transposed per head (timm Attention's qkv + reshape + permute, DiT.py:120), with
-    every GEMM kernel (fragment-direct V^T stores in v1/v2 and v3's two-barrier schedule, operand-swapped V tiles in v3)."""
-    from lfm_amd import hip
-
+@functools.lru_cache(maxsize=8)
+def _qkv_case(batch, tokens, D):
     M = batch * tokens
     g = torch.Generator().manual_seed(batch + tokens + D)
     A = (torch.randn(M, D, generator=g) * 0.5).half()
     W = (torch.randn(3 * D, D, generator=g) / D ** 0.5).half()
     bias = torch.randn(3 * D, generator=g) * 0.1
-    ref = A.float() @ W.float().t() + bias
+    return A, W, bias, A.float() @ W.float().t() + bias
+
+
+@pytest.mark.parametrize("kernel", [1, 2, 3, 3 | (1 << 4), 3 | (1024 << 4), 4, 5, 5 | (1024 << 4)])
+@pytest.mark.parametrize("batch,tokens,D,hd", [(3, 256, 384, 64), (8, 64, 512, 64), (2, 256, 1024, 64), (2, 256, 1152, 72), (3, 64, 576, 72)])
+def test_gemm_qkv_split(dev, batch, tokens, D, hd, kernel):
+    """Fused QKV projection: Q, K row-major, V transposed per head (timm Attention's qkv + reshape + permute, DiT.py:120), with
+    every GEMM kernel (fragment-direct V^T stores in v1/v2 and v3's two-barrier schedule, operand-swapped V tiles in v3)."""
+    from lfm_amd import hip
+
+    A, W, bias, ref = _qkv_case(batch, tokens, D)
     hip.gemm_select(kernel)
     try:
         Q, K, Vt = hip.gemm_qkv_f16(A.to(dev), W.to(dev), bias.to(dev), hd, tokens)
@@ -172,30 +186,40 @@ def test_ln_modulate(dev, D, tokens, shared, n_img):
     assert rel_l2(got, ref) < 1e-3
 
 
-@pytest.mark.parametrize("T,heads,batch", [(256, 16, 3), (256, 2, 1), (64, 6, 2), (128, 4, 2), (256, 16, 17), (256, 16, 64), (256, 12, 43)])
-def test_attention(dev, T, heads, batch):
-    """Up to the benchmark's own shape (64 images x 16 heads x 256 tokens); every (image, head) item is checked on its own."""
+@pytest.mark.parametrize("T,heads,batch,hd", [(256, 16, 3, 64), (256, 2, 1, 64), (64, 6, 2, 64), (128, 4, 2, 64), (256, 16, 17, 64), (256, 16, 64, 64),
+                                              (256, 12, 43, 64), (256, 16, 3, 72), (64, 16, 5, 72), (128, 3, 2, 72), (256, 16, 33, 72), (16, 6, 7, 64), (16, 16, 3, 72)])
+def test_attention(dev, T, heads, batch, hd):
+    """Up to the benchmark's own shape (64 images x 16 heads x 256 tokens); every (image, head) item is checked on its own.
+    head_dim 72 = the DiT-XL family (4.5 MFMA k-slots, 2.25 output row blocks: the padding lanes must contribute exactly nothing)."""
     from lfm_amd import hip
 
     g = torch.Generator().manual_seed(T + heads)
-    D = heads * 64
-    q = (torch.randn(batch, heads, T, 64, generator=g) * 1.5).half()
-    k = (torch.randn(batch, heads, T, 64, generator=g) * 1.5).half()
-    v = torch.randn(batch, heads, T, 64, generator=g).half()
+    D = heads * hd
+    q = (torch.randn(batch, heads, T, hd, generator=g) * 1.5).half()
+    k = (torch.randn(batch, heads, T, hd, generator=g) * 1.5).half()
+    v = torch.randn(batch, heads, T, hd, generator=g).half()
     k[0, 0, 5] *= 6  # a spiky key row exercises the running-max rescale of the online softmax
-    ref = torch.softmax((q.float() @ k.float().transpose(-1, -2)) * 0.125, -1) @ v.float()
+    ref = torch.softmax((q.float() @ k.float().transpose(-1, -2)) * hd ** -0.5, -1) @ v.float()
     ref = ref.transpose(1, 2).reshape(batch * T, D)
     Q = q.transpose(1, 2).reshape(batch * T, D).contiguous().to(dev)
     K = k.transpose(1, 2).reshape(batch * T, D).contiguous().to(dev)
-    Vt = v.transpose(-1, -2).contiguous().to(dev)  # [b, h, 64, T]
-    got = hip.dit_attention(Q, K, Vt, batch, heads, T)
-    got2 = hip.dit_attention(Q, K, Vt, batch, heads, T)
+    Vt = v.transpose(-1, -2).contiguous().to(dev)  # [b, h, hd, T]
+    got = hip.dit_attention(Q, K, Vt, batch, heads, T, head_dim=hd)
+    got2 = hip.dit_attention(Q, K, Vt, batch, heads, T, head_dim=hd)
     torch.cuda.synchronize()
     assert rel_l2(got, ref) < 2e-3
     assert torch.equal(got, got2)
-    per_item = (got.float().cpu().reshape(batch, T, heads, 64) - ref.reshape(batch, T, heads, 64)).pow(2).sum((1, 3)).sqrt() / \
-        ref.reshape(batch, T, heads, 64).pow(2).sum((1, 3)).sqrt()
+    per_item = (got.float().cpu().reshape(batch, T, heads, hd) - ref.reshape(batch, T, heads, hd)).pow(2).sum((1, 3)).sqrt() / \
+        ref.reshape(batch, T, heads, hd).pow(2).sum((1, 3)).sqrt()
     assert float(per_item.max()) < 4e-3  # no single (image, head) item is off (a stale-buffer bug would hit whole items)
+
+
+def test_attention_refuses_unbuilt_head_sizes(dev):
+    from lfm_amd import hip
+
+    z = torch.zeros(256, 96, device=dev, dtype=torch.float16)
+    with pytest.raises(hip.LfmHipError):
+        hip.dit_attention(z, z, z.reshape(1, 1, 96, 256), 1, 1, 256, head_dim=96)
 
 
 # ----------------------------------------------------------------------------- whole model
@@ -224,6 +248,36 @@ def test_dit_matches_reference_golden(dev, golden_dir, which):
         assert rel_l2(got, rec["v_cfg"]) < 2e-3
 
 
+def test_dit_head_dim_72_matches_reference_golden(dev, golden_dir):
+    """The DiT-XL family's head size (1152 / 16 = 72, reference models/DiT.py:354-363): golden from the unmodified reference on a 576-wide,
+    8-head, depth-2 model (tests/golden/dit_hd72.pt; weights regenerated from the seeded state maker, checksum-checked), then
+    DiT-XL/2 and DiT-XL/4 at full size against the oracle -- XL/2 once at a batch that reaches the 256x256 GEMM kernels through auto-dispatch."""
+    rec = _load(golden_dir, "dit_hd72.pt")
+    cfg = dit_ref.DiTCfg(**rec["cfg"])
+    sd = dit_ref.make_dit_state(cfg, seed=rec["state_seed"])
+    assert abs(float(sum(v.double().abs().sum() for v in sd.values())) - rec["state_checksum"]) < 1e-6 * rec["state_checksum"]
+    m = _model_from_state(rec["cfg"], sd, dev)
+    x, y = rec["x"].to(dev), rec["y"].to(dev)
+    assert rel_l2(m(torch.tensor([0.9, 0.5, 0.02], device=dev), x, y), rec["v_tN"]) < 2e-3
+    got = m.forward_with_cfg(torch.tensor(0.37, device=dev), rec["x_cfg"].to(dev), rec["y_cfg"].to(dev), cfg_scale=rec["cfg_scale"])
+    assert rel_l2(got, rec["v_cfg"]) < 2e-3
+    from lfm_amd.models import DiT_models
+
+    for name, batch in (("DiT-XL/2", 2), ("DiT-XL/4", 3), ("DiT-XL/2", 48)):
+        kw = dict(num_classes=10, label_dropout=0.1)
+        cfg = dit_ref.DiTCfg.named(name, **kw)
+        sd = dit_ref.make_dit_state(cfg, seed=5)
+        mm = DiT_models[name](img_resolution=32, in_channels=4, **kw)
+        mm.load_state_dict(sd, strict=True)
+        mm = mm.to(dev).eval()
+        g = torch.Generator().manual_seed(9)
+        xx = torch.randn(batch, 4, 32, 32, generator=g)
+        yy = torch.randint(0, 10, (batch,), generator=g)
+        t = torch.linspace(0.2, 0.9, batch)
+        assert rel_l2(mm(t.to(dev), xx.to(dev), yy.to(dev)), dit_ref.dit_forward(sd, cfg, t, xx, yy)) < 2e-3, (name, batch)
+        del mm
+
+
 def test_dit_patch4_matches_reference_golden(dev, golden_dir):
     """DiT-x/4 family: the patch embedding runs on the MFMA GEMM (K = 64), the final layer emits 64 outputs per token in four passes.
     Golden from the unmodified reference (tests/golden/dit_p4.pt); then DiT-S/4 and DiT-B/4 at full size against the oracle."""
@@ -235,7 +289,7 @@ def test_dit_patch4_matches_reference_golden(dev, golden_dir):
     assert rel_l2(got, rec["v_cfg"]) < 2e-3
     from lfm_amd.models import DiT_models
 
-    for name, batch in (("DiT-S/4", 5), ("DiT-B/4", 2)):
+    for name, batch in (("DiT-S/4", 5), ("DiT-B/4", 2), ("DiT-S/8", 9), ("DiT-XL/8", 3)):  # x/8 on 32x32 latents: 16 tokens of 256 inputs
         kw = dict(num_classes=10, label_dropout=0.1)
         cfg = dit_ref.DiTCfg.named(name, **kw)
         sd = dit_ref.make_dit_state(cfg, seed=4)
@@ -274,13 +328,9 @@ def test_dit_matches_oracle_fullsize(dev, name, batch, kw):
         assert rel_l2(got, ref) < 2e-3, (name, t)
 
 
-@pytest.mark.parametrize("kernel", [1, 2, 3, 3 | (1 << 4), 4, 5])
-@pytest.mark.parametrize("name,batch", [("DiT-S/2", 5), ("DiT-B/2", 3)])
-def test_dit_with_every_gemm_kernel(dev, name, batch, kernel):
-    """The same forward with each GEMM kernel forced (auto picks by size, so small test batches would never reach the 256x256
-    kernels through the model): covers the fused epilogues in situ, in particular the QKV split with V written transposed
-    (fragment-direct in v1/v2, operand-swapped tiles + transposed epilogue in v3)."""
-    from lfm_amd import hip
+@functools.lru_cache(maxsize=4)
+def _every_kernel_case(name, batch):
+    """Model on the GPU, inputs and the oracle's answer: built once per (model, batch), run with every kernel."""
     from lfm_amd.models import DiT_models
 
     kw = dict(num_classes=10, label_dropout=0.1)
@@ -288,12 +338,24 @@ def test_dit_with_every_gemm_kernel(dev, name, batch, kernel):
     sd = dit_ref.make_dit_state(cfg, seed=3)
     m = DiT_models[name](img_resolution=32, in_channels=4, **kw)
     m.load_state_dict(sd, strict=True)
-    m = m.to(dev).eval()
+    m = m.to(torch.device("cuda:0")).eval()
     g = torch.Generator().manual_seed(7)
     x = torch.randn(batch, 4, 32, 32, generator=g)
     y = torch.randint(0, 10, (batch,), generator=g)
     t = torch.linspace(0.2, 0.8, batch)
-    ref = dit_ref.dit_forward(sd, cfg, t, x, y)
+    return m, x, y, t, dit_ref.dit_forward(sd, cfg, t, x, y)
+
+
+@pytest.mark.parametrize("kernel", [1, 2, 3, 3 | (1 << 4), 4, 5])
+@pytest.mark.parametrize("name,batch", [("DiT-S/2", 5), ("DiT-B/2", 3), ("DiT-XL/2", 2)])
+def test_dit_with_every_gemm_kernel(dev, name, batch, kernel):
+    """The same forward with each GEMM kernel forced (auto picks by size, so small test batches would never reach the 256x256
+    kernels through the model): covers the fused epilogues in situ, in particular the QKV split with V written transposed
+    (fragment-direct in v1/v2, operand-swapped tiles + transposed epilogue in v3)."""
+    from lfm_amd import hip
+    from lfm_amd.models import DiT_models
+
+    m, x, y, t, ref = _every_kernel_case(name, batch)
     hip.gemm_select(kernel)
     try:
         got = m(t.to(dev), x.to(dev), y.to(dev))

@@ -251,12 +251,13 @@ def test_dit_workspace_requirement_is_monotone_in_the_batch():
     L = hip.lib()
     for kw in (dict(depth=24, hidden=1024, heads=16, mlp_hidden=4096, patch=2, in_ch=4, res=32, label_rows=1),     # DiT-L/2, T = 256
                dict(depth=12, hidden=768, heads=12, mlp_hidden=3072, patch=2, in_ch=4, res=32, label_rows=1001),   # DiT-B/2 class-conditional
-               dict(depth=12, hidden=384, heads=6, mlp_hidden=1536, patch=2, in_ch=4, res=16, label_rows=11)):    # T = 64
+               dict(depth=12, hidden=384, heads=6, mlp_hidden=1536, patch=2, in_ch=4, res=16, label_rows=11),     # T = 64
+               dict(depth=28, hidden=1152, heads=16, mlp_hidden=4608, patch=2, in_ch=4, res=32, label_rows=1)):   # DiT-XL/2: head_dim 72
         s = hip.DitShape(**kw)
         sizes = [L.lfm_dit_workspace_bytes(C.byref(s), b) for b in range(1, 70)]
         assert all(v > 0 for v in sizes)
         assert all(b >= a for a, b in zip(sizes, sizes[1:])), kw
-    bad = hip.DitShape(depth=28, hidden=1152, heads=16, mlp_hidden=4608, patch=2, in_ch=4, res=32, label_rows=1)  # DiT-XL: head_dim 72
+    bad = hip.DitShape(depth=28, hidden=1280, heads=16, mlp_hidden=5120, patch=2, in_ch=4, res=32, label_rows=1)  # head_dim 80: no kernel
     assert L.lfm_dit_workspace_bytes(C.byref(bad), 1) == 0
 
 
@@ -308,9 +309,13 @@ def test_flow_matching_pair_defines_the_sampled_ode():
 def test_unbuilt_dit_shapes_are_refused_at_construction():
     from lfm_amd.models import DiT_models
 
+    from lfm_amd.models import DiT
+
     with pytest.raises(NotImplementedError):
-        DiT_models["DiT-XL/2"](img_resolution=32, in_channels=4, num_classes=1, label_dropout=0.0)   # head_dim 72
+        DiT(img_resolution=32, hidden_size=1280, depth=2, num_heads=16, num_classes=1, label_dropout=0.0)   # head_dim 80: no attention kernel
+    DiT_models["DiT-XL/2"](img_resolution=32, in_channels=4, num_classes=1, label_dropout=0.0)       # head_dim 72: built
+    DiT_models["DiT-B/8"](img_resolution=32, in_channels=4, num_classes=1, label_dropout=0.0)        # 16 tokens: built
     with pytest.raises(NotImplementedError):
-        DiT_models["DiT-B/8"](img_resolution=32, in_channels=4, num_classes=1, label_dropout=0.0)    # 16 tokens
+        DiT_models["DiT-S/2"](img_resolution=64, in_channels=4, num_classes=1, label_dropout=0.0)    # 1024 tokens: K / V^T do not fit the LDS
     DiT_models["DiT-S/4"](img_resolution=32, in_channels=4, num_classes=1, label_dropout=0.0)        # 64 tokens, K = 64: built
     DiT_models["DiT-S/8"](img_resolution=64, in_channels=4, num_classes=1, label_dropout=0.0)        # 64 tokens, K = 256: built

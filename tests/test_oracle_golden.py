@@ -31,6 +31,31 @@ def test_dit_ref_matches_reference(golden_dir, which):
         torch.testing.assert_close(v, rec["v_cfg"], rtol=1e-5, atol=1e-6)
 
 
+def _hd72_state(rec):
+    cfg = dit_ref.DiTCfg(**rec["cfg"])
+    sd = dit_ref.make_dit_state(cfg, seed=rec["state_seed"])
+    # the fixture holds no weights: the seeded state must be the one the reference ran with
+    assert abs(float(sum(v.double().abs().sum() for v in sd.values())) - rec["state_checksum"]) < 1e-6 * rec["state_checksum"]
+    return cfg, sd
+
+
+def test_dit_ref_head_dim_72_and_patch_4_match_reference(golden_dir):
+    """The DiT-XL family's head size (1152 / 16 = 72, models/DiT.py:354-363) and the DiT-x/4 patch size, both produced by the unmodified
+    reference (tests/golden/dit_hd72.pt, dit_p4.pt)."""
+    rec = _load(golden_dir, "dit_hd72.pt")
+    cfg, sd = _hd72_state(rec)
+    assert cfg.hidden // cfg.heads == 72
+    assert float(rec["v_tN"].abs().mean()) > 1e-3
+    v = dit_ref.dit_forward(sd, cfg, torch.tensor([0.9, 0.5, 0.02]), rec["x"], rec["y"])
+    torch.testing.assert_close(v, rec["v_tN"], rtol=1e-5, atol=1e-6)
+    v = dit_ref.dit_forward_with_cfg(sd, cfg, torch.tensor(0.37), rec["x_cfg"], rec["y_cfg"], rec["cfg_scale"])
+    torch.testing.assert_close(v, rec["v_cfg"], rtol=1e-5, atol=1e-6)
+    rec = _load(golden_dir, "dit_p4.pt")
+    cfg = dit_ref.DiTCfg(**rec["cfg"])
+    v = dit_ref.dit_forward(rec["state_dict"], cfg, torch.tensor([0.9, 0.5, 0.02]), rec["x"], rec["y"])
+    torch.testing.assert_close(v, rec["v_tN"], rtol=1e-5, atol=1e-6)
+
+
 def test_pos_embed_closed_form(golden_dir):
     rec = _load(golden_dir, "dit_tiny.pt")["cond"]
     pe = dit_ref.sincos_pos_embed_2d(128, 16)
