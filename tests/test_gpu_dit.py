@@ -251,7 +251,7 @@ def test_dit_matches_reference_golden(dev, golden_dir, which):
 def test_dit_head_dim_72_matches_reference_golden(dev, golden_dir):
     """The DiT-XL family's head size (1152 / 16 = 72, reference models/DiT.py:354-363): golden from the unmodified reference on a 576-wide,
     8-head, depth-2 model (tests/golden/dit_hd72.pt; weights regenerated from the seeded state maker, checksum-checked), then
-    DiT-XL/2 and DiT-XL/4 at full size against the oracle -- XL/2 once at a batch that reaches the 256x256 GEMM kernels through auto-dispatch."""
+    DiT-XL/2 and DiT-XL/4 at full size against the oracle (XL/2 with every GEMM kernel forced: test_dit_with_every_gemm_kernel)."""
     rec = _load(golden_dir, "dit_hd72.pt")
     cfg = dit_ref.DiTCfg(**rec["cfg"])
     sd = dit_ref.make_dit_state(cfg, seed=rec["state_seed"])
@@ -263,7 +263,7 @@ def test_dit_head_dim_72_matches_reference_golden(dev, golden_dir):
     assert rel_l2(got, rec["v_cfg"]) < 2e-3
     from lfm_amd.models import DiT_models
 
-    for name, batch in (("DiT-XL/2", 2), ("DiT-XL/4", 3), ("DiT-XL/2", 48)):
+    for name, batch in (("DiT-XL/2", 2), ("DiT-XL/4", 3)):
         kw = dict(num_classes=10, label_dropout=0.1)
         cfg = dit_ref.DiTCfg.named(name, **kw)
         sd = dit_ref.make_dit_state(cfg, seed=5)
@@ -289,7 +289,7 @@ def test_dit_patch4_matches_reference_golden(dev, golden_dir):
     assert rel_l2(got, rec["v_cfg"]) < 2e-3
     from lfm_amd.models import DiT_models
 
-    for name, batch in (("DiT-S/4", 5), ("DiT-B/4", 2), ("DiT-S/8", 9), ("DiT-XL/8", 3)):  # x/8 on 32x32 latents: 16 tokens of 256 inputs
+    for name, batch in (("DiT-S/4", 5), ("DiT-B/4", 2), ("DiT-S/8", 9), ("DiT-B/8", 3)):  # x/8 on 32x32 latents: 16 tokens of 256 inputs
         kw = dict(num_classes=10, label_dropout=0.1)
         cfg = dit_ref.DiTCfg.named(name, **kw)
         sd = dit_ref.make_dit_state(cfg, seed=4)
