@@ -19,7 +19,13 @@
 
 int lfm_gemm_debug_flags();
 
-template <int T, int JQ, int HD>
+// MODE (measurement only, tools/r2_probe3.py): 0 = the kernel; 1 = memory phases only (stage K / V^T, fetch Q, store a row per query, no
+// S / softmax / PV); 2 = compute only (K / V^T are never fetched: the loop runs on whatever the LDS holds).  Round 2, 64 images x 16 heads x 256
+// tokens (profiles/r02_probe3_attention_phases_ln_rows.txt): whole kernel 40-41 us, memory phases 22-23 us, compute (with its Q / O traffic) 33-36 us
+// -- the kernel is bound by the instruction stream of its two waves per SIMD, and the memory phases already hide behind the co-resident workgroup.
+// Measured and NOT kept on that evidence: a streamed schedule (DMAs issued key block by key block, V^T slices as 64-byte pieces, the online-softmax
+// loop started after block 0 behind one counted vmcnt + barrier per block): correct, 40.8-41.7 us vs 40.1-42.8 us.
+template <int T, int JQ, int HD, int MODE = 0>
 __global__ __launch_bounds__((T / (32 * JQ)) * 64, HD == 64 ? (T / (32 * JQ)) / 2 : 2) void dit_attention_kernel(
     const half_t* __restrict__ Q, const half_t* __restrict__ K, const half_t* __restrict__ Vt, half_t* __restrict__ O, int D, int heads,
     float scale_log2e) {
@@ -56,7 +62,7 @@ __global__ __launch_bounds__((T / (32 * JQ)) * 64, HD == 64 ? (T / (32 * JQ)) / 
     if (SLOTS % NTHR == 0 || p + 1 < NPASS || s < SLOTS) {
       const int row = s / KCH, ch = s - row * KCH;
       const int c = KSWZ ? (ch ^ ((row >> 1) & 7)) : ch;
-      glds16(Kg + (long)row * D + c * 8, Ks + (p * NTHR + wave * 64) * 16);
+      if (MODE != 2) glds16(Kg + (long)row * D + c * 8, Ks + (p * NTHR + wave * 64) * 16);
     }
   }
   const int q0 = wave * 32 * JQ;
@@ -77,10 +83,20 @@ __global__ __launch_bounds__((T / (32 * JQ)) * 64, HD == 64 ? (T / (32 * JQ)) / 
     if (SLOTS % NTHR == 0 || p + 1 < NPASS || s < SLOTS) {
       constexpr int CPR = T / 8;  // 16-B chunks per V^T row
       const int row = s / CPR, c = (s % CPR) ^ (row & VKEY);
-      glds16(Vg + (long)row * T + c * 8, Vs + (p * NTHR + wave * 64) * 16);
+      if (MODE != 2) glds16(Vg + (long)row * T + c * 8, Vs + (p * NTHR + wave * 64) * 16);
     }
   }
 
+  if constexpr (MODE == 1) {  // everything has landed -> one output row per query, straight from the Q registers
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int jq = 0; jq < JQ; ++jq)
+#pragma unroll
+      for (int ks = 0; ks < HD / 16; ++ks)
+        *(half8_t*)(O + ((long)img * T + q0 + jq * 32 + l31) * D + head * HD + ks * 16 + hsel * 8) = qf[jq][ks];
+    return;
+  }
   f32x16 Oa[JQ][NDB];  // [jq][db]
 #pragma unroll
   for (int jq = 0; jq < JQ; ++jq)
@@ -271,6 +287,19 @@ static int attention_launch(const half_t* Q, const half_t* K, const half_t* Vt, 
   // A/B switch (measurement only): 8 waves x 32 queries (4 waves/SIMD) measured 44.3 us vs 40.2 us for 4 waves x 64 queries --
   // the kernel moves Q,K,V^T,O = 134 MB per launch (3.4 TB/s): more waves do not help
   const bool narrow = T == 256 && (lfm_gemm_debug_flags() & 256);
+  const int mode = (lfm_gemm_debug_flags() >> 25) & 3;  // flags 33554432 / 67108864: the measurement-only phase variants (hd 64, 256 tokens)
+  if (mode && hd == 64 && T == 256) {
+    static bool set = false;
+    if (!set) {
+      (void)hipFuncSetAttribute((const void*)dit_attention_kernel<256, 2, 64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 64 * 4);
+      (void)hipFuncSetAttribute((const void*)dit_attention_kernel<256, 2, 64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 64 * 4);
+      set = true;
+    }
+    if (mode == 1) hipLaunchKernelGGL((dit_attention_kernel<256, 2, 64, 1>), grid, dim3(256), lds, st, Q, K, Vt, O, D, heads, sl2);
+    else hipLaunchKernelGGL((dit_attention_kernel<256, 2, 64, 2>), grid, dim3(256), lds, st, Q, K, Vt, O, D, heads, sl2);
+    LFM_CHECK_LAUNCH();
+    return LFM_OK;
+  }
   if (T == 16) {
     const int items = batch * heads;
     if (hd == 64) hipLaunchKernelGGL(dit_attention_t16_kernel<64>, dim3((items + 3) / 4), dim3(64), 0, st, Q, K, Vt, O, D, heads, items, sl2);

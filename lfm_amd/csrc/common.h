@@ -37,6 +37,23 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// Full-wave sum on the DPP cross-lane network (quad swaps, two row rotations, row_bcast15 / row_bcast31), total read back from lane 63
+// through an SGPR: six VALU adds with DPP operands instead of six ds_bpermute round trips through the LDS (~100+ cycles each), which is
+// what __shfl_xor compiles to.  Every lane receives the same value.  Summation order differs from wave_sum (a tree over lanes either way).
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int m = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false);
+  return v + __builtin_bit_cast(float, m);
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v = dpp_add<0xB1>(v);        // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);        // quad_perm [2,3,0,1]
+  v = dpp_add<0x124>(v);       // row_ror:4
+  v = dpp_add<0x128>(v);       // row_ror:8   -> every lane of a 16-lane row holds the row total
+  v = dpp_add<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
+  v = dpp_add<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3 -> lane 63 holds the wave total
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -206,16 +206,18 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
 // Same computation with 16-byte stores: lane l owns EIGHT consecutive columns 8 (l + 64 i) .. + 7 (two adjacent float4 loads), so a row
 // of the fp16 output goes out as 16 B per lane instead of 8 (the GEMM epilogues gained 3-4 % from the same change).  D % 8 == 0.
 #define LN_MAXP 3  // column octets per lane: D <= 1536
+// NR = rows per wave, DPP = row sums on the DPP cross-lane network instead of ds_bpermute (<1, true> ships; the others are A/B variants)
+template <int NR, bool DPP = false>
 __global__ __launch_bounds__(256) void ln_modulate8_kernel(const float* __restrict__ X, half_t* __restrict__ A, int M, int D, int tokens,
                                                            const float* __restrict__ shift, const float* __restrict__ scale, long mod_stride) {
   const int lane = threadIdx.x & 63;
-  const long m0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_ROWS;
+  const long m0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * NR;
   if (m0 >= M) return;
   const int np = D >> 3;
-  f32x4 v[LN_ROWS][LN_MAXP][2];
-  float s[LN_ROWS];
+  f32x4 v[NR][LN_MAXP][2];
+  float s[NR];
 #pragma unroll
-  for (int r = 0; r < LN_ROWS; ++r) {
+  for (int r = 0; r < NR; ++r) {
     const long m = (m0 + r < M) ? m0 + r : M - 1;
     const f32x4* xr = (const f32x4*)(X + m * D);
     s[r] = 0.f;
@@ -231,10 +233,10 @@ __global__ __launch_bounds__(256) void ln_modulate8_kernel(const float* __restri
     }
   }
 #pragma unroll
-  for (int r = 0; r < LN_ROWS; ++r) {
+  for (int r = 0; r < NR; ++r) {
     const long m = m0 + r;
     if (m >= M) break;
-    const float mean = wave_sum(s[r]) / (float)D;
+    const float mean = (DPP ? wave_sum_dpp(s[r]) : wave_sum(s[r])) / (float)D;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < LN_MAXP; ++i) {
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(256) void ln_modulate8_kernel(const float* __restri
         }
       }
     }
-    const float rstd = rsqrtf(wave_sum(q) / (float)D + 1e-6f);
+    const float rstd = rsqrtf((DPP ? wave_sum_dpp(q) : wave_sum(q)) / (float)D + 1e-6f);
     const long mo = (m / tokens) * mod_stride;
     const f32x4* sh = (const f32x4*)(shift + mo);
     const f32x4* sc = (const f32x4*)(scale + mo);
@@ -499,7 +501,14 @@ static int ln_modulate_launch(const float* X, half_t* A, int M, int D, int token
                               hipStream_t st) {
   if (D % 4 || D > 256 * LN_MAXV) return LFM_ERR_SHAPE;
   if (D % 8 == 0 && !(((uintptr_t)A | (uintptr_t)X) & 15) && !(lfm_gemm_debug_flags() & 32768)) {  // flag 32768: the 8-byte-store kernel (A/B)
-    hipLaunchKernelGGL(ln_modulate8_kernel, dim3(cdiv(M, 4 * LN_ROWS)), dim3(256), 0, st, X, A, M, D, tokens, shift, scale, stride);
+    // ONE row per wave and the two row sums on the DPP network (r02_probe3: 17.0-17.2 us = 5.9 TB/s at M 16384 x D 1024; two rows per wave with
+    // ds_bpermute sums -- the round-1 choice -- 20.4-20.9 us, one row with ds_bpermute 17.5-17.8 us, four rows 23.3-24.0 us).  A/B flags: 65536 =
+    // one row + ds_bpermute sums, 524288 = two rows, 262144 = four rows.
+    const int f = lfm_gemm_debug_flags();
+    if (f & 65536) hipLaunchKernelGGL(ln_modulate8_kernel<1>, dim3(cdiv(M, 4)), dim3(256), 0, st, X, A, M, D, tokens, shift, scale, stride);
+    else if (f & 524288) hipLaunchKernelGGL(ln_modulate8_kernel<2>, dim3(cdiv(M, 8)), dim3(256), 0, st, X, A, M, D, tokens, shift, scale, stride);
+    else if (f & 262144) hipLaunchKernelGGL(ln_modulate8_kernel<4>, dim3(cdiv(M, 16)), dim3(256), 0, st, X, A, M, D, tokens, shift, scale, stride);
+    else hipLaunchKernelGGL((ln_modulate8_kernel<1, true>), dim3(cdiv(M, 4)), dim3(256), 0, st, X, A, M, D, tokens, shift, scale, stride);
     LFM_CHECK_LAUNCH();
     return LFM_OK;
   }
