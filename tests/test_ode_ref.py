@@ -14,6 +14,9 @@ sources that share no code or author with either file:
 * a full adaptive solve against ``scipy.integrate.solve_ivp(method="RK45")`` at the same tolerances (different controller and
   estimator, so the step sequences differ; both must sit within the tolerance band of a tight reference solution).
 """
+import functools
+import itertools
+
 import numpy as np
 import pytest
 import torch
@@ -225,7 +228,7 @@ def test_bosh3_tableau_equals_scipy_rk23_and_orders():
     assert prod._AH_SOL == (0.5, 0.5) and tuple(np.array(prod._AH_SOL) - np.array(prod._AH_E)) == (0.0, 1.0)
 
 
-@pytest.mark.parametrize("method,stages,tol", [("bosh3", 3, 1e-6), ("adaptive_heun", 1, 1e-5), ("dopri5", 6, 1e-7)])
+@pytest.mark.parametrize("method,stages,tol", [("bosh3", 3, 1e-6), ("adaptive_heun", 1, 1e-5), ("dopri5", 6, 1e-7), ("dopri8", 13, 1e-9)])
 def test_adaptive_pairs_solve_and_count(method, stages, tol):
     stats = {}
     y0 = torch.from_numpy(Y0)
@@ -237,7 +240,90 @@ def test_adaptive_pairs_solve_and_count(method, stages, tol):
         n_sci = solve_ivp(lambda t, y: -_f_np(t, y), (1.0, 0.0), Y0, method="RK23", rtol=tol, atol=tol).t.size - 1
         assert 0.4 * n_sci <= stats["accepted"] <= 2.5 * n_sci
     with pytest.raises(NotImplementedError):
-        prod.odeint(lambda t, y: -y, y0, torch.tensor([1.0, 0.0]), method="dopri8")
+        prod.odeint(lambda t, y: -y, y0, torch.tensor([1.0, 0.0]), method="tsit5")
+
+
+# ----------------------------------------------------------------------------- dopri8: the 13-stage Prince-Dormand 8(7) pair
+@functools.lru_cache(None)
+def _rooted_trees(n):
+    """All rooted trees with n vertices as canonical nested tuples (1, 1, 2, 4, 9, 20, 48, 115 of them for n = 1..8)."""
+    if n == 1:
+        return [()]
+
+    def parts(total, biggest):
+        if total == 0:
+            yield []
+            return
+        for p in range(min(total, biggest), 0, -1):
+            for rest in parts(total - p, p):
+                yield [p] + rest
+
+    out = set()
+    for part in parts(n - 1, n - 1):
+        for combo in itertools.product(*[_rooted_trees(p) for p in part]):
+            out.add(tuple(sorted(combo)))
+    return sorted(out)
+
+
+def _tree_order(t):
+    return 1 + sum(_tree_order(c) for c in t)
+
+
+def _tree_gamma(t):
+    g = _tree_order(t)
+    for c in t:
+        g *= _tree_gamma(c)
+    return g
+
+
+def _tree_phi(t, A):
+    v = np.ones(A.shape[0])
+    for c in t:
+        v = v * (A @ _tree_phi(c, A))
+    return v
+
+
+def _worst(b, A, orders, theta=1.0):
+    return max(abs(b @ _tree_phi(t, A) - theta ** r / _tree_gamma(t)) for r in orders for t in _rooted_trees(r))
+
+
+def test_dopri8_tableau_satisfies_every_order_condition():
+    """torchdiffeq is not installable, so its dopri8 table cannot be diffed; what CAN be checked is the mathematics: a Runge-Kutta method has
+    order p iff b . Phi(tau) = 1 / gamma(tau) for every rooted tree tau with at most p vertices.  The 8th-order weights satisfy all 200
+    conditions through order 8 and not those of order 9; the embedded weights all 85 through order 7 and not order 8 (so err = O(h^8)); a single
+    mistyped digit in any of the ~100 rationals breaks these at the 1e-9 level.  The midpoint weights (ours) satisfy the 17 conditions through
+    order 5 at theta = 1/2 on the tableau extended by the first-same-as-last stage."""
+    assert [len(_rooted_trees(n)) for n in range(1, 9)] == [1, 1, 2, 4, 9, 20, 48, 115]
+    n = 13
+    A = np.zeros((n, n))
+    for i, row in enumerate(prod._D8_B[:-1]):
+        A[i + 1, : len(row)] = row
+    c = np.array([0.0] + list(prod._D8_A[:-1]))
+    np.testing.assert_allclose(A.sum(1), c, rtol=0, atol=4e-15)
+    b8, b7 = np.array(prod._D8_SOL), np.array(prod._D8_EMB)
+    assert prod._D8_B[-1] == prod._D8_SOL and prod._D8_A[-1] == 1.0
+    assert _worst(b8, A, range(1, 9)) < 4e-15
+    assert _worst(b7, A, range(1, 8)) < 4e-15
+    assert _worst(b8, A, [9]) > 1e-6 and _worst(b7, A, [8]) > 1e-5
+    np.testing.assert_allclose(np.array(prod._D8_E), np.append(b8 - b7, 0.0), rtol=0, atol=0)
+    Ae = np.zeros((14, 14))
+    Ae[:13, :13] = A
+    Ae[13, :13] = b8
+    assert _worst(np.array(prod._D8_MID), Ae, range(1, 6), theta=0.5) < 1e-14
+
+
+def test_dopri8_local_error_is_ninth_order():
+    """One forced step of size h and of size h / 2 on the nonlinear field: the local error of an 8th-order method falls by 2^9."""
+    y0 = torch.from_numpy(Y0)
+    errs = []
+    for h in (0.06, 0.03):
+        s = prod.Dopri8(_f_torch, y0, torch.tensor(0.0, dtype=torch.float64), 1e-3, 1e-3)
+        s.dt = torch.tensor(h, dtype=torch.float64)
+        s._step()
+        assert s.accepted == 1
+        tight = solve_ivp(_f_np, (0.0, h), Y0, method="DOP853", rtol=1e-13, atol=1e-14).y[:, -1]
+        errs.append(np.abs(s.y0.numpy() - tight).max())
+    assert 8.0 < np.log2(errs[0] / errs[1]) < 10.0, errs
 
 
 def test_perturb_samples_inside_the_step():
