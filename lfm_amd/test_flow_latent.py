@@ -189,6 +189,8 @@ def build_parser():
     p.add_argument("--random_weights", action="store_true", help="synthetic weights instead of ./saved_info checkpoints (benchmarking)")
     p.add_argument("--heun_reference_quirk", type=int, default=1, help="1: corrector only on intervals < 39 as the reference does")
     p.add_argument("--save_dir", type=str, default=None)
+    p.add_argument("--fid_feature_extractor", type=str, default="", help="pkg.module:factory -- factory(device) returns f(uint8 NHWC batch) -> "
+                   "[n, 2048] pool3 features; with it --compute_fid reduces the statistics on the GPUs (lfm_amd/fid.py) instead of writing JPEGs")
     p.add_argument("--trust_checkpoint", action="store_true", help="allow the full (unsafe) unpickler for checkpoints the safe loader rejects")
     return p
 
@@ -264,6 +266,21 @@ def main(argv=None):
         n = args.batch_size
         total_samples = int(math.ceil(args.n_sample / n) * n)
         t0 = time.time()
+        if getattr(args, "fid_feature_extractor", ""):
+            # on-device statistics (lfm_amd/fid.py): the images never leave the GPU; mu / sigma / Frechet distance as fid_score.py:230-283
+            from .fid import FeatureStatistics, fid_against_reference_stats, load_feature_extractor
+
+            extract = load_feature_extractor(args.fid_feature_extractor, device)
+            stats = None
+            for i in range(total_samples // n):
+                feats = extract(images_to_uint8(run_sampling(model, vae, args, n, generator, device), rounding=True))
+                stats = stats or FeatureStatistics(feats.shape[1], feats.device)
+                stats.update(feats)
+            fid = fid_against_reference_stats(stats.all_reduce(), args.real_img_dir)
+            print("FID = {}".format(fid))
+            with open(args.output_log or os.devnull, "a") as f:
+                f.write("Epoch = {}, FID = {}\n".format(args.epoch_id, fid))
+            return
         for i in range(total_samples // n):
             img = run_sampling(model, vae, args, n, generator, device)
             # the single-process script writes through torchvision.utils.save_image: ROUNDING uint8 conversion (:264-269)

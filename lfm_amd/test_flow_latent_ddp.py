@@ -99,7 +99,7 @@ class GatherPipeline:
         return p
 
 
-def run(args, model, vae, generator, rank, world, device, to_uint8, save=None, log=print):
+def run(args, model, vae, generator, rank, world, device, to_uint8, save=None, log=print, extractor=None):
     """The reference's sampling loop (test_flow_latent_ddp.py:116-146) for one rank: ``iters`` batches, each solved and decoded
     locally, converted to uint8 on the device, all-gathered (overlapped with the next batch) and -- on rank 0 under --compute_fid --
     written out under the reference's global file indices ``j*world + rank + total`` (:138).  Returns what was done, for tests."""
@@ -114,6 +114,23 @@ def run(args, model, vae, generator, rank, world, device, to_uint8, save=None, l
             save(block, i * args.batch_size * world)
             written.append((i * args.batch_size * world, int(block.shape[0])))
 
+    extract = extractor
+    if extract is None and args.compute_fid and getattr(args, "fid_feature_extractor", ""):
+        from .fid import load_feature_extractor
+
+        extract = load_feature_extractor(args.fid_feature_extractor, device)
+    if extract is not None and args.compute_fid:
+        # on-device FID statistics: every rank reduces its own batches to (n, sum x, sum x x^T); ONE all_reduce of those sums replaces the
+        # per-batch all-gather of pixels and the JPEG rendezvous (lfm_amd/fid.py; reference fid_score.py:114-174, 230-251)
+        from .fid import FeatureStatistics
+
+        stats = None
+        for i in range(iters):
+            feats = extract(to_uint8(run_sampling(model, vae, args, args.batch_size, generator, device)))
+            stats = stats or FeatureStatistics(feats.shape[1], feats.device)
+            stats.update(feats)
+        stats.all_reduce()
+        return {"total": total, "iters": iters, "written": written, "gather_seconds": 0.0, "fid_stats": stats}
     for i in range(iters):
         img = run_sampling(model, vae, args, args.batch_size, generator, device)
         sink(pipe.submit(to_uint8(img)), i - 1)
@@ -123,7 +140,7 @@ def run(args, model, vae, generator, rank, world, device, to_uint8, save=None, l
 
 def main(argv=None, hooks=None):
     """torchrun entry point.  ``hooks`` (tests only) replaces the device-bound pieces for the CPU / gloo rehearsal of the multi-rank
-    control flow: {"backend", "device", "build_models", "to_uint8", "save"}; the product path (hooks=None) is RCCL + HIP only."""
+    control flow: {"backend", "device", "build_models", "to_uint8", "save", "extractor"}; the product path (hooks=None) is RCCL + HIP only."""
     from .autoencoder import images_to_uint8
 
     hooks = hooks or {}
@@ -144,10 +161,18 @@ def main(argv=None, hooks=None):
     generator = get_generator(args.generator, args.n_sample, args.seed)
     save_dir = args.save_dir or "./generated_samples/{}/exp{}_ep{}_m{}".format(args.dataset, args.exp, args.epoch_id, args.method)
     save = hooks.get("save") or (lambda block, start: save_images_uint8(block, save_dir, start))
-    res = run(args, model, vae, generator, rank, world, device, hooks.get("to_uint8", images_to_uint8), save)
+    res = run(args, model, vae, generator, rank, world, device, hooks.get("to_uint8", images_to_uint8), save, extractor=hooks.get("extractor"))
     dist.barrier()
+    if rank == 0 and "fid_stats" in res:  # reference :147-153: rank 0 reports and logs the score
+        from .fid import fid_against_reference_stats
+
+        res["fid"] = fid_against_reference_stats(res["fid_stats"], args.real_img_dir)
+        print("FID = {}".format(res["fid"]))
+        if getattr(args, "output_log", ""):
+            with open(args.output_log, "a") as f:
+                f.write("Epoch = {}, FID = {}\n".format(args.epoch_id, res["fid"]))
     if rank == 0:
-        print(f"sampled {res['total']} images on {world} GPUs" + (f" -> {save_dir}" if args.compute_fid else ""))
+        print(f"sampled {res['total']} images on {world} GPUs" + (f" -> {save_dir}" if args.compute_fid and "fid_stats" not in res else ""))
     if dist.is_initialized():
         dist.destroy_process_group()
     return res
