@@ -122,6 +122,12 @@ int lfm_gemm_select(int which);
 /* Measurement only: when enabled, every eager lfm_dit_forward records a HIP event pair around each block's fc1 GEMM (the
  * dominant kernel); lfm_profile_fc1_read synchronises and returns the per-launch durations in ms (bench.py roofline row). */
 int lfm_profile_fc1(int enable);
+/* Library-wide options.  key 1 (LFM_OPT_FUSE_LN), value 0 / 1: EXPERIMENTAL -- LayerNorm + modulate (models/DiT.py:20-21,119,121) computed
+ * inside the gated-residual epilogues of the proj / fc2 GEMMs where the shape allows it (whole 256-row tiles of one image, 1024-wide residual,
+ * chip-filling batch), instead of by separate lfm_ln_modulate launches.  Default 0.  Not yet measured on hardware. */
+#define LFM_OPT_FUSE_LN 1
+int lfm_set_option(int key, int value);
+
 /* Measurement only: s_memtime stamps written by the quadrant-phased GEMM (select flag 2) after every barrier of block 0,
  * wave groups 0 and 1; host_out receives 2 x n_per_group values. */
 int lfm_gemm_trace_read(unsigned long long* host_out, int n_per_group);

@@ -17,6 +17,14 @@ int lfm_gemm_prefers_v4(int M, int N, int K) {
   if (g_gemm_dbg & 8192) return 1;
   return 0;
 }
+static int g_opt_fuse_ln = 0;
+extern "C" int lfm_set_option(int key, int value) {  // key 1 (LFM_OPT_FUSE_LN): EXPERIMENTAL LayerNorm-modulate inside the gated-residual epilogues
+  if (key == 1) {
+    g_opt_fuse_ln = value != 0;
+    return LFM_OK;
+  }
+  return LFM_ERR_ARG;
+}
 extern "C" int lfm_gemm_select(int which) {  // low 4 bits: kernel choice (0 auto, 1..5); bits 4+: ablation flags (measurement only)
   if ((which & 15) > 5 || which < 0) return LFM_ERR_ARG;
   g_gemm_sel = which & 15;
@@ -416,6 +424,8 @@ struct DitWs {
   half_t* c_half; // [B, D]
   float* mod;     // [B, J]
   float* ones;    // [D] of 1.0f: gate row of the patch-embedding GEMM (large patches)
+  float* ln_part;      // [M][D / 256][2] row partials of the fused LayerNorm epilogue (experimental option)
+  unsigned* ln_count;  // [M / 256] panel counters + 1 word of spin time-outs
   float* slab;    // split-K partial tiles (small M only, else null)
   size_t slab_bytes;
   size_t total;
@@ -441,6 +451,8 @@ static DitWs carve(const lfm_dit_shape* s, int B, void* ws, bool sizing = false)
   w.c_half = (half_t*)take((size_t)B * D * 2);
   w.mod = (float*)take((size_t)B * J * 4);
   w.ones = (float*)take(D * 4);
+  w.ln_part = (float*)take(M * ((D + 255) / 256) * 8);
+  w.ln_count = (unsigned*)take((M / 256 + 2) * 4);
   // latency mode: room for up to 4 K slices of the widest GEMM output (fc1), when the token count is small
   // (when SIZING for a maximum batch, reserve the slabs of the largest small batch too, so that the requirement is monotone in the
   // batch and a workspace sized for max_batch serves every smaller batch)
@@ -652,10 +664,26 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
   half_t* Qb = ws.QKVH;
   half_t* Kb = Qb + (size_t)M * D;
   half_t* Vb = Kb + (size_t)M * D;
+  // EXPERIMENTAL (lfm_set_option(1, 1)): LayerNorm-modulate inside the proj / fc2 epilogues (EpiGateResidLN).  Only where its preconditions
+  // hold: whole 256-row tiles of ONE image each, the column tiles of a panel on one XCD (grid % 128 == 0 with the 4 x tiles_n tile groups),
+  // chip-filling shapes on the default kernel.
+  const int ln_tn = D / 256, ln_tm = M / 256;
+  const bool fuse_ln = g_opt_fuse_ln && (D % 256 == 0) && (M % 256 == 0) && (T % 256 == 0) && ln_tn == 4 && ((ln_tm * ln_tn) % 128 == 0) &&
+                       (g_gemm_sel == 0 || g_gemm_sel == 5) && !(g_gemm_dbg & 1048576) && (H % 64 == 0);
+  unsigned ln_launches = 0;
+  if (fuse_ln && lfm_zero_async(ws.ln_count, (size_t)(ln_tm + 1) * 4, st)) return LFM_ERR_LAUNCH;
+  auto gate_resid_ln = [&](const half_t* Asrc, long lda, const half_t* W, int K, const float* bias, const float* gate, const float* shift,
+                           const float* scale) {
+    EpiGateResidLN e{ws.X, D, bias, gate, mstride, T, ws.A, shift, scale, mstride, ws.ln_part, ws.ln_count, (unsigned)ln_tn * ++ln_launches, ln_tn,
+                     (int*)(ws.ln_count + ln_tm)};
+    return launch_gemm256h_tn(ASrcRowMajor{Asrc, lda, M, 0}, W, K, M, D, K, e, st);
+  };
   for (int i = 0; i < s->depth; ++i) {
     const float* mod = ws.mod + (long)i * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
-    rc = ln_modulate_launch(ws.X, ws.A, M, D, T, mod, mod + D, mstride, st);
-    if (rc) return rc;
+    if (!(fuse_ln && i > 0)) {  // fused: the previous block's fc2 epilogue already wrote this block's first LN-modulate
+      rc = ln_modulate_launch(ws.X, ws.A, M, D, T, mod, mod + D, mstride, st);
+      if (rc) return rc;
+    }
     const EpiQKV e_qkv = EpiQKV::make(Qb, Kb, Vb, w->qkv_b + (size_t)i * 3 * D, D, D / s->heads, T);
     rc = launch_gemm_splitk(ws.A, D, (const half_t*)w->qkv_w + (size_t)i * 3 * D * D, D, M, 3 * D, D, e_qkv, ws.slab, ws.slab_bytes, st);
     if (rc == 1) rc = launch_gemm_auto(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->qkv_w + (size_t)i * 3 * D * D, D, M, 3 * D, D, e_qkv, st);
@@ -663,11 +691,16 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
     rc = attention_launch(Qb, Kb, Vb, ws.A, B, s->heads, D / s->heads, T, st);
     if (rc) return rc;
     const EpiGateResidF32 e_proj{ws.X, D, w->proj_b + (size_t)i * D, mod + 2 * D, mstride, T};
-    rc = launch_gemm_splitk(ws.A, D, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D, e_proj, ws.slab, ws.slab_bytes, st);
-    if (rc == 1) rc = launch_gemm_auto(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D, e_proj, st);
-    if (rc) return rc;
-    rc = ln_modulate_launch(ws.X, ws.A, M, D, T, mod + 3 * D, mod + 4 * D, mstride, st);
-    if (rc) return rc;
+    if (fuse_ln) {  // the epilogue overwrites A (this GEMM's own operand) panel by panel, after every tile of the panel has finished reading it
+      rc = gate_resid_ln(ws.A, D, (const half_t*)w->proj_w + (size_t)i * D * D, D, w->proj_b + (size_t)i * D, mod + 2 * D, mod + 3 * D, mod + 4 * D);
+      if (rc) return rc;
+    } else {
+      rc = launch_gemm_splitk(ws.A, D, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D, e_proj, ws.slab, ws.slab_bytes, st);
+      if (rc == 1) rc = launch_gemm_auto(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D, e_proj, st);
+      if (rc) return rc;
+      rc = ln_modulate_launch(ws.X, ws.A, M, D, T, mod + 3 * D, mod + 4 * D, mstride, st);
+      if (rc) return rc;
+    }
     const bool prof = g_prof_on && g_prof_count < LFM_PROF_MAX;
     if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_count], st);
     const EpiBiasGeluF16 e_fc1{ws.QKVH, H, w->fc1_b + (size_t)i * H};
@@ -676,6 +709,11 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
     if (rc) return rc;
     if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_count++ + 1], st);
     const EpiGateResidF32 e_fc2{ws.X, D, w->fc2_b + (size_t)i * D, mod + 5 * D, mstride, T};
+    if (fuse_ln && i + 1 < s->depth) {  // ... and writes the NEXT block's first LN-modulate (its shift_msa / scale_msa)
+      rc = gate_resid_ln(ws.QKVH, H, (const half_t*)w->fc2_w + (size_t)i * D * H, H, w->fc2_b + (size_t)i * D, mod + 5 * D, mod + 6 * D, mod + 7 * D);
+      if (rc) return rc;
+      continue;
+    }
     rc = launch_gemm_splitk(ws.QKVH, H, (const half_t*)w->fc2_w + (size_t)i * D * H, H, M, D, H, e_fc2, ws.slab, ws.slab_bytes, st);
     if (rc == 1) rc = launch_gemm_auto(ASrcRowMajor{ws.QKVH, H, M, 0}, (const half_t*)w->fc2_w + (size_t)i * D * H, H, M, D, H, e_fc2, st);
     if (rc) return rc;

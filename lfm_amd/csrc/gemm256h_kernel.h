@@ -149,6 +149,124 @@ __device__ __forceinline__ void g256h_epilogue_rows(f32x4_t (&acc)[8][4], char* 
   }
 }
 
+// sum over the 16 lanes of a DPP row (every lane of the row receives it): quad swaps, then two row rotations
+__device__ __forceinline__ float g256h_row16_sum(float v) {
+  v = dpp_add<0xB1>(v);
+  v = dpp_add<0x4E>(v);
+  v = dpp_add<0x124>(v);
+  v = dpp_add<0x128>(v);
+  return v;
+}
+
+// EXPERIMENTAL fused gated-residual + LayerNorm-modulate epilogue (EpiGateResidLN, gemm_kernel.h).  Interior tiles only.
+// Row-major hand-over as g256h_epilogue_rows (4-column form): per pass a lane owns rows mb + 4 ps (ps = 0..7), columns n .. n + 3; the 16
+// lanes that share a row are one DPP row, so a row's partial sums over the wave's 64 columns cost four DPP adds.
+template <class Epi>
+__device__ __forceinline__ void g256h_epilogue_fused_ln(f32x4_t (&acc)[8][4], char* smem, const Epi& epi, int m0, int n0, int tile_m, int tile_n,
+                                                        int N, int g, int wn, int lane, int wave) {
+  char* scr = smem + wave * (32 * 272);
+  float* red = (float*)(smem + 8 * 32 * 272);          // [g][wn][128 rows][2]: 8 KiB behind the eight scratch areas
+  float* rowstat = (float*)(smem + 8 * 32 * 272 + 8192);  // [256 rows][2] = (mean, rstd) of the whole rows
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int rrow = lane >> 4, rcol = lane & 15;
+  const int n = n0 + wn * 64 + rcol * 4;
+  const int img = m0 / epi.tokens;
+  const f32x4 bias = *(const f32x4*)(epi.bias + n);
+  const f32x4 gate = *(const f32x4*)(epi.gate + (long)img * epi.gate_stride + n);
+  f32x4 xk[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *(f32x4_t*)(scr + (h2 * 16 + l15) * 272 + (j * 16 + l4 * 4) * 4) = acc[2 * i + h2][j];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int mb = m0 + g * 128 + i * 32 + rrow;
+    f32x4 xo[8];
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) xo[ps] = *(const f32x4*)(epi.X + (long)(mb + ps * 4) * epi.ldx + n);
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+      const f32x4 v = *(const f32x4*)(scr + (ps * 4 + rrow) * 272 + rcol * 16);
+      const f32x4 xn = xo[ps] + gate * (v + bias);
+      *(f32x4*)(epi.X + (long)(mb + ps * 4) * epi.ldx + n) = xn;
+      xk[i][ps] = xn;
+      const float s = g256h_row16_sum((xn.x + xn.y) + (xn.z + xn.w));
+      const float q = g256h_row16_sum((xn.x * xn.x + xn.y * xn.y) + (xn.z * xn.z + xn.w * xn.w));
+      if (rcol == 0) {
+        float* d = red + (((g * 4 + wn) * 128) + i * 32 + ps * 4 + rrow) * 2;
+        d[0] = s;
+        d[1] = q;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  // tile-level row sums (fixed order over the four waves) -> this tile's slot of the panel's partials
+  if (wn == 0) {
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int r = lane + 64 * rr;
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int w4 = 0; w4 < 4; ++w4) {
+        s += red[((g * 4 + w4) * 128 + r) * 2];
+        q += red[((g * 4 + w4) * 128 + r) * 2 + 1];
+      }
+      float* d = epi.part + ((long)(m0 + g * 128 + r) * epi.tiles_n + tile_n) * 2;
+      d[0] = s;
+      d[1] = q;
+    }
+  }
+  // the partials must be in the L2 (the siblings run on the same XCD) before the counter says so: stores are write-through, vmcnt(0) = acknowledged
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // relaxed on purpose: an agent-scope release / acquire would write back / invalidate the L2 per operation; the ordering that is needed
+    // (same XCD, same L2) is the vmcnt(0) above and the one invalidate below
+    __hip_atomic_fetch_add(epi.counter + tile_m, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int it = 0;
+    while (__hip_atomic_load(epi.counter + tile_m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epi.target) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++it > (1 << 20)) {  // ~ a second: something is wrong (a sibling tile was never scheduled); do not hang the device
+        if (epi.spin_timeouts) atomicAdd(epi.spin_timeouts, 1);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // nothing of the siblings' partials may be served from this CU's L1
+  // whole-row statistics of the tile's 256 rows: thread r < 256 sums the panel's tiles_n partials of row r in a fixed order
+  if (threadIdx.x < 256) {
+    const int r = threadIdx.x;
+    const float* pp = epi.part + (long)(m0 + r) * epi.tiles_n * 2;
+    float s = 0.f, q = 0.f;
+    for (int t = 0; t < epi.tiles_n; ++t) {
+      s += pp[2 * t];
+      q += pp[2 * t + 1];
+    }
+    const float inv_n = 1.0f / (float)N;
+    const float mean = s * inv_n;
+    const float var = fmaxf(q * inv_n - mean * mean, 0.f);
+    rowstat[2 * r] = mean;
+    rowstat[2 * r + 1] = rsqrtf(var + 1e-6f);
+  }
+  __syncthreads();
+  const f32x4 sc = *(const f32x4*)(epi.scale + (long)img * epi.mod_stride + n);
+  const f32x4 sh = *(const f32x4*)(epi.shift + (long)img * epi.mod_stride + n);
+  const f32x4 sc1 = sc + 1.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+      const int r = g * 128 + i * 32 + ps * 4 + rrow;
+      const float mean = rowstat[2 * r], rstd = rowstat[2 * r + 1];
+      const f32x4 o = (xk[i][ps] - mean) * rstd * sc1 + sh;
+      const half4_t h = {(half_t)o.x, (half_t)o.y, (half_t)o.z, (half_t)o.w};
+      *(half4_t*)(epi.A + (long)(m0 + r) * N + n) = h;
+    }
+}
+
 template <int BN, bool TRACE = false, class Epi>
 __device__ __forceinline__ void g256h_epilogue(f32x4_t (&acc)[8][4], char* smem, Epi& epi, int m0, int n0, int M, int N, int g, int wn, int lane,
                                                int wave, int bz, long bsC, int dbg, bool swapped) {
@@ -156,6 +274,10 @@ __device__ __forceinline__ void g256h_epilogue(f32x4_t (&acc)[8][4], char* smem,
   epi_batch(epi, bz, bsC, 0);
   g256h_stamp<TRACE>(tr, g, wn, lane, 0);
   if (dbg & 4) return;  // ablation: no epilogue
+  if constexpr (epi_is_fused_ln<Epi>::value) {
+    g256h_epilogue_fused_ln(acc, smem, epi, m0, n0, m0 / G256_BM, n0 / BN, N, g, wn, lane, wave);
+    return;
+  }
   const int l15 = lane & 15, l4 = lane >> 4;
   if constexpr (epi_has_transposed<Epi>::value) {
     // The K loop ran this tile with the MFMA operands swapped: acc[i][j][r] = C[m = 16 i + 4 l4 + r][n = 16 j + l15], FOUR CONSECUTIVE m per

@@ -129,6 +129,55 @@ struct EpiGateResidF32 {
   }
 };
 
+// EXPERIMENTAL (off unless lfm_set_option(LFM_OPT_FUSE_LN, 1); written at the end of round 2 without GPU time left to measure it):
+// the gated-residual epilogue of proj / fc2 ALSO produces the next GEMM's A operand, fp16(LayerNorm(X') * (1 + scale) + shift), so the
+// LN-modulate launch that would re-read the 67 MB of X' disappears.  N == D: the tiles_n column tiles of an M-panel hold
+// whole rows between them.  Each tile keeps its block of X' in registers, publishes per-row (sum, sum of squares) partials in a fixed
+// slot part[m][tile_n] (deterministic), bumps the panel's counter and waits until all tiles_n tiles of the panel have done so; then it
+// normalises its own block.  Host-side preconditions (lfm_dit_forward): interior tiles only, one image per tile (tokens % 256 == 0), the
+// panel's tiles on ONE XCD (tile order: grid % 128 == 0), all of which holds for the benchmark shape; the gemm256h kernel only.
+// Variance is E[x^2] - mean^2 in fp32 (one pass), so the result differs from ln_modulate's two-pass value in the last bits.
+struct EpiGateResidLN {
+  float* X;
+  long ldx;
+  const float* bias;
+  const float* gate;
+  long gate_stride;
+  int tokens;
+  // fused LayerNorm + modulate of the CONSUMER (shift / scale of the LN that follows this GEMM)
+  half_t* A;              // [M][N] fp16, leading dimension N
+  const float* shift;
+  const float* scale;
+  long mod_stride;
+  float* part;            // [M][tiles_n][2]
+  unsigned* counter;      // [tiles_m], monotone over the fused launches of one forward (zeroed at its start)
+  unsigned target;        // tiles_n * (index of this launch among the fused launches + 1)
+  int tiles_n;
+  int* spin_timeouts;     // debug: incremented when the bounded wait ran out (the result is then wrong, but nothing hangs)
+  static constexpr bool fused_ln = true;
+  struct Aux {
+    f32x4 b, g, x;
+  };
+  __device__ __forceinline__ Aux load(int m, int n) const {
+    Aux a;
+    a.b = *(const f32x4*)(bias + n);
+    a.g = *(const f32x4*)(gate + (long)(m / tokens) * gate_stride + n);
+    a.x = *(const f32x4*)(X + (long)m * ldx + n);
+    return a;
+  }
+  __device__ __forceinline__ void store(int m, int n, f32x4 v, const Aux& a) const {
+    *(f32x4*)(X + (long)m * ldx + n) = a.x + a.g * (v + a.b);
+  }
+};
+template <class Epi, class = void>
+struct epi_is_fused_ln {
+  static constexpr bool value = false;
+};
+template <class Epi>
+struct epi_is_fused_ln<Epi, decltype((void)Epi::fused_ln)> {
+  static constexpr bool value = Epi::fused_ln;
+};
+
 // Split-K partial tile: slice bz of the K range writes its fp32 partial product to slab[bz][M][N] (see launch_gemm_splitk).
 struct EpiSlabF32 {
   float* slab;

@@ -74,6 +74,8 @@ def lib():
     L.lfm_ln_modulate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
     L.lfm_dit_attention.restype = C.c_int
     L.lfm_dit_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.lfm_set_option.restype = C.c_int
+    L.lfm_set_option.argtypes = [C.c_int, C.c_int]
     L.lfm_dit_attention_hd.restype = C.c_int
     L.lfm_dit_attention_hd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.lfm_grid_advance.restype = C.c_int
@@ -200,6 +202,13 @@ def ln_modulate(X, shift, scale, tokens, mod_stride):
     A = torch.empty(M, D, device=X.device, dtype=torch.float16)
     check(lib().lfm_ln_modulate(ptr(X), ptr(A), M, D, tokens, ptr(shift), ptr(scale), mod_stride, stream_ptr()), "lfm_ln_modulate")
     return A
+
+
+OPT_FUSE_LN = 1  # experimental: LayerNorm-modulate inside the gated-residual GEMM epilogues (include/lfm_hip.h)
+
+
+def set_option(key, value):
+    check(lib().lfm_set_option(int(key), int(value)), "lfm_set_option")
 
 
 def dit_attention(Q, K, Vt, batch, heads, T, head_dim=64):

@@ -394,3 +394,29 @@ def test_forward_refuses_cpu():
     m = DiT_models["DiT-S/2"](img_resolution=32, in_channels=4, num_classes=1, label_dropout=0.0).eval()
     with pytest.raises(hip.LfmHipError):
         m(torch.tensor(0.5), torch.zeros(1, 4, 32, 32))
+
+
+@pytest.mark.skipif(os.environ.get("LFM_EXPERIMENTAL") != "1", reason="experimental option, written without GPU time left to validate it (LFM_EXPERIMENTAL=1 runs it)")
+def test_experimental_fused_ln_epilogue_matches_separate_launches(dev):
+    """lfm_set_option(LFM_OPT_FUSE_LN): LayerNorm-modulate inside the proj / fc2 epilogues must give the forward of the separate launches up
+    to the one-pass variance (E[x^2] - mean^2) and be repeatable; DiT-L/2 at batch 32 is the smallest batch that meets its preconditions."""
+    from lfm_amd import hip
+    from lfm_amd.models import DiT_models
+
+    kw = dict(num_classes=1, label_dropout=0.0)
+    cfg = dit_ref.DiTCfg.named("DiT-L/2", **kw)
+    m = DiT_models["DiT-L/2"](img_resolution=32, in_channels=4, **kw)
+    m.load_state_dict(dit_ref.make_dit_state(cfg, seed=6), strict=True)
+    m = m.to(dev).eval()
+    x = torch.randn(32, 4, 32, 32, generator=torch.Generator().manual_seed(1)).to(dev)
+    t = torch.tensor(0.6, device=dev)
+    base = m(t, x).clone()
+    hip.set_option(hip.OPT_FUSE_LN, 1)
+    try:
+        a = m(t, x).clone()
+        b = m(t, x).clone()
+        torch.cuda.synchronize()
+    finally:
+        hip.set_option(hip.OPT_FUSE_LN, 0)
+    assert torch.equal(a, b)
+    assert rel_l2(a, base) < 5e-4
