@@ -131,6 +131,8 @@ int lfm_set_option(int key, int value);
 /* Measurement only: s_memtime stamps written by the quadrant-phased GEMM (select flag 2) after every barrier of block 0,
  * wave groups 0 and 1; host_out receives 2 x n_per_group values. */
 int lfm_gemm_trace_read(unsigned long long* host_out, int n_per_group);
+/* Measurement only: s_memtime stamps of the attention kernel's trace build (select flags 33554432 | 67108864; slot map in csrc/attention_kernel.h). */
+int lfm_attention_trace_read(unsigned long long* host_out, int n);
 int lfm_profile_fc1_read(float* host_ms_out, int max_n);
 
 /* A fp16 [M,D] = LayerNorm(X fp32 [M,D], eps 1e-6, no affine) * (1 + scale[img]) + shift[img]

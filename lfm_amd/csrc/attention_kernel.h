@@ -19,6 +19,13 @@
 
 int lfm_gemm_debug_flags();
 
+// MODE 3 (measurement only): s_memtime stamps of wave 0 of the first workgroup (slots 0..31) and of the last one (32..63), read back with
+// lfm_attention_trace_read.  Slots: 0 start, 1 all DMAs / Q loads issued, 2 K and Q landed (first barrier), 3 + 4 k + {0: S(next) issued,
+// 1: softmax + PV of the even block done, 2: S(next even) issued, 3: softmax + PV of the odd block done} for the k-th loop iteration,
+// 19 stores issued, 20 stores acknowledged; inside the first softmax_pv: 21 softmax VALU done, 22 V^T landed (barrier), 23 PV MFMAs issued.
+#define ATT_TRACE_SLOTS 64
+static __device__ unsigned long long att_trace[ATT_TRACE_SLOTS];
+
 // MODE (measurement only, tools/r2_probe3.py): 0 = the kernel; 1 = memory phases only (stage K / V^T, fetch Q, store a row per query, no
 // S / softmax / PV); 2 = compute only (K / V^T are never fetched: the loop runs on whatever the LDS holds).  Round 2, 64 images x 16 heads x 256
 // tokens (profiles/r02_probe3_attention_phases_ln_rows.txt): whole kernel 40-41 us, memory phases 22-23 us, compute (with its Q / O traffic) 33-36 us
@@ -44,6 +51,17 @@ __global__ __launch_bounds__((T / (32 * JQ)) * 64, HD == 64 ? (T / (32 * JQ)) / 
   char* Vs = smem + T * KROW;  // [HD][T] halves, 2T-B rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int head = blockIdx.x, img = blockIdx.y;
+  const bool tr_first = blockIdx.x == 0 && blockIdx.y == 0, tr_last = blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1;
+  auto stamp = [&](int slot) {
+    if constexpr (MODE == 3) {
+      if (wave == 0 && (tr_first || tr_last)) {
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        if (lane == 0) att_trace[(tr_first ? 0 : 32) + slot] = t;
+      }
+    }
+  };
+  stamp(0);
   const half_t* Kg = K + (long)img * T * D + head * HD;
   const half_t* Vg = Vt + ((long)img * heads + head) * HD * T;
 
@@ -97,6 +115,7 @@ __global__ __launch_bounds__((T / (32 * JQ)) * 64, HD == 64 ? (T / (32 * JQ)) / 
         *(half8_t*)(O + ((long)img * T + q0 + jq * 32 + l31) * D + head * HD + ks * 16 + hsel * 8) = qf[jq][ks];
     return;
   }
+  stamp(1);
   f32x16 Oa[JQ][NDB];  // [jq][db]
 #pragma unroll
   for (int jq = 0; jq < JQ; ++jq)
@@ -115,6 +134,7 @@ __global__ __launch_bounds__((T / (32 * JQ)) * 64, HD == 64 ? (T / (32 * JQ)) / 
   else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // raw barrier: __syncthreads() would drain the in-flight V^T DMAs
   asm volatile("" ::: "memory");
+  stamp(2);
 
   f32x16 zero16;
 #pragma unroll
@@ -171,9 +191,11 @@ __global__ __launch_bounds__((T / (32 * JQ)) * 64, HD == 64 ? (T / (32 * JQ)) / 
       }
     }
     if (kb == 0) {  // V^T was issued after K and Q: only now must it have landed (every wave's share)
+      stamp(21);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      stamp(22);
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -191,6 +213,7 @@ __global__ __launch_bounds__((T / (32 * JQ)) * 64, HD == 64 ? (T / (32 * JQ)) / 
         for (int jq = 0; jq < JQ; ++jq) Oa[jq][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, P[jq][s], Oa[jq][db], 0, 0, 0);
       }
     }
+    if (kb == 0) stamp(23);
   };
   // software pipeline over the key blocks: the S MFMAs of block kb+1 are issued BEFORE the softmax VALU of block kb, so
   // the matrix pipe works underneath the VALU-heavy part instead of the wave idling on the MFMA -> max -> exp -> MFMA chain
@@ -199,9 +222,13 @@ __global__ __launch_bounds__((T / (32 * JQ)) * 64, HD == 64 ? (T / (32 * JQ)) / 
 #pragma unroll 1
   for (int kb = 0; kb < NKB; kb += 2) {
     qk(Sb, kb + 1);
+    stamp(3 + 2 * kb);
     softmax_pv(Sa, kb);
+    stamp(4 + 2 * kb);
     if (kb + 2 < NKB) qk(Sa, kb + 2);
+    stamp(5 + 2 * kb);
     softmax_pv(Sb, kb + 1);
+    stamp(6 + 2 * kb);
   }
   // ---- normalise and store: lane owns query q, d = db*32 + 8g + 4*hsel + r
 #pragma unroll
@@ -217,6 +244,11 @@ __global__ __launch_bounds__((T / (32 * JQ)) * 64, HD == 64 ? (T / (32 * JQ)) / 
                      (half_t)(Oa[jq][db][4 * g + 3] * inv)};
         *(half4_t*)(orow + db * 32 + 8 * g + 4 * hsel) = h;
       }
+  }
+  stamp(19);
+  if constexpr (MODE == 3) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp(20);
   }
 }
 
@@ -287,15 +319,17 @@ static int attention_launch(const half_t* Q, const half_t* K, const half_t* Vt, 
   // A/B switch (measurement only): 8 waves x 32 queries (4 waves/SIMD) measured 44.3 us vs 40.2 us for 4 waves x 64 queries --
   // the kernel moves Q,K,V^T,O = 134 MB per launch (3.4 TB/s): more waves do not help
   const bool narrow = T == 256 && (lfm_gemm_debug_flags() & 256);
-  const int mode = (lfm_gemm_debug_flags() >> 25) & 3;  // flags 33554432 / 67108864: the measurement-only phase variants (hd 64, 256 tokens)
+  const int mode = (lfm_gemm_debug_flags() >> 25) & 3;  // flags 33554432 / 67108864 / both: the measurement-only variants MODE 1 / 2 / 3 (hd 64, 256 tokens)
   if (mode && hd == 64 && T == 256) {
     static bool set = false;
     if (!set) {
       (void)hipFuncSetAttribute((const void*)dit_attention_kernel<256, 2, 64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 64 * 4);
       (void)hipFuncSetAttribute((const void*)dit_attention_kernel<256, 2, 64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 64 * 4);
+      (void)hipFuncSetAttribute((const void*)dit_attention_kernel<256, 2, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 64 * 4);
       set = true;
     }
-    if (mode == 1) hipLaunchKernelGGL((dit_attention_kernel<256, 2, 64, 1>), grid, dim3(256), lds, st, Q, K, Vt, O, D, heads, sl2);
+    if (mode == 3) hipLaunchKernelGGL((dit_attention_kernel<256, 2, 64, 3>), grid, dim3(256), lds, st, Q, K, Vt, O, D, heads, sl2);
+    else if (mode == 1) hipLaunchKernelGGL((dit_attention_kernel<256, 2, 64, 1>), grid, dim3(256), lds, st, Q, K, Vt, O, D, heads, sl2);
     else hipLaunchKernelGGL((dit_attention_kernel<256, 2, 64, 2>), grid, dim3(256), lds, st, Q, K, Vt, O, D, heads, sl2);
     LFM_CHECK_LAUNCH();
     return LFM_OK;

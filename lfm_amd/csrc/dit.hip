@@ -616,6 +616,13 @@ extern "C" int lfm_gemm_trace_read(unsigned long long* host_out, int n_per_group
   return LFM_OK;
 }
 
+extern "C" int lfm_attention_trace_read(unsigned long long* host_out, int n) {  // the s_memtime stamps of the MODE 3 attention build
+  if (!host_out || n <= 0 || n > ATT_TRACE_SLOTS) return LFM_ERR_ARG;
+  if (hipDeviceSynchronize() != hipSuccess) return LFM_ERR_LAUNCH;
+  if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(att_trace), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost) != hipSuccess) return LFM_ERR_LAUNCH;
+  return LFM_OK;
+}
+
 extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w, void* workspace, size_t workspace_bytes,
                                const lfm_dit_call* c, lfm_stream_t stream) {
   int rc = check_shape(s);

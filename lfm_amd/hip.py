@@ -74,6 +74,8 @@ def lib():
     L.lfm_ln_modulate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
     L.lfm_dit_attention.restype = C.c_int
     L.lfm_dit_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.lfm_attention_trace_read.restype = C.c_int
+    L.lfm_attention_trace_read.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
     L.lfm_set_option.restype = C.c_int
     L.lfm_set_option.argtypes = [C.c_int, C.c_int]
     L.lfm_dit_attention_hd.restype = C.c_int
