@@ -319,3 +319,15 @@ def test_unbuilt_dit_shapes_are_refused_at_construction():
         DiT_models["DiT-S/2"](img_resolution=64, in_channels=4, num_classes=1, label_dropout=0.0)    # 1024 tokens: K / V^T do not fit the LDS
     DiT_models["DiT-S/4"](img_resolution=32, in_channels=4, num_classes=1, label_dropout=0.0)        # 64 tokens, K = 64: built
     DiT_models["DiT-S/8"](img_resolution=64, in_channels=4, num_classes=1, label_dropout=0.0)        # 64 tokens, K = 256: built
+
+
+def test_library_options_are_host_state_only():
+    """lfm_set_option touches no device: unknown keys are refused, the experimental fused-LayerNorm switch toggles and defaults to off."""
+    from lfm_amd import hip
+
+    L = hip.lib()
+    assert L.lfm_set_option(99, 1) < 0
+    with pytest.raises(hip.LfmHipError):
+        hip.set_option(99, 1)
+    hip.set_option(hip.OPT_FUSE_LN, 1)
+    hip.set_option(hip.OPT_FUSE_LN, 0)
