@@ -19,6 +19,13 @@ Pinning status (see DESIGN.md "Oracle"):
 * ``ode_ref`` (torchdiffeq) and ``vae_ref`` (diffusers ``AutoencoderKL``
   decoder) restate third-party packages that are neither vendored in the
   reference nor installed here (requirements.txt:2-3, no versions):
-  **parity unpinned** for those two -- they are anchored on analytic
-  known-answer tests and on the reference's call sites only.
+  **parity unpinned** against those packages themselves.  Independent anchors:
+  scipy's RK45 / RK23 / DOP853 and the Runge-Kutta order conditions for
+  ``ode_ref`` (tests/test_ode_ref.py); for ``vae_ref`` the ``transformers``
+  package's own port of the latent-diffusion Encoder / Decoder (the network
+  ``AutoencoderKL`` ports), which reproduces ``vae_decode`` /
+  ``vae_encode_moments`` from our state dict (tests/test_vae_ref_ldm.py), the
+  published parameter counts and the frozen diffusers key list
+  (tests/test_vae_ref.py); ``torch.nn.MultiheadAttention`` / ``F.unfold`` for
+  the timm shim (tests/test_timm_shim.py).
 """

@@ -9,7 +9,10 @@ architecture of ``AutoencoderKL`` (decoder half) for the ``sd-vae-ft-mse`` confi
 latent 4, block_out_channels [128,256,512,512], layers_per_block 2 (=> 3 resnets per up block),
 norm_num_groups 32, GN eps 1e-6, SiLU, single-head mid attention.
 State-dict key names follow diffusers (>=0.2x) so a real checkpoint loads unchanged.
-Anchors (``tests/test_vae_ref.py``): the published parameter count (49,490,179 decoder + 20 post_quant_conv), the frozen diffusers key
+Pinned against an INDEPENDENT port of the same network (``tests/test_vae_ref_ldm.py``): the ``transformers`` package's Janus VQ-VAE is the
+CompVis latent-diffusion Encoder / Decoder that ``AutoencoderKL`` ports; loaded with this file's state dict it reproduces ``vae_decode`` and
+``vae_encode_moments`` to 1e-4.  Still unpinned against diffusers' own code and the real weights.
+Further anchors (``tests/test_vae_ref.py``): the published parameter count (49,490,179 decoder + 20 post_quant_conv), the frozen diffusers key
 list ``tests/golden/vae_decoder_keys.json``, mid attention vs ``F.scaled_dot_product_attention``, resnet / GroupNorm / upsample
 identities, FLOP count 622.2 G.
 """
