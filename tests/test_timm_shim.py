@@ -70,3 +70,37 @@ def test_mlp_is_fc2_act_fc1_with_the_reference_activation():
         torch.testing.assert_close(mlp(x), want, rtol=1e-6, atol=1e-6)
     assert [n for n, _ in mlp.named_children()] == ["fc1", "act", "drop1", "norm", "fc2", "drop2"]  # attribute names of the published class
     assert sorted(k for k, _ in mlp.named_parameters()) == ["fc1.bias", "fc1.weight", "fc2.bias", "fc2.weight"]
+
+
+def test_attention_and_patch_embed_equal_the_transformers_vit_port():
+    """A third implementation: the ViT of the ``transformers`` package (its own port of the timm / google-research ViT): separate q / k / v
+    projections = the three row blocks of timm's fused ``qkv``, heads as contiguous slices, ``head_dim ** -0.5``; patch embedding = strided
+    convolution, ``flatten(2).transpose(1, 2)``."""
+    vit = pytest.importorskip("transformers.models.vit.modeling_vit")
+    cfgmod = pytest.importorskip("transformers.models.vit.configuration_vit")
+    dim, heads, tokens = 144, 2, 16  # head size 72
+    cfg = cfgmod.ViTConfig(hidden_size=dim, num_attention_heads=heads, qkv_bias=True, attention_probs_dropout_prob=0.0, image_size=8, patch_size=2,
+                           num_channels=4)
+    cfg._attn_implementation = "eager"
+    g = torch.Generator().manual_seed(9)
+    att = timm_shim.Attention(dim, num_heads=heads, qkv_bias=True).eval()
+    with torch.no_grad():
+        for p in att.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * 0.2)
+    theirs = vit.ViTAttention(cfg).eval()
+    with torch.no_grad():
+        for i, proj in enumerate((theirs.q_proj, theirs.k_proj, theirs.v_proj)):
+            proj.weight.copy_(att.qkv.weight[i * dim:(i + 1) * dim])
+            proj.bias.copy_(att.qkv.bias[i * dim:(i + 1) * dim])
+        theirs.o_proj.weight.copy_(att.proj.weight)
+        theirs.o_proj.bias.copy_(att.proj.bias)
+    x = torch.randn(2, tokens, dim, generator=g)
+    with torch.no_grad():
+        torch.testing.assert_close(att(x), theirs(x)[0], rtol=1e-4, atol=1e-4)
+    pe = timm_shim.PatchEmbed(8, 2, 4, dim, bias=True).eval()
+    tpe = vit.ViTPatchEmbeddings(cfg).eval()
+    with torch.no_grad():
+        tpe.projection.weight.copy_(pe.proj.weight)
+        tpe.projection.bias.copy_(pe.proj.bias)
+        img = torch.randn(3, 4, 8, 8, generator=g)
+        torch.testing.assert_close(pe(img), tpe(img), rtol=1e-6, atol=1e-6)
