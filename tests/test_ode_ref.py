@@ -345,3 +345,26 @@ def test_perturb_samples_inside_the_step():
     seen.clear()
     prod.odeint(f, y0, torch.tensor([0.0, 1.0]), method="rk4", options={"step_size": 0.5, "perturb": True})
     assert seen[0] > 0.0 and seen[3] < 0.5 and seen[3] > 0.4999  # k1 just after t0, k4 just before t1
+
+
+def test_fixed_grid_rk4_equals_the_transformers_port_of_torchdiffeq():
+    """``transformers`` ships a port of torchdiffeq's fixed-grid solver for one of its models (``RungeKutta4ODESolver`` in
+    ``models/qwen2_5_omni``: the 3/8-rule step with its 1/3, 2/3 nodes, the integrate loop over a time grid, linear interpolation of the
+    requested times) -- written by other people from the package our restatement could not be diffed against.  Same grid, same field: the
+    oracle and the product reproduce it to rounding, including an output time that falls between two grid points and a decreasing time axis."""
+    qo = pytest.importorskip("transformers.models.qwen2_5_omni.modeling_qwen2_5_omni")
+    y0 = torch.from_numpy(Y0)
+    h = 0.0625
+    t = torch.tensor([0.0, 0.33, 0.8, 1.0], dtype=torch.float64)
+    grid = prod.fixed_grid(t, h)
+    theirs = qo.RungeKutta4ODESolver(_f_torch, y0).integrate(grid)
+    i = int(0.33 // h)
+    at_033 = theirs[i] + (0.33 - grid[i]) / (grid[i + 1] - grid[i]) * (theirs[i + 1] - theirs[i])
+    for impl in (prod, ode_ref):
+        ours = impl.odeint(_f_torch, y0, t, method="rk4", options={"step_size": h})
+        torch.testing.assert_close(ours[-1], theirs[-1], rtol=0, atol=1e-14)
+        torch.testing.assert_close(ours[1], at_033, rtol=0, atol=1e-14)
+        # the sampler's direction, t: 1 -> 0 (torchdiffeq integrates the negated field on the negated time axis)
+        back = impl.odeint(lambda tt, y: -_f_torch(tt, y), y0, torch.tensor([1.0, 0.0], dtype=torch.float64), method="rk4", options={"step_size": h})
+        fwd = qo.RungeKutta4ODESolver(lambda tt, y: _f_torch(-tt, y), y0).integrate(prod.fixed_grid(torch.tensor([-1.0, 0.0], dtype=torch.float64), h))
+        torch.testing.assert_close(back[-1], fwd[-1], rtol=0, atol=1e-13)
