@@ -49,7 +49,25 @@ def parse():
     p.add_argument("--nfe", type=int, default=50)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--stub", action="store_true", help="(tests) CPU / gloo rehearsal of the launcher + rank logic: a stub step instead of the HIP path")
     return p.parse_args()
+
+
+def self_launch(a, argv=None):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: re-exec THIS script under torch.distributed.run, one rank per GPU
+    (what /root/reference/bash_scripts/run_test_ddp.sh:15-34 does for the reference's _ddp script).  Rank 0's JSON line goes to our stdout."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *(sys.argv[1:] if argv is None else argv)]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // a.gpus)))
+    return subprocess.run(cmd, env=env).returncode
 
 
 def usable_cores():
@@ -103,6 +121,34 @@ def cpu_baseline(model_name, nfe, budget_s=25.0):
                       f"({t_dec:.2f} s/img at 256x256), scaled to {nfe} NFE + decode per image"}
 
 
+# ------------------------------------------------------------------------------------------------ algorithmic FLOPs
+def dit_flops_per_image(tokens, hidden, depth, patch_inputs):
+    """2 x MACs of one DiT evaluation of one image: per block qkv + proj + fc1 + fc2 (12 T D^2), QK^T and PV (2 T^2 D), the adaLN rows (6 D^2);
+    patch embed, final layer, timestep MLP (256 D + D^2) and final adaLN (2 D^2).  161.4 GFLOP for DiT-L/2 (checked against the oracle's
+    count in tests/test_host_logic.py)."""
+    T, D, L = tokens, hidden, depth
+    return 2 * (L * (12 * T * D * D + 2 * T * T * D + 6 * D * D) + T * patch_inputs * D * 2 + 2 * D * D + 256 * D + D * D)
+
+
+def vae_decode_flops(R):
+    """2 x MACs of one kl-f8 decode at latent side R (622.2 GFLOP at R = 32): post_quant 1x1, conv_in, mid (2 resnets + 1-head attention),
+    four up blocks of 3 resnets (512, 512, 512->256, 256->128 channels at R, 2R, 4R, 8R) with three upsampler convs, conv_out."""
+    px = R * R
+    mac = px * 4 * 4 + px * 4 * 512 * 9                       # post_quant_conv, conv_in
+    mac += 2 * 2 * px * 512 * 512 * 9                         # mid resnets
+    mac += 4 * px * 512 * 512 + 2 * px * px * 512             # mid attention: q, k, v, out + QK^T, PV
+    side = R
+    for cin, cout, up in ((512, 512, True), (512, 512, True), (512, 256, True), (256, 128, False)):
+        p = side * side
+        mac += p * (cin * cout * 9 + cout * cout * 9 + (cin * cout if cin != cout else 0))  # resnet 0 (+ 1x1 shortcut)
+        mac += 2 * p * 2 * cout * cout * 9                                                  # resnets 1, 2
+        if up:
+            side *= 2
+            mac += side * side * cout * cout * 9
+    mac += side * side * 128 * 3 * 9                          # conv_out
+    return 2 * mac
+
+
 # ------------------------------------------------------------------------------------------------ workloads
 def build_workload(a, dev, rank):
     """Returns dict(step_fn(x_dev) -> fp32 images, x_host (pinned), B, res, workload, flop_per_image, model, solve_fn, extra)."""
@@ -110,7 +156,9 @@ def build_workload(a, dev, rank):
     from lfm_amd.models import DiT_models, create_network
     from lfm_amd.solvers import GraphedFixedGrid, odeint, torchdiffeq_euler_grid
     from lfm_amd.test_flow_latent import dezero_
-    from oracle import dit_ref, vae_ref  # FLOP closed forms only
+
+    def dit_flops(m):
+        return dit_flops_per_image(m.x_embedder.num_patches, m.hidden_size, m.depth, m.patch_size * m.patch_size * m.in_channels)
 
     vae = AutoencoderKL.from_random(seed=0).to(dev)
     g = torch.Generator().manual_seed(42 + rank)
@@ -124,7 +172,7 @@ def build_workload(a, dev, rank):
         solver = GraphedFixedGrid(model, B)
         solver.set_grid(ts, dts)
         solve = lambda x: solver.run(x)  # noqa: E731
-        f_model = a.nfe * dit_ref.dit_flops_per_image(dit_ref.DiTCfg.named(name, num_classes=1, label_dropout=0.0))
+        f_model = a.nfe * dit_flops(model)
         wl = f"{name} celeb256 f8 (4x32x32 latents), batch {B}/GPU, {a.nfe}-step Euler (torchdiffeq grid) + f8 VAE decode to 256x256 + uint8 NHWC"
         x_shape, res, extra = (B, 4, 32, 32), 32, {"nfe": a.nfe}
     elif a.config in (3, 4):
@@ -133,7 +181,7 @@ def build_workload(a, dev, rank):
         torch.manual_seed(0)
         model = dezero_(DiT_models[name](img_resolution=32, in_channels=4, label_dropout=0.1, num_classes=1000)).to(dev).eval()
         y = torch.cat([torch.randint(0, 1000, (B,), generator=g), torch.full((B,), 1000)]).to(dev)
-        per_eval = 2 * dit_ref.dit_flops_per_image(dit_ref.DiTCfg.named(name, num_classes=1000, label_dropout=0.1))  # CFG: 2 rows per image
+        per_eval = 2 * dit_flops(model)  # CFG: 2 rows per image
         extra = {}
         if a.config == 3:
             stats = {}
@@ -178,7 +226,7 @@ def build_workload(a, dev, rank):
         wl = f"origin-ADM celeb512 (352 M params), 4x64x64 latents, batch {B}/GPU, {a.nfe}-step Euler + f8 VAE decode to 512x512 + uint8 NHWC"
         x_shape, res, extra = (B, 4, 64, 64), 64, {"nfe": a.nfe}
     x_host = torch.randn(*x_shape, generator=g).pin_memory()
-    return dict(model=model, vae=vae, solve=solve, B=B, res=res, x_host=x_host, workload=wl, f_model=f_model, f_vae=vae_ref.vae_decode_flops(res),
+    return dict(model=model, vae=vae, solve=solve, B=B, res=res, x_host=x_host, workload=wl, f_model=f_model, f_vae=vae_decode_flops(res),
                 extra=extra, name=(a.model or {2: "DiT-L/2", 3: "DiT-L/2", 4: "DiT-B/2", 5: "ADM-celeb512"}[a.config]))
 
 
@@ -253,17 +301,73 @@ def roofline_adm(B, dev):
             "avg_launch_us": dur * 1e6, "launches_timed": 10}
 
 
+def main_stub(a, world, rank):
+    """CPU / gloo rehearsal (tests/test_multi_rank.py): the same launch contract, rank bookkeeping, gather pipeline, max-over-ranks timing and
+    ONE JSON line from rank 0 as the real run, around a stub step (no model, no HIP).  Never a measurement."""
+    from lfm_amd.test_flow_latent_ddp import GatherPipeline
+
+    if world > 1:
+        dist.init_process_group("gloo")
+    B = a.batch or 4
+    pipe = GatherPipeline(world, "cpu")
+    g = torch.Generator().manual_seed(42 + rank)
+    x = torch.randn(B, 4, 8, 8, generator=g)
+    got = []
+
+    def step():
+        u8 = (x.clamp(-1, 1) * 127 + 128).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+        prev = pipe.submit(u8) if world > 1 else None
+        if prev is not None:
+            got.append(prev)
+        return u8
+
+    def fence():
+        last = pipe.flush()
+        if last is not None:
+            got.append(last)
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(max(a.warmup, 0)):
+        step()
+    fence()
+    got.clear()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    el = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([el], dtype=torch.float64)
+        allt = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(allt, tt)
+        el = max(float(t) for t in allt)
+        assert len(got) == a.steps and all(b.shape[0] == B * world for b in got)
+    if rank == 0:
+        print(json.dumps({"metric": "images/sec", "value": world * B * a.steps / el, "unit": "images/sec", "n_gpus": world, "steps": a.steps,
+                          "warmup": a.warmup, "ms_per_step": 1e3 * el / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "u8", "data": "stub", "config": {"workload": "STUB (launcher rehearsal, not a measurement)", "sharding": f"dp{world}"},
+                          "rccl_world": dist.get_world_size() if world > 1 else 1}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        raise SystemExit(self_launch(a))  # the driver's `python bench.py --gpus N`: become the torchrun launcher
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    torch.set_grad_enabled(False)
+    if a.stub:
+        return main_stub(a, world, rank)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
-    torch.set_grad_enabled(False)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)

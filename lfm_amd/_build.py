@@ -34,11 +34,26 @@ def _digest():
 
 
 def build(force=False, verbose=False):
-    """Compile every .hip under csrc/ into ONE shared library.  Returns the library path."""
+    """Compile every .hip under csrc/ into ONE shared library.  Returns the library path.  Safe under torchrun: the stamp check and the
+    build run under an exclusive file lock (N ranks starting on stale sources compile once), and the library is linked to a temporary
+    name and renamed into place (a concurrent dlopen never sees a half-written file)."""
+    import fcntl
+
     os.makedirs(LIBDIR, exist_ok=True)
     dig = _digest()
     if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read() == dig:
         return LIB
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read() == dig:
+                return LIB  # another process built it while we waited
+            return _build_locked(dig, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(dig, verbose):
     if not os.path.exists(HIPCC):
         raise RuntimeError(f"hipcc not found at {HIPCC}; cannot build liblfm_hip.so")
     objs = []
@@ -56,10 +71,12 @@ def build(force=False, verbose=False):
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
         if verbose and out:
             print(out.decode())
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    tmp = LIB + f".tmp{os.getpid()}"
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout.decode()}")
+    os.replace(tmp, LIB)
     open(STAMP, "w").write(dig)
     return LIB
 

@@ -473,10 +473,11 @@ extern "C" int lfm_groupnorm_f16(const void* x, void* y, const float* gamma, con
   hipStream_t st = (hipStream_t)stream;
   const int G = groups, cpg = C / G;
   // (measured on the celeb512 UNet: at 64x64 maps the fused kernel's 256 blocks are too few -- 300 us vs ~35 us for the three kernels)
-  if (cpg % 8 == 0 && HW <= 1024 && !(lfm_gemm_debug_flags() & 16384)) {  // flag 16384: the three-kernel path (A/B)
+  // fused path: one block's 256 threads cover the gpb * cpg / 8 eight-channel columns of its groups, so a single group may be at most 2048
+  // channels wide (wider groups -- e.g. groups = 1 on 4096 channels -- take the three-kernel path below instead of shrinking gpb to zero)
+  if (cpg % 8 == 0 && cpg <= 2048 && HW <= 1024 && !(lfm_gemm_debug_flags() & 16384)) {  // flag 16384: the three-kernel path (A/B)
     int gpb = 1;
     while (gpb * 2 <= G && G % (gpb * 2) == 0 && (long)N * (G / (gpb * 2)) >= 256 && gpb * 2 * cpg <= 2048) gpb *= 2;
-    while (256 / ((gpb * cpg) >> 3) < 1) gpb >>= 1;
     dim3 grid(G / gpb, N);
     if (silu) hipLaunchKernelGGL(gn_fused_kernel<true>, grid, dim3(256), 0, st, (const half_t*)x, (half_t*)y, gamma, beta, film, film_stride, HW, C, cpg, gpb, eps);
     else hipLaunchKernelGGL(gn_fused_kernel<false>, grid, dim3(256), 0, st, (const half_t*)x, (half_t*)y, gamma, beta, film, film_stride, HW, C, cpg, gpb, eps);

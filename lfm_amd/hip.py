@@ -141,25 +141,26 @@ def ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
-_LABELS_OK = {}
-
-
 def check_labels(y, rows, what):
     """Labels must index the embedding table (the reference's nn.Embedding raises IndexError otherwise; a kernel cannot).  The check
-    reads two scalars back from the device, so it is cached per (storage, version) and skipped during graph capture -- solver loops
-    that pass the same label tensor to every evaluation pay for it once."""
+    reads two scalars back from the device, so the verdict is remembered ON THE TENSOR OBJECT (attribute, keyed by its version counter and
+    the table size) -- a solver loop that passes the same label tensor to every evaluation pays once, while a fresh tensor that merely
+    reuses a freed tensor's address is checked again.  Skipped during graph capture (no readback possible there)."""
     if y is None or y.numel() == 0:
         return
     if y.is_cuda and torch.cuda.is_current_stream_capturing():
         return
-    key = (y.data_ptr(), y._version, y.numel(), rows)
-    if _LABELS_OK.get("key") == key:
+    key = (y._version, y.numel(), rows)
+    if getattr(y, "_lfm_labels_ok", None) == key:
         return
-    lo, hi = int(y.min()), int(y.max())
+    lo, hi = (int(v) for v in torch.stack([y.min(), y.max()]).tolist())  # one readback
     if lo < 0 or hi >= rows:
         raise IndexError(f"{what}: label {hi if hi >= rows else lo} is outside the embedding table [0, {rows}) "
                          "(classifier-free guidance needs a model built with label_dropout > 0: its null class is row num_classes)")
-    _LABELS_OK["key"] = key
+    try:
+        y._lfm_labels_ok = key
+    except Exception:  # noqa
+        pass
 
 
 def require_gpu(t, what):

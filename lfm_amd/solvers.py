@@ -15,6 +15,17 @@ import torch
 
 from . import hip
 
+
+class _SolverCache(dict):
+    """{(shape, cfg, ...): GraphedFixedGrid} held by the model object (so it dies with the model) -- but captured graphs must never be
+    copied or serialised with it: copy.deepcopy(model) / torch.save(model) see an EMPTY cache."""
+
+    def __deepcopy__(self, memo):
+        return _SolverCache()
+
+    def __reduce__(self):
+        return (_SolverCache, ())
+
 ADAPTIVE_SOLVER = ["dopri5", "dopri8", "adaptive_heun", "bosh3"]
 FIXER_SOLVER = ["euler", "rk4", "midpoint", "stochastic"]
 
@@ -222,6 +233,7 @@ def _perturbed(f):
     ulp after it, the one at the END one ulp before it (so a field that is discontinuous at grid points is sampled inside the step)."""
 
     def g(t, y, perturb=0):
+        t = t.to(y.dtype)  # torchdiffeq casts the time to the state's dtype FIRST: an ulp of a float64 grid would be rounded away in a float32 state
         if perturb > 0:
             t = torch.nextafter(t, t + 1)
         elif perturb < 0:
@@ -449,7 +461,7 @@ def _fused(model, x, model_kwargs):
     use_cfg = cfg_scale > 1.0
     if y is not None and _label_rows(model):
         hip.check_labels(y, _label_rows(model), type(model).__name__)  # once, before the labels go into the captured graph's buffer
-    per_model = model.__dict__.setdefault("_fused_solvers", {})
+    per_model = model.__dict__.setdefault("_fused_solvers", _SolverCache())
     key = (tuple(x.shape), use_cfg, cfg_scale, y is not None, x.device)
     fg = per_model.get(key)
     if fg is None:

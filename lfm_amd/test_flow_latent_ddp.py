@@ -157,7 +157,12 @@ def main(argv=None, hooks=None):
         dist.init_process_group(hooks["backend"])
     rank, world = dist.get_rank(), dist.get_world_size()
     model, vae = hooks.get("build_models", build_models)(args, device)  # un-offset seed: --random_weights gives every rank the SAME model
-    args.seed = args.seed + rank  # reference :30 (rank-local noise / label stream)
+    args.seed = args.seed + rank  # reference :28-32 (rank-local noise / label stream)
+    # build_models seeded the GLOBAL generators with the un-offset seed (same random weights everywhere); the reference seeds torch / cuda with
+    # seed + rank, and everything that draws from the global RNG afterwards (--generator dummy, latent_dist.sample()) must differ per rank
+    torch.manual_seed(args.seed)
+    if device.type == "cuda":
+        torch.cuda.manual_seed_all(args.seed)
     generator = get_generator(args.generator, args.n_sample, args.seed)
     save_dir = args.save_dir or "./generated_samples/{}/exp{}_ep{}_m{}".format(args.dataset, args.exp, args.epoch_id, args.method)
     save = hooks.get("save") or (lambda block, start: save_images_uint8(block, save_dir, start))

@@ -142,3 +142,49 @@ def test_world2_ddp_main_end_to_end(tmp_path):
         for j in range(3):
             for r in range(world):  # global index j*world + r + start  ->  position j*world + r of the gathered block
                 assert torch.equal(block[j * world + r], want[r][it][j]), (it, j, r)
+
+
+def test_bench_self_launches_two_gloo_ranks():
+    """`python bench.py --gpus 2` WITHOUT a torchrun environment (how the driver starts the scaling leg) must become the launcher itself:
+    two ranks over 127.0.0.1, one JSON line from rank 0 with the contract's keys.  --stub swaps the HIP step for a CPU stub (gloo)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--stub"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["rccl_world"] == 2 and j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "weak"
+    assert j["value"] > 0 and abs(j["value"] - 2 * 4 * 3 / (j["ms_per_step"] * 3e-3)) < 1e-6 * j["value"]
+
+
+def test_bench_refuses_a_mismatched_world():
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode != 0 and b"WORLD_SIZE=1" in r.stderr
+
+
+def test_bench_flop_closed_forms_match_the_oracle():
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    from oracle import dit_ref, vae_ref
+
+    for R in (8, 32, 64):
+        assert bench.vae_decode_flops(R) == vae_ref.vae_decode_flops(R)
+    assert abs(bench.vae_decode_flops(32) / 1e9 - 622.2) < 0.05
+    for name in ("DiT-S/2", "DiT-B/2", "DiT-L/2", "DiT-XL/2", "DiT-B/4", "DiT-L/8"):
+        c = dit_ref.DiTCfg.named(name, num_classes=1, label_dropout=0.0)
+        assert bench.dit_flops_per_image(c.tokens, c.hidden, c.depth, c.patch * c.patch * c.in_ch) == dit_ref.dit_flops_per_image(c)
