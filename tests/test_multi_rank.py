@@ -85,16 +85,20 @@ class _StubVae:
         return type("O", (), {"sample": img})()
 
 
-def _ddp_worker(rank, world, port, q, outdir):
+def _ddp_worker(rank, world, port, q, outdir, generator="determ"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     from lfm_amd import test_flow_latent_ddp as ddp
     from lfm_amd.io_formats import to_uint8_truncating
 
     saved = []
-    hooks = dict(backend="gloo", device="cpu", build_models=lambda a, d: (_StubModel().eval(), _StubVae()), to_uint8=to_uint8_truncating,
+    def build(a, d):
+        torch.manual_seed(a.seed)  # what build_models does with --random_weights: the GLOBAL generator, un-offset seed, on every rank
+        return _StubModel().eval(), _StubVae()
+
+    hooks = dict(backend="gloo", device="cpu", build_models=build, to_uint8=to_uint8_truncating,
                  save=lambda block, start: saved.append((start, block.clone())))
     argv = ["--model_type", "DiT-S/2", "--image_size", "32", "--num_in_channels", "4", "--n_sample", "10", "--batch_size", "3", "--method", "euler",
-            "--step_size", "0.25", "--generator", "determ", "--seed", "7", "--compute_fid", "--save_dir", outdir]
+            "--step_size", "0.25", "--generator", generator, "--seed", "7", "--compute_fid", "--save_dir", outdir]
     res = ddp.main(argv, hooks=hooks)
     q.put((rank, res["total"], res["iters"], res["written"], [(s, tuple(b.shape), b.numpy().tobytes()) for s, b in saved]))  # plain bytes: the
     # producer exits right after the put, tensors would travel as shared-memory handles that die with it
@@ -142,6 +146,39 @@ def test_world2_ddp_main_end_to_end(tmp_path):
         for j in range(3):
             for r in range(world):  # global index j*world + r + start  ->  position j*world + r of the gathered block
                 assert torch.equal(block[j * world + r], want[r][it][j]), (it, j, r)
+
+
+def test_world2_dummy_generator_draws_differ_per_rank(tmp_path):
+    """--generator dummy draws from torch's GLOBAL generator: the reference seeds it with seed + rank (test_flow_latent_ddp.py:28-32), so the two
+    ranks' images must differ -- they were identical when main() left the un-offset seed of build_models in place (advisor finding, round 2)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, q, str(tmp_path), "dummy")) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    saved = res[0][4]
+    assert len(saved) == 2
+    for start, shape, raw in saved:
+        block = torch.frombuffer(bytearray(raw), dtype=torch.uint8).reshape(shape)  # [6, 8, 8, 3]: position j * world + r
+        r0, r1 = block[0::2], block[1::2]
+        assert not torch.equal(r0, r1)
+        assert (r0 != r1).float().mean() > 0.5
+    # and rank 0's first batch is what seed 7 + 0 gives
+    torch.manual_seed(7)
+    x = torch.randn(3, 4, 4, 4)
+    for k in range(4):
+        x = x + (-0.25) * (-x + 0.1 * (1.0 - 0.25 * k))
+    from lfm_amd.io_formats import to_uint8_truncating
+
+    want = to_uint8_truncating(_StubVae().decode(x / 0.18215).sample)
+    block = torch.frombuffer(bytearray(saved[0][2]), dtype=torch.uint8).reshape(saved[0][1])
+    assert torch.equal(block[0::2], want)
 
 
 def test_bench_self_launches_two_gloo_ranks():
