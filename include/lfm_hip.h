@@ -122,10 +122,12 @@ int lfm_gemm_select(int which);
 /* Measurement only: when enabled, every eager lfm_dit_forward records a HIP event pair around each block's fc1 GEMM (the
  * dominant kernel); lfm_profile_fc1_read synchronises and returns the per-launch durations in ms (bench.py roofline row). */
 int lfm_profile_fc1(int enable);
-/* Library-wide options.  key 1 (LFM_OPT_FUSE_LN), value 0 / 1: EXPERIMENTAL -- LayerNorm + modulate (models/DiT.py:20-21,119,121) computed
- * inside the gated-residual epilogues of the proj / fc2 GEMMs where the shape allows it (whole 256-row tiles of one image, 1024-wide residual,
- * chip-filling batch), instead of by separate lfm_ln_modulate launches.  Default 0.  Not yet measured on hardware. */
-#define LFM_OPT_FUSE_LN 1
+/* Library-wide options.  key 1 (LFM_OPT_FOLD_LN), value 0 / 1, default 1: modulate(LayerNorm(x), shift, scale) (models/DiT.py:20-21, 129-130) FOLDED
+ * into the GEMM epilogues around it -- the gated-residual GEMMs (proj, fc2) emit the centred, (1 + scale)-weighted fp16 operand and per-row partial
+ * sums, the consuming GEMMs (qkv, fc1) apply rstd, the mean correction and the shift term in their epilogues -- wherever the shape allows it
+ * (residual width a multiple of 256, whole 256-row tiles of one image or one shared conditioning row, chip-filling batch); 0 = always the separate
+ * lfm_ln_modulate launches (the path every other shape takes).  Same result up to fp16 rounding of the operand (tests/test_gpu_dit.py). */
+#define LFM_OPT_FOLD_LN 1
 int lfm_set_option(int key, int value);
 
 /* Measurement only: s_memtime stamps written by the quadrant-phased GEMM (select flag 2) after every barrier of block 0,

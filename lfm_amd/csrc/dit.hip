@@ -17,10 +17,10 @@ int lfm_gemm_prefers_v4(int M, int N, int K) {
   if (g_gemm_dbg & 8192) return 1;
   return 0;
 }
-static int g_opt_fuse_ln = 0;
-extern "C" int lfm_set_option(int key, int value) {  // key 1 (LFM_OPT_FUSE_LN): EXPERIMENTAL LayerNorm-modulate inside the gated-residual epilogues
+static int g_opt_fold_ln = 1;
+extern "C" int lfm_set_option(int key, int value) {  // key 1 (LFM_OPT_FOLD_LN): adaLN LayerNorm-modulate folded into the GEMM epilogues (default 1)
   if (key == 1) {
-    g_opt_fuse_ln = value != 0;
+    g_opt_fold_ln = value != 0;
     return LFM_OK;
   }
   return LFM_ERR_ARG;
@@ -275,6 +275,79 @@ __global__ __launch_bounds__(256) void ln_modulate8_kernel(const float* __restri
   }
 }
 
+// Folded LayerNorm-modulate (gemm_kernel.h, "adaLN LayerNorm-modulate FOLDED into the GEMM epilogues"): the FIRST LayerNorm of a forward has no
+// producer GEMM in front of it (x comes from the patch embedding), so this kernel plays the producer: A' = fp16((x - mu)(1 + scale)) with the exact
+// row mean as the centring constant, partial slot 0 = (sum x, sum (x - mu)^2), the other slots 0, cen[m] = mu.  One row per wave, DPP sums.
+__global__ __launch_bounds__(256) void ln_center_mod_kernel(const float* __restrict__ X, half_t* __restrict__ A, int M, int D, int tokens,
+                                                            const float* __restrict__ scale, long mod_stride, float* __restrict__ part, int tiles_p,
+                                                            float* __restrict__ cen) {
+  const int lane = threadIdx.x & 63;
+  const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const int np = D >> 3;
+  f32x4 v[LN_MAXP][2];
+  const f32x4* xr = (const f32x4*)(X + m * D);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXP; ++i) {
+    const int c = lane + 64 * i;
+    if (c < np) {
+      v[i][0] = xr[2 * c];
+      v[i][1] = xr[2 * c + 1];
+      const f32x4 t = v[i][0] + v[i][1];
+      s += (t.x + t.y) + (t.z + t.w);
+    }
+  }
+  const float sum = wave_sum_dpp(s), mean = sum / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXP; ++i) {
+    if (lane + 64 * i < np) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        v[i][h] -= mean;
+        const f32x4 t = v[i][h] * v[i][h];
+        q += (t.x + t.y) + (t.z + t.w);
+      }
+    }
+  }
+  const float qs = wave_sum_dpp(q);
+  const f32x4* sc = (const f32x4*)(scale + (m / tokens) * mod_stride);
+  half8_t* ar = (half8_t*)(A + m * D);
+#pragma unroll
+  for (int i = 0; i < LN_MAXP; ++i) {
+    const int c = lane + 64 * i;
+    if (c < np) {
+      const f32x4 lo = v[i][0] * (1.0f + sc[2 * c]), hi = v[i][1] * (1.0f + sc[2 * c + 1]);
+      half8_t h = {(half_t)lo.x, (half_t)lo.y, (half_t)lo.z, (half_t)lo.w, (half_t)hi.x, (half_t)hi.y, (half_t)hi.z, (half_t)hi.w};
+      ar[c] = h;
+    }
+  }
+  if (lane < tiles_p) *(f32x2*)(part + (m * tiles_p + lane) * 2) = lane == 0 ? (f32x2){sum, qs} : (f32x2){0.f, 0.f};
+  if (lane == 0) cen[m] = mean;
+}
+
+// A operand of the u / v GEMMs of the folded path: for block i and branch b (0 = msa, 1 = mlp) rows [0, R) = fp16(1 + scale), rows [R, 2R) = fp16(shift);
+// Amod[((i * 2 + b) * 2 + h) * R + r][k].  (u only ever multiplies rstd (mu - c), a small correction, and v takes the place of a term that used
+// to be rounded to fp16 inside the LN output anyway: fp16 operands cost nothing here.)
+__global__ __launch_bounds__(256) void mod_rows_f16_kernel(const float* __restrict__ mod, long mod_stride, int depth, int R, int D,
+                                                           half_t* __restrict__ Amod) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // over depth * 2 * 2 * R * D / 4
+  const int d4 = D >> 2;
+  const long total = (long)depth * 4 * R * d4;
+  if (idx >= total) return;
+  const int k = (int)(idx % d4) * 4;
+  long t = idx / d4;
+  const int r = (int)(t % R);
+  t /= R;
+  const int h = (int)(t & 1), b = (int)((t >> 1) & 1), i = (int)(t >> 2);
+  const float* src = mod + (long)r * mod_stride + (long)i * 6 * D + (b ? 3 * D : 0) + (h ? 0 : D) + k;  // h = 0: scale (+ 1), h = 1: shift
+  f32x4 v = *(const f32x4*)src;
+  if (!h) v += 1.0f;
+  half4_t o = {(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
+  *(half4_t*)(Amod + idx * 4) = o;
+}
+
 #include "attention_kernel.h"  // dit_attention_kernel<T, JQ, HD> + attention_launch
 
 // ------------------------------------------------------------------ final layer + unpatchify + solver update
@@ -424,8 +497,12 @@ struct DitWs {
   half_t* c_half; // [B, D]
   float* mod;     // [B, J]
   float* ones;    // [D] of 1.0f: gate row of the patch-embedding GEMM (large patches)
-  float* ln_part;      // [M][D / 256][2] row partials of the fused LayerNorm epilogue (experimental option)
-  unsigned* ln_count;  // [M / 256] panel counters + 1 word of spin time-outs
+  // folded LayerNorm-modulate (gemm_kernel.h): row partials, two centring-constant arrays (ping-pong), the u / v GEMM's operand and results
+  float* ln_part;  // [M][ceil(D / 256)][2]
+  float* cen[2];   // [M] each
+  half_t* amod;    // [depth][2 branches][2][rows][D] fp16: (1 + scale | shift) rows
+  float* uvq;      // [depth][2 rows][3D]: u, v of the qkv projections
+  float* uvf;      // [depth][2 rows][H]:  u, v of fc1
   float* slab;    // split-K partial tiles (small M only, else null)
   size_t slab_bytes;
   size_t total;
@@ -452,7 +529,11 @@ static DitWs carve(const lfm_dit_shape* s, int B, void* ws, bool sizing = false)
   w.mod = (float*)take((size_t)B * J * 4);
   w.ones = (float*)take(D * 4);
   w.ln_part = (float*)take(M * ((D + 255) / 256) * 8);
-  w.ln_count = (unsigned*)take((M / 256 + 2) * 4);
+  w.cen[0] = (float*)take(M * 4);
+  w.cen[1] = (float*)take(M * 4);
+  w.amod = (half_t*)take((size_t)s->depth * 4 * B * D * 2);
+  w.uvq = (float*)take((size_t)s->depth * 2 * B * 3 * D * 4);
+  w.uvf = (float*)take((size_t)s->depth * 2 * B * H * 4);
   // latency mode: room for up to 4 K slices of the widest GEMM output (fc1), when the token count is small
   // (when SIZING for a maximum batch, reserve the slabs of the largest small batch too, so that the requirement is monotone in the
   // batch and a workspace sized for max_batch serves every smaller batch)
@@ -623,6 +704,13 @@ extern "C" int lfm_attention_trace_read(unsigned long long* host_out, int n) {  
   return LFM_OK;
 }
 
+extern "C" int lfm_attention_wg_trace_read(unsigned long long* host_out, int n_wg) {  // MODE 3: {hw id, start, landed, end} per workgroup
+  if (!host_out || n_wg <= 0 || n_wg > ATT_WG_TRACE) return LFM_ERR_ARG;
+  if (hipDeviceSynchronize() != hipSuccess) return LFM_ERR_LAUNCH;
+  if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(att_wg_trace), sizeof(unsigned long long) * 4 * n_wg, 0, hipMemcpyDeviceToHost) != hipSuccess) return LFM_ERR_LAUNCH;
+  return LFM_OK;
+}
+
 extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w, void* workspace, size_t workspace_bytes,
                                const lfm_dit_call* c, lfm_stream_t stream) {
   int rc = check_shape(s);
@@ -671,26 +759,68 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
   half_t* Qb = ws.QKVH;
   half_t* Kb = Qb + (size_t)M * D;
   half_t* Vb = Kb + (size_t)M * D;
-  // EXPERIMENTAL (lfm_set_option(1, 1)): LayerNorm-modulate inside the proj / fc2 epilogues (EpiGateResidLN).  Only where its preconditions
-  // hold: whole 256-row tiles of ONE image each, the column tiles of a panel on one XCD (grid % 128 == 0 with the 4 x tiles_n tile groups),
-  // chip-filling shapes on the default kernel.
-  const int ln_tn = D / 256, ln_tm = M / 256;
-  const bool fuse_ln = g_opt_fuse_ln && (D % 256 == 0) && (M % 256 == 0) && (T % 256 == 0) && ln_tn == 4 && ((ln_tm * ln_tn) % 128 == 0) &&
-                       (g_gemm_sel == 0 || g_gemm_sel == 5) && !(g_gemm_dbg & 1048576) && (H % 64 == 0);
-  unsigned ln_launches = 0;
-  if (fuse_ln && lfm_zero_async(ws.ln_count, (size_t)(ln_tm + 1) * 4, st)) return LFM_ERR_LAUNCH;
-  auto gate_resid_ln = [&](const half_t* Asrc, long lda, const half_t* W, int K, const float* bias, const float* gate, const float* shift,
-                           const float* scale) {
-    EpiGateResidLN e{ws.X, D, bias, gate, mstride, T, ws.A, shift, scale, mstride, ws.ln_part, ws.ln_count, (unsigned)ln_tn * ++ln_launches, ln_tn,
-                     (int*)(ws.ln_count + ln_tm)};
-    return launch_gemm256h_tn(ASrcRowMajor{Asrc, lda, M, 0}, W, K, M, D, K, e, st);
+  // FOLDED LayerNorm-modulate (default; gemm_kernel.h): only where its preconditions hold -- whole 256-row tiles of ONE image each (or one shared
+  // modulation row), row partials in D / 256 slots, all four GEMMs chip-filling on the 16x16x32 kernel.  Everything else (small batches, DiT-S / XL
+  // widths, patch 4 / 8 token counts with per-image conditioning, forced kernels) takes the separate ln_modulate launches below.
+  const int tiles_p = D / 256;
+  const bool fold = g_opt_fold_ln && (D % 256 == 0) && (M % 256 == 0) && (rows == 1 || T % 256 == 0) && (long)(M / 256) * tiles_p >= 192 &&
+                    g_gemm_sel == 0 && !(g_gemm_dbg & 1048576) && (H % 64 == 0) && s->depth >= 1;
+  const long uvs_q = rows == 1 ? 0 : 3 * D, uvs_f = rows == 1 ? 0 : H;
+  int cen_cur = 0;
+  if (fold) {
+    const long nmod = (long)s->depth * 4 * rows * (D / 4);
+    hipLaunchKernelGGL(mod_rows_f16_kernel, dim3(cdiv(nmod, 256)), dim3(256), 0, st, ws.mod, mstride, s->depth, rows, D, ws.amod);
+    LFM_CHECK_LAUNCH();
+    // u, v of every block in two batched GEMMs (batch = depth): [2 rows x D] x [D x 3D] and [2 rows x D] x [D x H]
+    rc = launch_gemm_auto(ASrcRowMajor{ws.amod, D, 2 * rows, 0}, (const half_t*)w->qkv_w, D, 2 * rows, 3 * D, D,
+                          EpiUV{ws.uvq, 3L * D, w->qkv_b, rows, 3L * D}, st, s->depth, 4L * rows * D, 3L * D * D, 2L * rows * 3 * D);
+    if (rc) return rc;
+    rc = launch_gemm_auto(ASrcRowMajor{ws.amod + 2L * rows * D, D, 2 * rows, 0}, (const half_t*)w->fc1_w, D, 2 * rows, H, D,
+                          EpiUV{ws.uvf, (long)H, w->fc1_b, rows, (long)H}, st, s->depth, 4L * rows * D, (long)H * D, 2L * rows * H);
+    if (rc) return rc;
+    hipLaunchKernelGGL(ln_center_mod_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, ws.X, ws.A, M, D, T, ws.mod + D, mstride, ws.ln_part, tiles_p,
+                       ws.cen[0]);
+    LFM_CHECK_LAUNCH();
+  }
+  auto rowstat_src = [&]() {  // consumer: reads cen[cen_cur], publishes the new row means into the other array, which becomes current
+    RowStatSrc r{ws.ln_part, ws.cen[cen_cur], ws.cen[cen_cur ^ 1], tiles_p, 1.0f / (float)D, 1e-6f};
+    cen_cur ^= 1;
+    return r;
   };
-  for (int i = 0; i < s->depth; ++i) {
-    const float* mod = ws.mod + (long)i * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
-    if (!(fuse_ln && i > 0)) {  // fused: the previous block's fc2 epilogue already wrote this block's first LN-modulate
-      rc = ln_modulate_launch(ws.X, ws.A, M, D, T, mod, mod + D, mstride, st);
+  if (fold) {
+    for (int i = 0; i < s->depth; ++i) {
+      const float* mod = ws.mod + (long)i * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+      const float* uq = ws.uvq + (long)i * 2 * rows * 3 * D;
+      const float* uf = ws.uvf + (long)i * 2 * rows * H;
+      const EpiQKVMod e_qkv{Qb, Kb, Vb, uq, uq + (long)rows * 3 * D, uvs_q, D, D / s->heads, T, EpiQKV::log2_or_neg(T), rowstat_src(), nullptr, 0};
+      rc = launch_gemm256h_tn(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->qkv_w + (size_t)i * 3 * D * D, D, M, 3 * D, D, e_qkv, st);
+      if (rc) return rc;
+      rc = attention_launch(Qb, Kb, Vb, ws.A, B, s->heads, D / s->heads, T, st);
+      if (rc) return rc;
+      // proj: X += gate_msa * (.), A' for fc1 with scale_mlp, partials; c = the row means the qkv GEMM just published
+      const EpiGateResidMod e_proj{ws.X, D, w->proj_b + (size_t)i * D, mod + 2 * D, mstride, T, ws.A, mod + 4 * D, mstride, ws.cen[cen_cur], ws.ln_part, tiles_p};
+      rc = launch_gemm256h_tn(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D, e_proj, st);
+      if (rc) return rc;
+      const bool prof = g_prof_on && g_prof_count < LFM_PROF_MAX;
+      if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_count], st);
+      const EpiModGeluF16 e_fc1{ws.QKVH, H, uf, uf + (long)rows * H, uvs_f, T, rowstat_src(), nullptr, 0};
+      rc = launch_gemm256h_tn(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->fc1_w + (size_t)i * H * D, D, M, H, D, e_fc1, st);
+      if (rc) return rc;
+      if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_count++ + 1], st);
+      if (i + 1 < s->depth) {  // fc2 writes the NEXT block's A' (its scale_msa)
+        const EpiGateResidMod e_fc2{ws.X, D, w->fc2_b + (size_t)i * D, mod + 5 * D, mstride, T, ws.A, mod + 7 * D, mstride, ws.cen[cen_cur], ws.ln_part, tiles_p};
+        rc = launch_gemm256h_tn(ASrcRowMajor{ws.QKVH, H, M, 0}, (const half_t*)w->fc2_w + (size_t)i * D * H, H, M, D, H, e_fc2, st);
+      } else {
+        const EpiGateResidF32 e_fc2{ws.X, D, w->fc2_b + (size_t)i * D, mod + 5 * D, mstride, T};
+        rc = launch_gemm256h_tn(ASrcRowMajor{ws.QKVH, H, M, 0}, (const half_t*)w->fc2_w + (size_t)i * D * H, H, M, D, H, e_fc2, st);
+      }
       if (rc) return rc;
     }
+  }
+  for (int i = 0; i < (fold ? 0 : s->depth); ++i) {
+    const float* mod = ws.mod + (long)i * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+    rc = ln_modulate_launch(ws.X, ws.A, M, D, T, mod, mod + D, mstride, st);
+    if (rc) return rc;
     const EpiQKV e_qkv = EpiQKV::make(Qb, Kb, Vb, w->qkv_b + (size_t)i * 3 * D, D, D / s->heads, T);
     rc = launch_gemm_splitk(ws.A, D, (const half_t*)w->qkv_w + (size_t)i * 3 * D * D, D, M, 3 * D, D, e_qkv, ws.slab, ws.slab_bytes, st);
     if (rc == 1) rc = launch_gemm_auto(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->qkv_w + (size_t)i * 3 * D * D, D, M, 3 * D, D, e_qkv, st);
@@ -698,16 +828,11 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
     rc = attention_launch(Qb, Kb, Vb, ws.A, B, s->heads, D / s->heads, T, st);
     if (rc) return rc;
     const EpiGateResidF32 e_proj{ws.X, D, w->proj_b + (size_t)i * D, mod + 2 * D, mstride, T};
-    if (fuse_ln) {  // the epilogue overwrites A (this GEMM's own operand) panel by panel, after every tile of the panel has finished reading it
-      rc = gate_resid_ln(ws.A, D, (const half_t*)w->proj_w + (size_t)i * D * D, D, w->proj_b + (size_t)i * D, mod + 2 * D, mod + 3 * D, mod + 4 * D);
-      if (rc) return rc;
-    } else {
-      rc = launch_gemm_splitk(ws.A, D, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D, e_proj, ws.slab, ws.slab_bytes, st);
-      if (rc == 1) rc = launch_gemm_auto(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D, e_proj, st);
-      if (rc) return rc;
-      rc = ln_modulate_launch(ws.X, ws.A, M, D, T, mod + 3 * D, mod + 4 * D, mstride, st);
-      if (rc) return rc;
-    }
+    rc = launch_gemm_splitk(ws.A, D, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D, e_proj, ws.slab, ws.slab_bytes, st);
+    if (rc == 1) rc = launch_gemm_auto(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D, e_proj, st);
+    if (rc) return rc;
+    rc = ln_modulate_launch(ws.X, ws.A, M, D, T, mod + 3 * D, mod + 4 * D, mstride, st);
+    if (rc) return rc;
     const bool prof = g_prof_on && g_prof_count < LFM_PROF_MAX;
     if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_count], st);
     const EpiBiasGeluF16 e_fc1{ws.QKVH, H, w->fc1_b + (size_t)i * H};
@@ -716,11 +841,6 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
     if (rc) return rc;
     if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_count++ + 1], st);
     const EpiGateResidF32 e_fc2{ws.X, D, w->fc2_b + (size_t)i * D, mod + 5 * D, mstride, T};
-    if (fuse_ln && i + 1 < s->depth) {  // ... and writes the NEXT block's first LN-modulate (its shift_msa / scale_msa)
-      rc = gate_resid_ln(ws.QKVH, H, (const half_t*)w->fc2_w + (size_t)i * D * H, H, w->fc2_b + (size_t)i * D, mod + 5 * D, mod + 6 * D, mod + 7 * D);
-      if (rc) return rc;
-      continue;
-    }
     rc = launch_gemm_splitk(ws.QKVH, H, (const half_t*)w->fc2_w + (size_t)i * D * H, H, M, D, H, e_fc2, ws.slab, ws.slab_bytes, st);
     if (rc == 1) rc = launch_gemm_auto(ASrcRowMajor{ws.QKVH, H, M, 0}, (const half_t*)w->fc2_w + (size_t)i * D * H, H, M, D, H, e_fc2, st);
     if (rc) return rc;

@@ -32,6 +32,16 @@ __device__ __forceinline__ void g256h_stamp(bool tr, int g, int wn, int lane, in
   }
 }
 
+// epilogues with per-row operands in LDS provide row_aux(m) -> f32x2 and store8r(m, n, lo, hi, aux_lo, aux_hi, row_aux)
+template <class Epi, class = void>
+struct epi_has_row_aux {
+  static constexpr bool value = false;
+};
+template <class Epi>
+struct epi_has_row_aux<Epi, decltype((void)&Epi::row_aux)> {
+  static constexpr bool value = true;
+};
+
 template <int BN, bool TRACE = false, class Epi>
 __device__ __forceinline__ void g256h_epilogue_rows(f32x4_t (&acc)[8][4], char* smem, const Epi& epi, int m0, int n0, int M, int N, int g, int wn,
                                                     int lane, int wave, bool narrow, bool tr = false) {
@@ -61,16 +71,27 @@ __device__ __forceinline__ void g256h_epilogue_rows(f32x4_t (&acc)[8][4], char* 
         fill32(i);
         g256h_stamp<TRACE>(tr, g, wn, lane, 1 + 4 * i);
         f32x4 lo[4], hi[4];
+        const int mb = m0 + g * 128 + i * 32 + rrow, n = n0 + wn * 64 + rcol * 8;
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
           lo[ps] = *(const f32x4*)(scr + (ps * 8 + rrow) * 272 + rcol * 32);
           hi[ps] = *(const f32x4*)(scr + (ps * 8 + rrow) * 272 + rcol * 32 + 16);
         }
+        if constexpr (epi_has_row_aux<Epi>::value) {  // per-row operands of the epilogue (LDS), fetched with the read-back: one wait covers both
+          if (COL && interior) {
+            f32x2 ra[4];
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) ra[ps] = epi.row_aux(mb + ps * 8);
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) epi.store8r(mb + ps * 8, n, lo[ps], hi[ps], cl, ch, ra[ps]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            continue;
+          }
+        }
         if constexpr (TRACE) {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           g256h_stamp<TRACE>(tr, g, wn, lane, 2 + 4 * i);
         }
-        const int mb = m0 + g * 128 + i * 32 + rrow, n = n0 + wn * 64 + rcol * 8;
         if (COL && interior) {
           if constexpr (COL) {
             g256h_stamp<TRACE>(tr, g, wn, lane, 3 + 4 * i);
@@ -158,22 +179,25 @@ __device__ __forceinline__ float g256h_row16_sum(float v) {
   return v;
 }
 
-// EXPERIMENTAL fused gated-residual + LayerNorm-modulate epilogue (EpiGateResidLN, gemm_kernel.h).  Interior tiles only.
-// Row-major hand-over as g256h_epilogue_rows (4-column form): per pass a lane owns rows mb + 4 ps (ps = 0..7), columns n .. n + 3; the 16
-// lanes that share a row are one DPP row, so a row's partial sums over the wave's 64 columns cost four DPP adds.
+// Producer epilogue of the folded LayerNorm-modulate (EpiGateResidMod, gemm_kernel.h): the gated-residual read-modify-write of X, plus the consumer
+// GEMM's A operand A' = fp16((X' - c)(1 + scale)) and this tile's per-row partials (sum X', sum (X' - c)^2).  Interior tiles of ONE image only (the
+// host guarantees it).  Row-major hand-over as g256h_epilogue_rows (4-column form): per pass a lane owns rows mb + 4 ps (ps = 0..7), columns n .. n + 3;
+// the 16 lanes that share a row are one DPP row, so a row's sums over the wave's 64 columns cost four DPP adds each.
 template <class Epi>
-__device__ __forceinline__ void g256h_epilogue_fused_ln(f32x4_t (&acc)[8][4], char* smem, const Epi& epi, int m0, int n0, int tile_m, int tile_n,
-                                                        int N, int g, int wn, int lane, int wave) {
+__device__ __forceinline__ void g256h_epilogue_mod(f32x4_t (&acc)[8][4], char* smem, const Epi& epi, int m0, int n0, int tile_n, int N, int g, int wn,
+                                                   int lane, int wave) {
   char* scr = smem + wave * (32 * 272);
-  float* red = (float*)(smem + 8 * 32 * 272);          // [g][wn][128 rows][2]: 8 KiB behind the eight scratch areas
-  float* rowstat = (float*)(smem + 8 * 32 * 272 + 8192);  // [256 rows][2] = (mean, rstd) of the whole rows
+  float* red = (float*)(smem + 8 * 32 * 272);           // [g][wn][128 rows][2]: 8 KiB behind the eight scratch areas
+  float* cen_s = (float*)(smem + 8 * 32 * 272 + 8192);  // [256 rows] centring constants of the tile's rows
   const int l15 = lane & 15, l4 = lane >> 4;
   const int rrow = lane >> 4, rcol = lane & 15;
   const int n = n0 + wn * 64 + rcol * 4;
   const int img = m0 / epi.tokens;
+  if (threadIdx.x < 256) cen_s[threadIdx.x] = epi.cen[m0 + threadIdx.x];
   const f32x4 bias = *(const f32x4*)(epi.bias + n);
   const f32x4 gate = *(const f32x4*)(epi.gate + (long)img * epi.gate_stride + n);
-  f32x4 xk[4][8];
+  const f32x4 sc1 = *(const f32x4*)(epi.scale + (long)img * epi.mod_stride + n) + 1.0f;
+  __syncthreads();
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -181,90 +205,86 @@ __device__ __forceinline__ void g256h_epilogue_fused_ln(f32x4_t (&acc)[8][4], ch
 #pragma unroll
       for (int j = 0; j < 4; ++j) *(f32x4_t*)(scr + (h2 * 16 + l15) * 272 + (j * 16 + l4 * 4) * 4) = acc[2 * i + h2][j];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const int mb = m0 + g * 128 + i * 32 + rrow;
+    const int rl = g * 128 + i * 32 + rrow;  // + 4 ps: row inside the tile
     f32x4 xo[8];
 #pragma unroll
-    for (int ps = 0; ps < 8; ++ps) xo[ps] = *(const f32x4*)(epi.X + (long)(mb + ps * 4) * epi.ldx + n);
+    for (int ps = 0; ps < 8; ++ps) xo[ps] = *(const f32x4*)(epi.X + (long)(m0 + rl + ps * 4) * epi.ldx + n);
 #pragma unroll
     for (int ps = 0; ps < 8; ++ps) {
       const f32x4 v = *(const f32x4*)(scr + (ps * 4 + rrow) * 272 + rcol * 16);
+      const float c = cen_s[rl + ps * 4];
       const f32x4 xn = xo[ps] + gate * (v + bias);
-      *(f32x4*)(epi.X + (long)(mb + ps * 4) * epi.ldx + n) = xn;
-      xk[i][ps] = xn;
-      const float s = g256h_row16_sum((xn.x + xn.y) + (xn.z + xn.w));
-      const float q = g256h_row16_sum((xn.x * xn.x + xn.y * xn.y) + (xn.z * xn.z + xn.w * xn.w));
+      *(f32x4*)(epi.X + (long)(m0 + rl + ps * 4) * epi.ldx + n) = xn;
+      const f32x4 d = xn - c;
+      const f32x4 ap = d * sc1;
+      const half4_t h = {(half_t)ap.x, (half_t)ap.y, (half_t)ap.z, (half_t)ap.w};
+      *(half4_t*)(epi.A + (long)(m0 + rl + ps * 4) * N + n) = h;
+      const float sx = g256h_row16_sum((xn.x + xn.y) + (xn.z + xn.w));
+      const float sq = g256h_row16_sum((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w));
       if (rcol == 0) {
-        float* d = red + (((g * 4 + wn) * 128) + i * 32 + ps * 4 + rrow) * 2;
-        d[0] = s;
-        d[1] = q;
+        float* dst = red + (((g * 4 + wn) * 128) + i * 32 + ps * 4 + rrow) * 2;
+        dst[0] = sx;
+        dst[1] = sq;
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
   __syncthreads();
-  // tile-level row sums (fixed order over the four waves) -> this tile's slot of the panel's partials
+  // tile-level row sums (fixed order over the four waves) -> this tile's slot of the row's partials
   if (wn == 0) {
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
       const int r = lane + 64 * rr;
-      float s = 0.f, q = 0.f;
+      float sx = 0.f, sq = 0.f;
 #pragma unroll
       for (int w4 = 0; w4 < 4; ++w4) {
-        s += red[((g * 4 + w4) * 128 + r) * 2];
-        q += red[((g * 4 + w4) * 128 + r) * 2 + 1];
+        sx += red[((g * 4 + w4) * 128 + r) * 2];
+        sq += red[((g * 4 + w4) * 128 + r) * 2 + 1];
       }
-      float* d = epi.part + ((long)(m0 + g * 128 + r) * epi.tiles_n + tile_n) * 2;
-      d[0] = s;
-      d[1] = q;
+      *(f32x2*)(epi.part + ((long)(m0 + g * 128 + r) * epi.tiles_n + tile_n) * 2) = (f32x2){sx, sq};
     }
   }
-  // the partials must be in the L2 (the siblings run on the same XCD) before the counter says so: stores are write-through, vmcnt(0) = acknowledged
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    // relaxed on purpose: an agent-scope release / acquire would write back / invalidate the L2 per operation; the ordering that is needed
-    // (same XCD, same L2) is the vmcnt(0) above and the one invalidate below
-    __hip_atomic_fetch_add(epi.counter + tile_m, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int it = 0;
-    while (__hip_atomic_load(epi.counter + tile_m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epi.target) {
-      __builtin_amdgcn_s_sleep(4);
-      if (++it > (1 << 20)) {  // ~ a second: something is wrong (a sibling tile was never scheduled); do not hang the device
-        if (epi.spin_timeouts) atomicAdd(epi.spin_timeouts, 1);
-        break;
-      }
-    }
-  }
-  __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // nothing of the siblings' partials may be served from this CU's L1
-  // whole-row statistics of the tile's 256 rows: thread r < 256 sums the panel's tiles_n partials of row r in a fixed order
+}
+
+// Consumer prologue of the folded LayerNorm-modulate: (a, b) = (rstd, -rstd (mu - c)) of the tile's 256 rows -> LDS rs[256][2] (above the operand
+// ring); tile column 0 publishes mu[m] as the next producer's centring constant.  Two halves around the K loop's first DMAs: the loads are issued
+// BEFORE them (vmcnt returns in order: a load issued behind the twelve prologue DMAs would make its consumer wait for all of them -- measured
+// +1.3 us per tile), the arithmetic runs while they fly.
+#define G256H_MAX_PARTS 5  // residual width <= 1280
+struct G256hRowStatRegs {
+  f32x2 p[G256H_MAX_PARTS];
+  float c;
+};
+template <class Epi>
+__device__ __forceinline__ G256hRowStatRegs g256h_rowstat_load(const Epi& epi, int m0, int M) {
+  G256hRowStatRegs r;
+  const int m = m0 + (int)threadIdx.x < M ? m0 + (int)threadIdx.x : M - 1;
   if (threadIdx.x < 256) {
-    const int r = threadIdx.x;
-    const float* pp = epi.part + (long)(m0 + r) * epi.tiles_n * 2;
-    float s = 0.f, q = 0.f;
-    for (int t = 0; t < epi.tiles_n; ++t) {
-      s += pp[2 * t];
-      q += pp[2 * t + 1];
-    }
-    const float inv_n = 1.0f / (float)N;
-    const float mean = s * inv_n;
-    const float var = fmaxf(q * inv_n - mean * mean, 0.f);
-    rowstat[2 * r] = mean;
-    rowstat[2 * r + 1] = rsqrtf(var + 1e-6f);
+    const f32x2* pp = (const f32x2*)(epi.st.part + (long)m * epi.st.tiles_p * 2);
+#pragma unroll
+    for (int t = 0; t < G256H_MAX_PARTS; ++t) r.p[t] = t < epi.st.tiles_p ? pp[t] : (f32x2){0.f, 0.f};
+    r.c = epi.st.cen_in[m];
   }
-  __syncthreads();
-  const f32x4 sc = *(const f32x4*)(epi.scale + (long)img * epi.mod_stride + n);
-  const f32x4 sh = *(const f32x4*)(epi.shift + (long)img * epi.mod_stride + n);
-  const f32x4 sc1 = sc + 1.0f;
+  return r;
+}
+template <class Epi>
+__device__ __forceinline__ void g256h_rowstat_finish(Epi& epi, const G256hRowStatRegs& r, char* smem, int m0, int M, int tile_n) {
+  float* rs = (float*)(smem + G256Q_LDS_BYTES);
+  if (threadIdx.x < 256) {
+    float sx = 0.f, sq = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int ps = 0; ps < 8; ++ps) {
-      const int r = g * 128 + i * 32 + ps * 4 + rrow;
-      const float mean = rowstat[2 * r], rstd = rowstat[2 * r + 1];
-      const f32x4 o = (xk[i][ps] - mean) * rstd * sc1 + sh;
-      const half4_t h = {(half_t)o.x, (half_t)o.y, (half_t)o.z, (half_t)o.w};
-      *(half4_t*)(epi.A + (long)(m0 + r) * N + n) = h;
+    for (int t = 0; t < G256H_MAX_PARTS; ++t) {  // fixed order
+      sx += r.p[t].x;
+      sq += r.p[t].y;
     }
+    const float mu = sx * epi.st.inv_n, dl = mu - r.c;
+    const float var = fmaxf(sq * epi.st.inv_n - dl * dl, 0.f);
+    const float rstd = rsqrtf(var + epi.st.eps);
+    *(f32x2*)(rs + 2 * threadIdx.x) = (f32x2){rstd, -rstd * dl};
+    if (tile_n == 0 && m0 + (int)threadIdx.x < M) epi.st.cen_out[m0 + threadIdx.x] = mu;
+  }
+  epi.rs = rs;
+  epi.m0 = m0;
 }
 
 template <int BN, bool TRACE = false, class Epi>
@@ -274,8 +294,8 @@ __device__ __forceinline__ void g256h_epilogue(f32x4_t (&acc)[8][4], char* smem,
   epi_batch(epi, bz, bsC, 0);
   g256h_stamp<TRACE>(tr, g, wn, lane, 0);
   if (dbg & 4) return;  // ablation: no epilogue
-  if constexpr (epi_is_fused_ln<Epi>::value) {
-    g256h_epilogue_fused_ln(acc, smem, epi, m0, n0, m0 / G256_BM, n0 / BN, N, g, wn, lane, wave);
+  if constexpr (epi_is_producer_mod<Epi>::value) {
+    g256h_epilogue_mod(acc, smem, epi, m0, n0, n0 / BN, N, g, wn, lane, wave);
     return;
   }
   const int l15 = lane & 15, l4 = lane >> 4;
@@ -287,14 +307,15 @@ __device__ __forceinline__ void g256h_epilogue(f32x4_t (&acc)[8][4], char* smem,
       char* scr = smem + wave * (32 * 272);
       const bool wide = !(dbg & 1024) && epi.wide_t_ok();
       // the per-column bias of every pass, loaded ahead of the first store (a load issued after stores waits for them: vmcnt is in order)
-      float bt[2][4];
+      typedef decltype(epi.load_t(0)) AuxT;  // float (a bias) or (u, v) of the folded path
+      AuxT bt[2][4];
       if (wide) {
 #pragma unroll
         for (int J = 0; J < 2; ++J)
 #pragma unroll
           for (int ps = 0; ps < 4; ++ps) {
             const int n = n0 + wn * 64 + J * 32 + (lane >> 3) + ps * 8;
-            bt[J][ps] = n < N ? epi.load_t(n) : 0.f;
+            bt[J][ps] = n < N ? epi.load_t(n) : AuxT{};
           }
       }
 #pragma unroll
@@ -334,7 +355,7 @@ __device__ __forceinline__ void g256h_epilogue(f32x4_t (&acc)[8][4], char* smem,
               const f32x4 hi = *(const f32x4*)(scr + (ps * 8 + rrow) * 272 + rcol * 32 + 16);
               const int n = nb + ps * 8;
               if (n >= N) continue;
-              const float b = bt[J][ps];
+              const AuxT b = bt[J][ps];
               if (m + 7 < M) epi.store_t8(n, m, lo, hi, b);
               else if (m + 3 < M) epi.store_t(n, m, lo, b);
             }
@@ -547,6 +568,11 @@ __global__ __launch_bounds__(512) void gemm256h_tn_kernel(ASrc asrc, const half_
   };
 
   // ---- prologue: pieces A0(0) B0(0) B1(0) A1(0) [A0(1) B0(1)]
+  G256hRowStatRegs rsr;
+  if constexpr (epi_has_rowstat<Epi>::value) {
+    rsr = g256h_rowstat_load(epi, m0, M);
+    __builtin_amdgcn_sched_barrier(0);
+  }
   asrc.begin_tile(0, G256Q_BK);
   issue_a(0, smem + G256Q_SLOT_A0);
   issue_b(0, 0, smem + G256Q_SLOT_B0);
@@ -557,6 +583,7 @@ __global__ __launch_bounds__(512) void gemm256h_tn_kernel(ASrc asrc, const half_
     issue_a(0, smem + G256Q_BUF_BYTES + G256Q_SLOT_A0);
     issue_b(0, 1, smem + G256Q_BUF_BYTES + G256Q_SLOT_B0);
   }
+  if constexpr (epi_has_rowstat<Epi>::value) g256h_rowstat_finish(epi, rsr, smem, m0, M, tile_n);
   if (nk > 1) G256H_VMCNT(6);
   else G256H_VMCNT(2);
   G256_BARRIER();
@@ -615,13 +642,14 @@ static inline int launch_gemm256h_tn(const ASrc& asrc, const half_t* W, long ldw
   if (M <= 0 || N <= 0 || K <= 0 || (K % G256Q_BK) != 0 || (N % 4) != 0) return LFM_ERR_SHAPE;
   if ((ldw % 8) != 0 || ((uintptr_t)W & 15)) return LFM_ERR_ALIGN;
   const int tm = cdiv(M, G256_BM), tn = cdiv(N, G256_BN);
+  constexpr int LDS = G256Q_LDS_BYTES + (epi_has_rowstat<Epi>::value ? 2048 : 0);  // + rs[256][2] of the folded LayerNorm consumers
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm256h_tn_kernel<ASrc, Epi, TRACE>, hipFuncAttributeMaxDynamicSharedMemorySize, G256Q_LDS_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemm256h_tn_kernel<ASrc, Epi, TRACE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return LFM_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm256h_tn_kernel<ASrc, Epi, TRACE>), dim3(tm * tn, batch), dim3(512), G256Q_LDS_BYTES, stream, asrc, W, ldw, M, N, K, tn, epi, bsA,
+  hipLaunchKernelGGL((gemm256h_tn_kernel<ASrc, Epi, TRACE>), dim3(tm * tn, batch), dim3(512), LDS, stream, asrc, W, ldw, M, N, K, tn, epi, bsA,
                      bsW, bsC, lfm_gemm_debug_flags());
   LFM_CHECK_LAUNCH();
   return LFM_OK;

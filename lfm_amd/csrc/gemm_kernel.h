@@ -129,32 +129,42 @@ struct EpiGateResidF32 {
   }
 };
 
-// EXPERIMENTAL (off unless lfm_set_option(LFM_OPT_FUSE_LN, 1); written at the end of round 2 without GPU time left to measure it):
-// the gated-residual epilogue of proj / fc2 ALSO produces the next GEMM's A operand, fp16(LayerNorm(X') * (1 + scale) + shift), so the
-// LN-modulate launch that would re-read the 67 MB of X' disappears.  N == D: the tiles_n column tiles of an M-panel hold
-// whole rows between them.  Each tile keeps its block of X' in registers, publishes per-row (sum, sum of squares) partials in a fixed
-// slot part[m][tile_n] (deterministic), bumps the panel's counter and waits until all tiles_n tiles of the panel have done so; then it
-// normalises its own block.  Host-side preconditions (lfm_dit_forward): interior tiles only, one image per tile (tokens % 256 == 0), the
-// panel's tiles on ONE XCD (tile order: grid % 128 == 0), all of which holds for the benchmark shape; the gemm256h kernel only.
-// Variance is E[x^2] - mean^2 in fp32 (one pass), so the result differs from ln_modulate's two-pass value in the last bits.
-struct EpiGateResidLN {
+// ------------------------------------------------------------------ adaLN LayerNorm-modulate FOLDED into the GEMM epilogues (round 3)
+// modulate(LayerNorm(x), shift, scale) (DiT.py:20-21, 129-130) feeds a Linear, so with mu, rstd the row statistics of x and c any per-row constant
+//   (LN(x) (1 + s) + sh) W^T  =  rstd * [ ((x - c)(1 + s)) W^T  -  (mu - c) * u ]  +  v,     u[n] = sum_k (1 + s[k]) W[n][k],  v[n] = sum_k sh[k] W[n][k] + bias[n].
+// PRODUCER = the gated-residual GEMM that updates x (proj, fc2; EpiGateResidMod): its epilogue already holds the new x in registers, so it also
+//   writes A' = fp16((x - c)(1 + s)) -- the consumer's A operand -- and per-row partials (sum x, sum (x - c)^2) of its 256 columns into a fixed slot
+//   part[m][tile_n] (plain stores, deterministic).  c = cen[m] = the row mean BEFORE this update (written by the previous consumer), so x - c is
+//   centred up to the mean shift of one residual update: no cancellation in the fp16 rounding of A' or in the one-pass variance.
+// CONSUMER = the GEMM that reads A' (qkv, fc1; rowstat epilogues below): before its K loop every tile reduces its 256 rows' partials to
+//   a = rstd, b = -rstd (mu - c) in LDS (and tile column 0 publishes mu as the next producer's c); its epilogue evaluates a * acc + (b * u + v).
+// No inter-workgroup synchronisation, no second pass over x: both LN-modulate launches of a block (2 x 100 MB of HBM traffic) disappear for
+// 33.5 MB of extra stores in each producer epilogue.  u, v: one small batched GEMM per forward over all blocks (lfm_dit_forward).
+// (Rejected first, measured in round 3: normalising inside the producer epilogue behind an inter-workgroup panel counter -- correct, bit-stable,
+// but 12.03 vs 11.92 ms per DiT-L/2 evaluation: the wait for the three sibling tiles cost more than the two launches it saved.)
+struct RowStatSrc {
+  const float* part;    // [M][tiles_p][2]
+  const float* cen_in;  // [M] the c the producer used
+  float* cen_out;       // [M] <- mu (written by tile column 0 only)
+  int tiles_p;          // partial slots per row (the producer's column tiles)
+  float inv_n, eps;     // 1 / row length, LayerNorm eps
+};
+
+// X[m][n] += gate * (acc + bias)  AND  A'[m][n] = fp16((X[m][n] - c[m]) (1 + scale[n])),  part[m][tile_n] = (sum X, sum (X - c)^2)
+struct EpiGateResidMod {
   float* X;
   long ldx;
   const float* bias;
   const float* gate;
   long gate_stride;
   int tokens;
-  // fused LayerNorm + modulate of the CONSUMER (shift / scale of the LN that follows this GEMM)
-  half_t* A;              // [M][N] fp16, leading dimension N
-  const float* shift;
-  const float* scale;
+  half_t* A;           // [M][N], leading dimension N
+  const float* scale;  // the consumer LayerNorm's scale row (+ img * mod_stride)
   long mod_stride;
-  float* part;            // [M][tiles_n][2]
-  unsigned* counter;      // [tiles_m], monotone over the fused launches of one forward (zeroed at its start)
-  unsigned target;        // tiles_n * (index of this launch among the fused launches + 1)
+  const float* cen;    // [M]
+  float* part;         // [M][tiles_n][2]
   int tiles_n;
-  int* spin_timeouts;     // debug: incremented when the bounded wait ran out (the result is then wrong, but nothing hangs)
-  static constexpr bool fused_ln = true;
+  static constexpr bool producer_mod = true;
   struct Aux {
     f32x4 b, g, x;
   };
@@ -170,12 +180,124 @@ struct EpiGateResidLN {
   }
 };
 template <class Epi, class = void>
-struct epi_is_fused_ln {
+struct epi_is_producer_mod {
   static constexpr bool value = false;
 };
 template <class Epi>
-struct epi_is_fused_ln<Epi, decltype((void)Epi::fused_ln)> {
-  static constexpr bool value = Epi::fused_ln;
+struct epi_is_producer_mod<Epi, decltype((void)Epi::producer_mod)> {
+  static constexpr bool value = Epi::producer_mod;
+};
+
+// C = a[m] * acc + (b[m] * u[n] + v[n]) -> fp16;  (a, b) of the tile's rows sit in LDS at rs[2 (m - m0)] (filled by the kernel's prologue)
+struct EpiModF16 {
+  half_t* C;
+  long ldc;
+  const float* u;  // + img * uv_stride + n
+  const float* v;
+  long uv_stride;
+  int tokens;
+  const float* rs;
+  int m0;
+  struct Aux {
+    f32x4 u, v;
+  };
+  static constexpr bool column_aux = true;
+  __device__ __forceinline__ Aux load(int m, int n) const {
+    const long o = (long)(m / tokens) * uv_stride + n;
+    Aux a;
+    a.u = *(const f32x4*)(u + o);
+    a.v = *(const f32x4*)(v + o);
+    return a;
+  }
+  __device__ __forceinline__ f32x4 affine(int m, f32x4 acc, const Aux& c) const {
+    const f32x2 ab = *(const f32x2*)(rs + 2 * (m - m0));
+    return ab.x * acc + (ab.y * c.u + c.v);
+  }
+  __device__ __forceinline__ void store(int m, int n, f32x4 acc, const Aux& c) const {
+    const f32x4 o = affine(m, acc, c);
+    half4_t h = {(half_t)o.x, (half_t)o.y, (half_t)o.z, (half_t)o.w};
+    *(half4_t*)(C + (long)m * ldc + n) = h;
+  }
+  __device__ __forceinline__ bool wide_ok() const { return (ldc & 7) == 0 && ((uintptr_t)C & 15) == 0; }
+  __device__ __forceinline__ f32x2 row_aux(int m) const { return *(const f32x2*)(rs + 2 * (m - m0)); }
+  __device__ __forceinline__ void store8r(int m, int n, f32x4 lo, f32x4 hi, const Aux& cl, const Aux& ch, f32x2 ab) const {
+    lo = ab.x * lo + (ab.y * cl.u + cl.v);
+    hi = ab.x * hi + (ab.y * ch.u + ch.v);
+    half8_t h = {(half_t)lo.x, (half_t)lo.y, (half_t)lo.z, (half_t)lo.w, (half_t)hi.x, (half_t)hi.y, (half_t)hi.z, (half_t)hi.w};
+    *(half8_t*)(C + (long)m * ldc + n) = h;
+  }
+  __device__ __forceinline__ void store8(int m, int n, f32x4 lo, f32x4 hi, const Aux& cl, const Aux& ch) const {
+    store8r(m, n, lo, hi, cl, ch, row_aux(m));
+  }
+};
+
+// fc1 of the folded path: C = gelu_tanh(a[m] * acc + (b[m] * u[n] + v[n])) -> fp16   (v carries the fc1 bias)
+struct EpiModGeluF16 {
+  half_t* C;
+  long ldc;
+  const float* u;
+  const float* v;
+  long uv_stride;
+  int tokens;
+  RowStatSrc st;
+  const float* rs;
+  int m0;
+  static constexpr bool rowstat = true;
+  struct Aux {
+    f32x4 u, v;
+  };
+  static constexpr bool column_aux = true;
+  __device__ __forceinline__ Aux load(int m, int n) const {
+    const long o = (long)(m / tokens) * uv_stride + n;
+    Aux a;
+    a.u = *(const f32x4*)(u + o);
+    a.v = *(const f32x4*)(v + o);
+    return a;
+  }
+  __device__ __forceinline__ void store(int m, int n, f32x4 acc, const Aux& c) const {
+    const f32x2 ab = *(const f32x2*)(rs + 2 * (m - m0));
+    const f32x4 x = ab.x * acc + (ab.y * c.u + c.v);
+    const f32x2_t p = gelu_tanh_pk((f32x2_t){x.x, x.y}), q = gelu_tanh_pk((f32x2_t){x.z, x.w});
+    half4_t h = {(half_t)p.x, (half_t)p.y, (half_t)q.x, (half_t)q.y};
+    *(half4_t*)(C + (long)m * ldc + n) = h;
+  }
+  __device__ __forceinline__ bool wide_ok() const { return (ldc & 7) == 0 && ((uintptr_t)C & 15) == 0; }
+  __device__ __forceinline__ f32x2 row_aux(int m) const { return *(const f32x2*)(rs + 2 * (m - m0)); }
+  __device__ __forceinline__ void store8(int m, int n, f32x4 lo, f32x4 hi, const Aux& cl, const Aux& ch) const {
+    store8r(m, n, lo, hi, cl, ch, row_aux(m));
+  }
+  __device__ __forceinline__ void store8r(int m, int n, f32x4 lo, f32x4 hi, const Aux& cl, const Aux& ch, f32x2 ab) const {
+    lo = ab.x * lo + (ab.y * cl.u + cl.v);
+    hi = ab.x * hi + (ab.y * ch.u + ch.v);
+    const f32x2_t a = gelu_tanh_pk((f32x2_t){lo.x, lo.y}), c = gelu_tanh_pk((f32x2_t){lo.z, lo.w});
+    const f32x2_t e = gelu_tanh_pk((f32x2_t){hi.x, hi.y}), g = gelu_tanh_pk((f32x2_t){hi.z, hi.w});
+    half8_t h = {(half_t)a.x, (half_t)a.y, (half_t)c.x, (half_t)c.y, (half_t)e.x, (half_t)e.y, (half_t)g.x, (half_t)g.y};
+    *(half8_t*)(C + (long)m * ldc + n) = h;
+  }
+};
+template <class Epi, class = void>
+struct epi_has_rowstat {
+  static constexpr bool value = false;
+};
+template <class Epi>
+struct epi_has_rowstat<Epi, decltype((void)Epi::rowstat)> {
+  static constexpr bool value = Epi::rowstat;
+};
+
+// u / v rows of the folded path (lfm_dit_forward): rows [0, R) = (1 + scale) W^T, rows [R, 2R) = shift W^T + bias; batched over the blocks
+struct EpiUV {
+  float* C;
+  long ldc;
+  const float* bias;
+  int R;
+  long bs_bias;
+  typedef f32x4 Aux;
+  __device__ __forceinline__ void batch(int bz, long bs) {
+    C += (long)bz * bs;
+    bias += (long)bz * bs_bias;
+  }
+  __device__ __forceinline__ Aux load(int m, int n) const { return m >= R ? *(const f32x4*)(bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  __device__ __forceinline__ void store(int m, int n, f32x4 v, const Aux& b) const { *(f32x4*)(C + (long)m * ldc + n) = v + b; }
 };
 
 // Split-K partial tile: slice bz of the K range writes its fp32 partial product to slab[bz][M][N] (see launch_gemm_splitk).
@@ -245,6 +367,74 @@ struct EpiQKV {
   __device__ __forceinline__ void store_t8(int n, int m, f32x4 lo, f32x4 hi, float b) const {  // eight consecutive tokens
     half8_t h = {(half_t)(lo.x + b), (half_t)(lo.y + b), (half_t)(lo.z + b), (half_t)(lo.w + b),
                  (half_t)(hi.x + b), (half_t)(hi.y + b), (half_t)(hi.z + b), (half_t)(hi.w + b)};
+    *(half8_t*)vt_ptr(n, m) = h;
+  }
+};
+
+// QKV projection of the folded path: EpiQKV's layout with the row-affine correction instead of the bias (v carries the qkv bias)
+struct EpiQKVMod {
+  half_t* Q;
+  half_t* K;
+  half_t* Vt;
+  const float* u;  // [rows][3D] (+ img * uv_stride)
+  const float* v;
+  long uv_stride;
+  int D, hd, tokens;
+  int tok_sh;
+  RowStatSrc st;
+  const float* rs;
+  int m0;
+  static constexpr bool rowstat = true;
+  typedef EpiModF16::Aux Aux;
+  __device__ __forceinline__ half_t* vt_ptr(int n, int m) const {
+    const int c = n - 2 * D;
+    const int img = tok_sh >= 0 ? (m >> tok_sh) : m / tokens, tok = m - img * tokens;
+    return Vt + ((long)img * D + c) * tokens + tok;
+  }
+  __device__ __forceinline__ Aux load(int m, int n) const {
+    const long o = (long)(m / tokens) * uv_stride + n;
+    Aux a;
+    a.u = *(const f32x4*)(u + o);
+    a.v = *(const f32x4*)(v + o);
+    return a;
+  }
+  __device__ __forceinline__ void store(int m, int n, f32x4 acc, const Aux& c) const {  // generic path (edge tiles of odd shapes only)
+    const f32x2 ab = *(const f32x2*)(rs + 2 * (m - m0));
+    const f32x4 o = ab.x * acc + (ab.y * c.u + c.v);
+    if (n < 2 * D) {
+      half_t* dst = (n < D) ? (Q + (long)m * D + n) : (K + (long)m * D + (n - D));
+      half4_t h = {(half_t)o.x, (half_t)o.y, (half_t)o.z, (half_t)o.w};
+      *(half4_t*)dst = h;
+    } else {
+      half_t* dst = vt_ptr(n, m);
+      dst[0] = (half_t)o.x;
+      dst[tokens] = (half_t)o.y;
+      dst[2 * tokens] = (half_t)o.z;
+      dst[3 * tokens] = (half_t)o.w;
+    }
+  }
+  __device__ __forceinline__ bool plain_tile(int n0, int bn) const { return n0 + bn <= D || (n0 >= D && n0 + bn <= 2 * D); }
+  __device__ __forceinline__ EpiModF16 plain(int n0) const { return EpiModF16{n0 < D ? Q : K - D, (long)D, u, v, uv_stride, tokens, rs, m0}; }
+  __device__ __forceinline__ bool transposed(int n0) const { return n0 >= 2 * D; }
+  // column constants of a V^T row: (u[n], v[n]) of the tile's image
+  __device__ __forceinline__ f32x2 load_t(int n) const {
+    const long o = (long)(m0 / tokens) * uv_stride + n;
+    return (f32x2){u[o], v[o]};
+  }
+  __device__ __forceinline__ void store_t(int n, int m, f32x4 acc, f32x2 c) const {  // four consecutive tokens m .. m + 3 of column n
+    const f32x4 r0 = *(const f32x4*)(rs + 2 * (m - m0)), r1 = *(const f32x4*)(rs + 2 * (m - m0) + 4);  // (a, b) x 4 rows
+    half4_t h = {(half_t)(r0.x * acc.x + (r0.y * c.x + c.y)), (half_t)(r0.z * acc.y + (r0.w * c.x + c.y)),
+                 (half_t)(r1.x * acc.z + (r1.y * c.x + c.y)), (half_t)(r1.z * acc.w + (r1.w * c.x + c.y))};
+    *(half4_t*)vt_ptr(n, m) = h;
+  }
+  __device__ __forceinline__ bool wide_t_ok() const { return (tokens & 7) == 0 && ((uintptr_t)Vt & 15) == 0; }
+  __device__ __forceinline__ void store_t8(int n, int m, f32x4 lo, f32x4 hi, f32x2 c) const {  // eight consecutive tokens
+    const float* r = rs + 2 * (m - m0);
+    const f32x4 r0 = *(const f32x4*)r, r1 = *(const f32x4*)(r + 4), r2 = *(const f32x4*)(r + 8), r3 = *(const f32x4*)(r + 12);
+    half8_t h = {(half_t)(r0.x * lo.x + (r0.y * c.x + c.y)), (half_t)(r0.z * lo.y + (r0.w * c.x + c.y)),
+                 (half_t)(r1.x * lo.z + (r1.y * c.x + c.y)), (half_t)(r1.z * lo.w + (r1.w * c.x + c.y)),
+                 (half_t)(r2.x * hi.x + (r2.y * c.x + c.y)), (half_t)(r2.z * hi.y + (r2.w * c.x + c.y)),
+                 (half_t)(r3.x * hi.z + (r3.y * c.x + c.y)), (half_t)(r3.z * hi.w + (r3.w * c.x + c.y))};
     *(half8_t*)vt_ptr(n, m) = h;
   }
 };

@@ -207,7 +207,7 @@ def ln_modulate(X, shift, scale, tokens, mod_stride):
     return A
 
 
-OPT_FUSE_LN = 1  # experimental: LayerNorm-modulate inside the gated-residual GEMM epilogues (include/lfm_hip.h)
+OPT_FOLD_LN = 1  # adaLN LayerNorm-modulate folded into the GEMM epilogues, default on (include/lfm_hip.h)
 
 
 def set_option(key, value):

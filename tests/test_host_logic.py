@@ -322,12 +322,12 @@ def test_unbuilt_dit_shapes_are_refused_at_construction():
 
 
 def test_library_options_are_host_state_only():
-    """lfm_set_option touches no device: unknown keys are refused, the experimental fused-LayerNorm switch toggles and defaults to off."""
+    """lfm_set_option touches no device: unknown keys are refused, the folded-LayerNorm switch toggles (default on)."""
     from lfm_amd import hip
 
     L = hip.lib()
     assert L.lfm_set_option(99, 1) < 0
     with pytest.raises(hip.LfmHipError):
         hip.set_option(99, 1)
-    hip.set_option(hip.OPT_FUSE_LN, 1)
-    hip.set_option(hip.OPT_FUSE_LN, 0)
+    hip.set_option(hip.OPT_FOLD_LN, 0)
+    hip.set_option(hip.OPT_FOLD_LN, 1)
