@@ -33,7 +33,13 @@ static __device__ unsigned long long att_wg_trace[ATT_WG_TRACE][4];
 // S / softmax / PV); 2 = compute only (K / V^T are never fetched: the loop runs on whatever the LDS holds).  Round 2, 64 images x 16 heads x 256
 // tokens (profiles/r02_probe3_attention_phases_ln_rows.txt): whole kernel 40-41 us, memory phases 22-23 us, compute (with its Q / O traffic) 33-36 us
 // -- the kernel is bound by the instruction stream of its two waves per SIMD, and the memory phases already hide behind the co-resident workgroup.
-// Measured and NOT kept on that evidence: a streamed schedule (DMAs issued key block by key block, V^T slices as 64-byte pieces, the online-softmax
+// Round 3 (profiles/r03_attention_*.txt): the per-workgroup timeline (MODE 3: HW_ID + s_memtime per workgroup) shows every CU holding two workgroups
+// that de-phase by themselves (the second of a pair lags by ~14k cycles), a workgroup living ~33k cycles of which the loads take ~11k, the key-block
+// loop ~15.5k and the store drain ~5k: the kernel is bound by memory LATENCY at an occupancy of two workgroups per CU (64 KiB of LDS each), not by
+// its instruction streams.  Measured and not kept: sleeping one workgroup of every first-round pair (37.7-43 us vs 38.5), and a one-basic-block
+// step with sched_group_barrier interleaving every MFMA with the VALU that covers its 32 pipe cycles (ISA as prescribed, 40.4 vs 39.5 us) -- the
+// partner wave already fills those gaps.  Kept: the lazy rescale (below).
+// Measured and NOT kept on that evidence (round 2): a streamed schedule (DMAs issued key block by key block, V^T slices as 64-byte pieces, the online-softmax
 // loop started after block 0 behind one counted vmcnt + barrier per block): correct, 40.8-41.7 us vs 40.1-42.8 us.
 template <int T, int JQ, int HD, int MODE = 0>
 __global__ __launch_bounds__((T / (32 * JQ)) * 64, HD == 64 ? (T / (32 * JQ)) / 2 : 2) void dit_attention_kernel(
