@@ -266,6 +266,13 @@ int lfm_grid_advance(const float* ts, const float* dts, int* step, float* t_cur,
 int lfm_lincomb(float* out, const float* base, const float* const* k_host_ptrs, const float* coef, const float* scale, int nk, long n,
                 lfm_stream_t stream);
 
+/* Error ratio of one adaptive Runge-Kutta step, as torchdiffeq's controller takes it (RMS over the WHOLE state tensor; reference call site
+ * test_flow_latent.py:61-73, dopri5 at rtol = atol = 1e-5):  out[0] = sqrt(mean_i ((*dt) * sum_j e_coef[j] k_j[i] / (atol + rtol max(|y0[i]|, |y1[i]|)))^2).
+ * e_coef, dt, out: DEVICE memory; k_host_ptrs: HOST array of nk <= 8 device pointers; scratch: >= 1024 floats of device memory; n % 4 == 0.
+ * Deterministic (two fixed-order stages); the only value of the step the host has to read. */
+int lfm_rk_error_norm(const float* y0, const float* y1, const float* const* k_host_ptrs, const float* e_coef, const float* dt, int nk, long n,
+                      float rtol, float atol, float* scratch, float* out, lfm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -485,6 +485,41 @@ __global__ void lincomb_kernel(float* out, const float* base, LinPtrs ks, const 
   ((f32x4*)out)[i] = acc;
 }
 
+// Error ratio of an adaptive Runge-Kutta step as torchdiffeq takes it (whole-tensor RMS): sqrt(mean(((dt * sum_j e_j k_j) / (atol + rtol max(|y0|, |y1|)))^2)).
+// Two fixed-order stages (block partials, then one block over them): deterministic, one float for the host to read.
+#define RK_BLOCKS 1024
+__global__ __launch_bounds__(256) void rk_err_partial_kernel(const float* __restrict__ y0, const float* __restrict__ y1, LinPtrs ks,
+                                                             const float* __restrict__ coef, const float* __restrict__ dt, int nk, long n4, float rtol,
+                                                             float atol, float* __restrict__ part) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  const float h = *dt;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    f32x4 e = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < nk; ++j) {
+      const float c = coef[j];
+      if (c != 0.f) e += c * ((const f32x4*)ks.k[j])[i];
+    }
+    const f32x4 a = ((const f32x4*)y0)[i], b = ((const f32x4*)y1)[i];
+    const f32x4 r = {h * e.x / (atol + rtol * fmaxf(fabsf(a.x), fabsf(b.x))), h * e.y / (atol + rtol * fmaxf(fabsf(a.y), fabsf(b.y))),
+                     h * e.z / (atol + rtol * fmaxf(fabsf(a.z), fabsf(b.z))), h * e.w / (atol + rtol * fmaxf(fabsf(a.w), fabsf(b.w)))};
+    acc += (r.x * r.x + r.y * r.y) + (r.z * r.z + r.w * r.w);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void rk_err_finish_kernel(const float* __restrict__ part, int nb, float inv_n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) acc += part[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = sqrtf(((red[0] + red[1]) + (red[2] + red[3])) * inv_n);
+}
+
 // ------------------------------------------------------------------ host side
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -860,6 +895,20 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
 extern "C" int lfm_grid_advance(const float* ts, const float* dts, int* step, float* t_cur, float* t_next, float* dt_cur, lfm_stream_t stream) {
   if (!ts || !dts || !step || !t_cur || !t_next || !dt_cur) return LFM_ERR_ARG;
   hipLaunchKernelGGL(grid_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, ts, dts, step, t_cur, t_next, dt_cur);
+  LFM_CHECK_LAUNCH();
+  return LFM_OK;
+}
+
+extern "C" int lfm_rk_error_norm(const float* y0, const float* y1, const float* const* k_host_ptrs, const float* e_coef, const float* dt, int nk, long n,
+                                 float rtol, float atol, float* scratch, float* out, lfm_stream_t stream) {
+  if (!y0 || !y1 || !k_host_ptrs || !e_coef || !dt || !scratch || !out || nk <= 0 || nk > 8) return LFM_ERR_ARG;
+  if (n <= 0 || n % 4 || (((uintptr_t)y0 | (uintptr_t)y1) & 15)) return LFM_ERR_ALIGN;
+  LinPtrs p;
+  for (int i = 0; i < 8; ++i) p.k[i] = i < nk ? k_host_ptrs[i] : nullptr;
+  const int nb = (int)(cdiv(n / 4, 256) < RK_BLOCKS ? cdiv(n / 4, 256) : RK_BLOCKS);
+  hipLaunchKernelGGL(rk_err_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, y0, y1, p, e_coef, dt, nk, n / 4, rtol, atol, scratch);
+  LFM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(rk_err_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, nb, 1.0f / (float)n, out);
   LFM_CHECK_LAUNCH();
   return LFM_OK;
 }

@@ -84,6 +84,9 @@ def lib():
     L.lfm_grid_advance.argtypes = [C.c_void_p] * 7
     L.lfm_lincomb.restype = C.c_int
     L.lfm_lincomb.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_void_p]
+    L.lfm_rk_error_norm.restype = C.c_int
+    L.lfm_rk_error_norm.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_float,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]
     L.lfm_vae_workspace_bytes.restype = C.c_size_t
     L.lfm_vae_workspace_bytes.argtypes = [C.c_int, C.c_int]
     L.lfm_vae_decode.restype = C.c_int
@@ -220,6 +223,15 @@ def dit_attention(Q, K, Vt, batch, heads, T, head_dim=64):
     O = torch.empty_like(Q)
     check(lib().lfm_dit_attention_hd(ptr(Q), ptr(K), ptr(Vt), ptr(O), batch, heads, head_dim, T, stream_ptr()), "lfm_dit_attention_hd")
     return O
+
+
+def rk_error_norm(y0, y1, ks, e_coef, dt, rtol, atol, scratch, out):
+    """out[0] = sqrt(mean(((dt * sum e_j k_j) / (atol + rtol max(|y0|, |y1|)))^2)) -- device fp32 tensors; e_coef, dt, out on the device."""
+    require_gpu(y0, "rk_error_norm")
+    arr = (C.c_void_p * len(ks))(*[k.data_ptr() for k in ks])
+    check(lib().lfm_rk_error_norm(ptr(y0), ptr(y1), arr, ptr(e_coef), ptr(dt), len(ks), y0.numel(), float(rtol), float(atol), ptr(scratch), ptr(out),
+                                  stream_ptr(y0.device)), "lfm_rk_error_norm")
+    return out
 
 
 def lincomb(out, base, ks, coef, scale=None):

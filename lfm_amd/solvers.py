@@ -146,11 +146,33 @@ class Dopri5:
         self.f, self.rtol, self.atol, self.max_num_steps = f, rtol, atol, max_num_steps
         self.nfe_steps = 0
         self.accepted = 0
+        # device fast path: fp32 state on the GPU and at most 8 stage derivatives per combination -> every stage sum is ONE
+        # lfm_lincomb launch, the error ratio ONE fused reduction (lfm_rk_error_norm) whose 4-byte result is the step's only device -> host read;
+        # time is kept twice, as device tensors for the kernels and as host doubles for the control flow (same IEEE arithmetic, no read-back)
+        self._dev = bool(y0.is_cuda and y0.dtype == torch.float32 and y0.is_contiguous() and y0.numel() % 4 == 0 and len(self.E) <= 8
+                         and float(rtol) == rtol and float(atol) == atol)
+        if self._dev:
+            dv = y0.device
+            self._cB = [torch.tensor(b, dtype=torch.float32, device=dv) for b in self.B]
+            self._cE = torch.tensor(self.E, dtype=torch.float32, device=dv)
+            self._cSOL = None if self.SOL is None else torch.tensor(self.SOL, dtype=torch.float32, device=dv)
+            self._scratch = torch.empty(1024, dtype=torch.float32, device=dv)
+            self._ratio = torch.empty(1, dtype=torch.float32, device=dv)
         f0 = f(t0, y0)
         self.y0, self.f0 = y0, f0
         self.t0 = self.t1 = t0
-        self.dt = self._initial_step(t0, y0, f0, order=self.ORDER - 1)
+        self._t0_h = self._t1_h = float(t0)
+        self.dt = self._initial_step(t0, y0, f0, order=self.ORDER - 1)  # (property: also sets the host copy)
+        self._last = None
         self.coef = [y0] * 5
+
+    @property
+    def dt(self):
+        return self._dt
+
+    @dt.setter
+    def dt(self, value):  # set from outside (initial step, tests forcing a step): one read-back keeps the host copy exact
+        self._dt, self._dt_h = value, float(value)
 
     def _initial_step(self, t0, y0, f0, order=4):
         scale = self.atol + y0.abs() * self.rtol
@@ -164,48 +186,70 @@ class Dopri5:
             h1 = (0.01 / torch.max(d1, d2)) ** (1.0 / (order + 1))
         return torch.min(100 * h0, h1).to(t0.dtype)
 
+    def _lin(self, base, ks, coef_dev, coef_host, dty):
+        """base + dty * sum coef_j k_j: one lincomb launch on the device path, eager torch otherwise."""
+        if self._dev and len(ks) <= 8:
+            out = torch.empty_like(base)
+            hip.lincomb(out, base, ks, coef_dev[: len(ks)], dty)
+            return out
+        return base + _comb(ks, coef_host, dty)
+
     def _step(self):
         y0, f0, t0, dt = self.y0, self.f0, self.t1, self.dt
         t1 = t0 + dt
         t0y, dty, t1y = t0.to(y0.dtype), dt.to(y0.dtype), t1.to(y0.dtype)
         k = [f0]
         yi = y0
-        for a, b in zip(self.A, self.B):
-            yi = y0 + _comb(k, b, dty)
+        for i, (a, b) in enumerate(zip(self.A, self.B)):
+            yi = self._lin(y0, k, self._cB[i] if self._dev else None, b, dty)
             k.append(self.f(t1y if a == 1.0 else t0y + a * dty, yi))
         # FSAL pairs: the last stage IS the solution; otherwise (adaptive_heun) the solution is its own combination and -- as in
         # torchdiffeq's _runge_kutta_step -- the last stage's derivative still serves as f1 of the next step
-        y1 = yi if self.SOL is None else y0 + _comb(k, self.SOL, dty)
+        y1 = yi if self.SOL is None else self._lin(y0, k, self._cSOL if self._dev else None, self.SOL, dty)
         f1 = k[-1]
-        err = _comb(k, self.E, dty)
-        tol = self.atol + self.rtol * torch.max(y0.abs(), y1.abs())
-        ratio = _rms(err / tol)  # the one device->host read of the step
-        ratio_h = float(ratio)
+        if self._dev:
+            hip.rk_error_norm(y0, y1, k, self._cE, dty, self.rtol, self.atol, self._scratch, self._ratio)
+            ratio_h = float(self._ratio)  # the one device->host read of the step
+        else:
+            err = _comb(k, self.E, dty)
+            tol = self.atol + self.rtol * torch.max(y0.abs(), y1.abs())
+            ratio_h = float(_rms(err / tol))
         self.nfe_steps += 1
         if ratio_h <= 1:
-            y_mid = y0 + _comb(k, self.MID, dty)
-            a = 2 * dty * (f1 - f0) - 8 * (y1 + y0) + 16 * y_mid
-            b = dty * (5 * f0 - 3 * f1) + 18 * y0 + 14 * y1 - 32 * y_mid
-            c = dty * (f1 - 4 * f0) - 11 * y0 - 5 * y1 + 16 * y_mid
-            self.coef = [y0, dty * f0, c, b, a]
+            # the quartic dense output is only ever evaluated for the step that contains a requested time: keep what it needs, fit lazily
+            self._last = (y0, y1, f0, f1, k, dty)
+            self.coef = None
             self.t0, self.t1, self.y0, self.f0 = t0, t1, y1, f1
+            self._t0_h, self._t1_h = self._t1_h, self._t1_h + self._dt_h
             self.accepted += 1
         if ratio_h == 0:
             factor = 10.0
         else:
             factor = min(10.0, max(0.9 / ratio_h ** (1.0 / self.ORDER), 1.0 if ratio_h < 1 else 0.2))
-        self.dt = dt * factor
+        self._dt, self._dt_h = dt * factor, self._dt_h * factor  # both copies, no read-back
+
+    def _fit(self):
+        if self.coef is None:
+            y0, y1, f0, f1, k, dty = self._last
+            y_mid = y0 + _comb(k, self.MID, dty)
+            a = 2 * dty * (f1 - f0) - 8 * (y1 + y0) + 16 * y_mid
+            b = dty * (5 * f0 - 3 * f1) + 18 * y0 + 14 * y1 - 32 * y_mid
+            c = dty * (f1 - 4 * f0) - 11 * y0 - 5 * y1 + 16 * y_mid
+            self.coef = [y0, dty * f0, c, b, a]
+        return self.coef
 
     def advance(self, t_next):
         n = 0
-        while bool(t_next > self.t1):
+        t_next_h = float(t_next)
+        while t_next_h > self._t1_h:
             assert n < self.max_num_steps
             self._step()
             n += 1
-        x = ((t_next - self.t0) / (self.t1 - self.t0)).to(self.coef[0].dtype)
-        total = self.coef[0] + x * self.coef[1]
+        coef = self._fit()
+        x = ((t_next - self.t0) / (self.t1 - self.t0)).to(coef[0].dtype)
+        total = coef[0] + x * coef[1]
         xp = x
-        for c in self.coef[2:]:
+        for c in coef[2:]:
             xp = xp * x
             total = total + xp * c
         return total
