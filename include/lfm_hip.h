@@ -114,9 +114,10 @@ int lfm_gemm_f16(const void* A, long lda, const void* W, long ldw, void* C, long
 int lfm_gemm_qkv_f16(const void* A, long lda, const void* W, long ldw, void* Q, void* K_out, void* Vt, int M, int D, int K,
                      const float* bias, int head_dim, int tokens, lfm_stream_t stream);
 
-/* Kernel selection for the GEMMs: 0 = automatic (a 256x256 kernel for chip-filling shapes -- the quadrant-phased one when
- * K % 64 == 0, else the ping-pong one -- and the 128x128 kernel otherwise), 1 = force 128x128, 2 = force ping-pong,
- * 3 = force quadrant-phased; | flags << 4 = ablation / A-B switches.  For measurement and parity tests. */
+/* Kernel selection for the GEMMs: 0 = automatic (the 256x256 quadrant-phased kernel on 16x16x32 MFMAs for chip-filling shapes with K % 64 == 0,
+ * the 256x128 two-workgroups-per-CU kernel for chip-filling shapes that are only 128 columns wide, the 128x128 kernel otherwise), 1 = force
+ * 128x128, 4 = force 256x128, 5 = force 256x256 (other values are refused); | flags << 4 = ablation / A-B switches.  For measurement and parity
+ * tests. */
 int lfm_gemm_select(int which);
 
 /* Measurement only: when enabled, every eager lfm_dit_forward records a HIP event pair around each block's fc1 GEMM (the

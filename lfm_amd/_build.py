@@ -15,6 +15,8 @@ STAMP = os.path.join(LIBDIR, "liblfm_hip.stamp")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only",
          "-Wno-macro-redefined"]
+if os.environ.get("LFM_MEASURE") == "1":  # measurement builds: the s_memtime-stamped GEMM epilogues and the attention phase / trace variants (tools/)
+    FLAGS.append("-DLFM_MEASURE")
 
 
 def sources():

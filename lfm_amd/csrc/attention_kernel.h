@@ -351,7 +351,8 @@ static int attention_launch(const half_t* Q, const half_t* K, const half_t* Vt, 
   // A/B switch (measurement only): 8 waves x 32 queries (4 waves/SIMD) measured 44.3 us vs 40.2 us for 4 waves x 64 queries --
   // the kernel moves Q,K,V^T,O = 134 MB per launch (3.4 TB/s): more waves do not help
   const bool narrow = T == 256 && (lfm_gemm_debug_flags() & 256);
-  const int mode = (lfm_gemm_debug_flags() >> 25) & 3;  // flags 33554432 / 67108864 / both: the measurement-only variants MODE 1 / 2 / 3 (hd 64, 256 tokens)
+  [[maybe_unused]] const int mode = (lfm_gemm_debug_flags() >> 25) & 3;  // flags 33554432 / 67108864 / both: the measurement-only variants MODE 1 / 2 / 3 (hd 64, 256 tokens)
+#ifdef LFM_MEASURE
   if (mode && hd == 64 && T == 256) {
     static bool set = false;
     if (!set) {
@@ -366,6 +367,7 @@ static int attention_launch(const half_t* Q, const half_t* K, const half_t* Vt, 
     LFM_CHECK_LAUNCH();
     return LFM_OK;
   }
+#endif
   if (T == 16) {
     const int items = batch * heads;
     if (hd == 64) hipLaunchKernelGGL(dit_attention_t16_kernel<64>, dim3((items + 3) / 4), dim3(64), 0, st, Q, K, Vt, O, D, heads, items, sl2);

@@ -25,8 +25,9 @@ extern "C" int lfm_set_option(int key, int value) {  // key 1 (LFM_OPT_FOLD_LN):
   }
   return LFM_ERR_ARG;
 }
-extern "C" int lfm_gemm_select(int which) {  // low 4 bits: kernel choice (0 auto, 1..5); bits 4+: ablation flags (measurement only)
-  if ((which & 15) > 5 || which < 0) return LFM_ERR_ARG;
+extern "C" int lfm_gemm_select(int which) {  // low 4 bits: kernel choice (0 auto, 1, 4, 5); bits 4+: ablation flags (measurement only)
+  const int k = which & 15;
+  if (which < 0 || !(k == 0 || k == 1 || k == 4 || k == 5)) return LFM_ERR_ARG;
   g_gemm_sel = which & 15;
   g_gemm_dbg = which >> 4;
   return LFM_OK;
@@ -660,23 +661,26 @@ extern "C" int lfm_gemm_f16(const void* A, long lda, const void* W, long ldw, vo
   ASrcRowMajor a{(const half_t*)A, lda, M, 0};
   switch (epilogue) {
     case 0:
-      if (g_gemm_sel == 3 && (g_gemm_dbg & 2) && K % G256Q_BK == 0)  // measurement: the time-stamped build of the quadrant-phased kernel
-        return (g_gemm_dbg & 1) ? launch_gemm256q_tn<ASrcRowMajor, EpiBiasF16, true, 0>(a, (const half_t*)W, ldw, M, N, K, EpiBiasF16{(half_t*)C, ldc, bias}, st)
-                                : launch_gemm256q_tn<ASrcRowMajor, EpiBiasF16, true, 1>(a, (const half_t*)W, ldw, M, N, K, EpiBiasF16{(half_t*)C, ldc, bias}, st);
+#ifdef LFM_MEASURE
       if (g_gemm_sel == 5 && (g_gemm_dbg & 2) && K % G256Q_BK == 0)  // measurement: the epilogue-stamped build of the 16x16x32 kernel
         return launch_gemm256h_tn<ASrcRowMajor, EpiBiasF16, true>(a, (const half_t*)W, ldw, M, N, K, EpiBiasF16{(half_t*)C, ldc, bias}, st);
+#endif
       return launch_gemm_auto(a, (const half_t*)W, ldw, M, N, K, EpiBiasF16{(half_t*)C, ldc, bias}, st);
     case 1:
       if (!bias) return LFM_ERR_ARG;
+#ifdef LFM_MEASURE
       if (g_gemm_sel == 5 && (g_gemm_dbg & 2) && K % G256Q_BK == 0)  // measurement: the epilogue-stamped build of the 16x16x32 kernel
         return launch_gemm256h_tn<ASrcRowMajor, EpiBiasGeluF16, true>(a, (const half_t*)W, ldw, M, N, K, EpiBiasGeluF16{(half_t*)C, ldc, bias}, st);
+#endif
       return launch_gemm_auto(a, (const half_t*)W, ldw, M, N, K, EpiBiasGeluF16{(half_t*)C, ldc, bias}, st);
     case 2: return launch_gemm_auto(a, (const half_t*)W, ldw, M, N, K, EpiBiasF32{(float*)C, ldc, bias}, st);
     case 3:
       if (!bias || !gate || tokens <= 0) return LFM_ERR_ARG;
+#ifdef LFM_MEASURE
       if (g_gemm_sel == 5 && (g_gemm_dbg & 2) && K % G256Q_BK == 0)
         return launch_gemm256h_tn<ASrcRowMajor, EpiGateResidF32, true>(a, (const half_t*)W, ldw, M, N, K,
                                                                        EpiGateResidF32{(float*)C, ldc, bias, gate, gate_stride, tokens}, st);
+#endif
       return launch_gemm_auto(a, (const half_t*)W, ldw, M, N, K, EpiGateResidF32{(float*)C, ldc, bias, gate, gate_stride, tokens}, st);
   }
   return LFM_ERR_ARG;
@@ -714,10 +718,12 @@ extern "C" int lfm_gemm_qkv_f16(const void* A, long lda, const void* W, long ldw
   if (!A || !W || !Q || !Kout || !Vt || !bias) return LFM_ERR_ARG;
   if ((lda % 8) || ((uintptr_t)A & 15)) return LFM_ERR_ALIGN;
   if (head_dim <= 0 || tokens <= 0 || (D % head_dim) || (head_dim % 8) || (tokens % 4) || (M % tokens)) return LFM_ERR_SHAPE;
+#ifdef LFM_MEASURE
   if (g_gemm_sel == 5 && (g_gemm_dbg & 2) && K % G256Q_BK == 0)
     return launch_gemm256h_tn<ASrcRowMajor, EpiQKV, true>(ASrcRowMajor{(const half_t*)A, lda, M, 0}, (const half_t*)W, ldw, M, 3 * D, K,
                                                           EpiQKV::make((half_t*)Q, (half_t*)Kout, (half_t*)Vt, bias, D, head_dim, tokens),
                                                           (hipStream_t)stream);
+#endif
   return launch_gemm_auto(ASrcRowMajor{(const half_t*)A, lda, M, 0}, (const half_t*)W, ldw, M, 3 * D, K,
                           EpiQKV::make((half_t*)Q, (half_t*)Kout, (half_t*)Vt, bias, D, head_dim, tokens), (hipStream_t)stream);
 }
@@ -799,7 +805,7 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
   // widths, patch 4 / 8 token counts with per-image conditioning, forced kernels) takes the separate ln_modulate launches below.
   const int tiles_p = D / 256;
   const bool fold = g_opt_fold_ln && (D % 256 == 0) && (M % 256 == 0) && (rows == 1 || T % 256 == 0) && (long)(M / 256) * tiles_p >= 192 &&
-                    g_gemm_sel == 0 && !(g_gemm_dbg & 1048576) && (H % 64 == 0) && s->depth >= 1;
+                    g_gemm_sel == 0 && (H % 64 == 0) && s->depth >= 1;
   const long uvs_q = rows == 1 ? 0 : 3 * D, uvs_f = rows == 1 ? 0 : H;
   int cen_cur = 0;
   if (fold) {

@@ -1,41 +1,18 @@
-// 256x256 "ping-pong" MFMA GEMM for gfx950 (v2):  C[m][n] = sum_k A[m][k] * W[n][k]  (+ fused epilogue).
-// Same operand / epilogue / A-source interfaces as gemm_kernel.h (v1); used for the large GEMMs of the hot path.
-//
-// 512 threads = 8 waves = two wave-GROUPS of four (one wave per SIMD each).  Group g owns rows g*128..+128 of the
-// tile, wave (g, wn) the 128x64 block at columns wn*64: 4(m) x 2(n) fragments of v_mfma_f32_32x32x16_f16 = 128
-// accumulator registers.  K is consumed in tiles of 32: per K-tile a wave runs a LOAD segment (12 ds_read_b128
-// fragments into registers + its share of a future tile's LDS-DMA) and a COMPUTE segment (16 MFMAs, nothing else).
-// The two groups run the same program shifted by ONE segment, separated by workgroup barriers:
-//
-//   slot      2t       2t+1     2t+2     2t+3
-//   group 0   L(t)     C(t)     L(t+1)   C(t+1)
-//   group 1   C(t-1)   L(t)     C(t)     L(t+1)
-//
-// so on every SIMD one wave is always in a COMPUTE segment while its partner loads: the matrix pipe sees a
-// back-to-back MFMA stream.
-//
-// LDS = a RING of four stages of (A 256x32 + W 256x32) fp16 = 4 x 32 KiB.  Measurement drove this shape: with two
-// 64-deep stages only ONE K-tile (64 KiB per CU) could be in flight and the loop ran at the DMA round-trip latency
-// (~1.9 us per 64-deep K-tile, equal with and without the MFMAs).  With the ring, K-tile t+3 is issued in L(t) and is
-// not needed before slot 2t+6: three tiles (96 KiB per CU) are always in flight and a load has ~6 segments to land.
-// Waits are COUNTED (s_waitcnt vmcnt(8): "everything except my last two tiles has landed"), never 0 in steady state.
-// Rows are 64 B, so the XOR swizzle key is (row>>2)&3 on 16-B chunks (a 256-B bank row = four tile rows); as in v1 it
-// is applied to the DMA source address and to the fragment read.  Every LOAD segment drains its own ds_reads
-// (lgkmcnt(0)) before its barrier, so a stage is never refilled while a read of it is in flight.
+// Shared pieces of the 256-row MFMA GEMM kernels (256x128 "two workgroups per CU", gemm256n_kernel.h; 256x256 quadrant-phased on
+// v_mfma_f32_16x16x32_f16, gemm256h_kernel.h): tile order, epilogue traits, the LDS-transposed row-major epilogue for the 32x32x16 accumulator
+// map, the barrier macro, the LDS image constants of the quadrant-phased ring.
+// History (DESIGN.md section 3 keeps the measurements): the first two 256x256 generations -- a four-stage ping-pong ring of 32-deep K-tiles
+// (round 1) and its quadrant-phased successor on 32x32x16 MFMAs with 64-deep K-tiles (round 1 / 2) -- were superseded by the 16x16x32 kernel
+// and removed in round 3; no reference shape dispatched to them (every K on the path is a multiple of 64).
 #pragma once
 #include "gemm_kernel.h"
 
-int lfm_gemm_selected();     // 0 auto, 1 force v1, 2 force v2 (set by lfm_gemm_select)
+int lfm_gemm_selected();     // 0 auto, 1 force the 128x128 kernel, 4 the 256x128 one, 5 the 256x256 one (set by lfm_gemm_select)
 int lfm_gemm_debug_flags();  // ablation switches, measurement only
 int lfm_gemm_prefers_v4(int M, int N, int K);  // shapes where the 256x128 two-workgroups-per-CU kernel measured faster than the 256x256 one
 
 #define G256_BM 256
 #define G256_BN 256
-#define G256_BK 32
-#define G256_NSTAGE 4
-#define G256_TILE_BYTES (256 * G256_BK * 2)     // one operand tile, 16 KiB
-#define G256_STAGE_BYTES (2 * G256_TILE_BYTES)  // A + W, 32 KiB
-#define G256_LDS_BYTES (G256_NSTAGE * G256_STAGE_BYTES)  // 128 KiB (the epilogue scratch reuses it)
 
 // Tile order.  Block b runs on XCD b%8: give each XCD a contiguous range of tile ids, and inside a range walk groups of
 // GM = 4 M-panels column-major, so the ~32 tiles an XCD runs concurrently form a 4 x 8 patch (12 operand panels in its
@@ -268,98 +245,6 @@ __device__ __forceinline__ void g256_epilogue(f32x16 (&acc)[4][2], char* smem, E
   g256_epilogue_rows<BN>(acc, smem, epi, m0, n0, M, N, g, wn, lane, wave, (dbg & 1024) != 0);  // flag 1024: the 8-byte-store epilogue (A/B)
 }
 
-template <class ASrc, class Epi>
-__global__ __launch_bounds__(512) void gemm256_tn_kernel(ASrc asrc, const half_t* __restrict__ W, long ldw, int M, int N, int K,
-                                                          int tiles_n, Epi epi, long bsA, long bsW, long bsC, int dbg) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g = wave >> 2, wn = wave & 3;
-  const bool dbg_noload = dbg & 1, dbg_nomfma = dbg & 2;  // ablation switches (measurement only)
-
-  int tile_m, tile_n;
-  g256_tile_order(blockIdx.x, gridDim.x, tiles_n, dbg, tile_m, tile_n);
-  const int m0 = tile_m * G256_BM, n0 = tile_n * G256_BN;
-  const int bz = blockIdx.y;
-  asrc.init(bz, bsA);
-  W += (long)bz * bsW;
-
-  // ---- DMA sources: 2 passes of 128 rows per operand, 4 lanes per 64-B row
-  typename ASrc::Row arow[2];
-  const half_t* wrow[2];
-  int cswz[2];
-#pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const int r = p * 128 + (tid >> 2);
-    arow[p] = asrc.row(m0 + r);
-    const int n = n0 + r;
-    wrow[p] = W + (long)(n < N ? n : N - 1) * ldw;
-    cswz[p] = ((tid & 3) ^ ((r >> 2) & 3)) * 8;
-  }
-  const int nk = K / G256_BK;
-
-  // 4 DMAs per thread per K-tile (2 A + 2 W)
-  auto issue_tile = [&](int kt) {
-    char* sA = smem + (kt & (G256_NSTAGE - 1)) * G256_STAGE_BYTES;
-    char* sW = sA + G256_TILE_BYTES;
-    const int k0 = kt * G256_BK;
-    asrc.begin_tile(kt, G256_BK);
-    if (dbg_noload && kt > 0) return;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      glds16(asrc.ptr(arow[p], cswz[p]), sA + (p * 512 + wave * 64) * 16);
-      glds16(wrow[p] + k0 + cswz[p], sW + (p * 512 + wave * 64) * 16);
-    }
-  };
-
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  // fragment read offsets (bytes inside an operand tile); chunk c of row r sits at c ^ ((r>>2)&3)
-  int a_off[4], a_key[4], w_off[2], w_key[2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = g * 128 + i * 32 + (lane & 31);
-    a_off[i] = r * 64;
-    a_key[i] = (r >> 2) & 3;
-  }
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int r = wn * 64 + j * 32 + (lane & 31);
-    w_off[j] = r * 64;
-    w_key[j] = (r >> 2) & 3;
-  }
-  const int chalf = lane >> 5;
-
-  half8_t af[4][2], wf[2][2];  // [frag][k16 step]
-
-  auto load_frags = [&](int kt) {
-    const char* sA = smem + (kt & (G256_NSTAGE - 1)) * G256_STAGE_BYTES;
-    const char* sW = sA + G256_TILE_BYTES;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) wf[j][ks] = *(const half8_t*)(sW + w_off[j] + (((ks * 2 + chalf) ^ w_key[j]) << 4));
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) af[i][ks] = *(const half8_t*)(sA + a_off[i] + (((ks * 2 + chalf) ^ a_key[i]) << 4));
-  };
-  auto compute = [&]() {
-    if (dbg_nomfma) return;
-    if (!(dbg & 8)) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j][ks], af[i][ks], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-  };
 #define G256_BARRIER()                  \
   do {                                  \
     asm volatile("" ::: "memory");      \
@@ -367,68 +252,25 @@ __global__ __launch_bounds__(512) void gemm256_tn_kernel(ASrc asrc, const half_t
     asm volatile("" ::: "memory");      \
     __builtin_amdgcn_sched_barrier(0);  \
   } while (0)
-#define G256_LGKM0()                                    \
-  do {                                                  \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
-    __builtin_amdgcn_sched_barrier(0);                  \
-  } while (0)
-  // "K-tile kt has landed" for this wave's share: every tile up to min(kt+2, nk-1) has been issued, 4 DMAs each, in order
-  auto wait_tile = [&](int kt) {
-    const int newer = (nk - 1 - kt) < 2 ? (nk - 1 - kt) : 2;
-    if (newer >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (newer == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  };
 
-  // ---- prologue: K-tiles 0..2 in flight, tile 0 landed
-  issue_tile(0);
-  if (nk > 1) issue_tile(1);
-  if (nk > 2) issue_tile(2);
-  wait_tile(0);
-  G256_BARRIER();
+// ---- LDS image of the quadrant-phased 256x256 kernel: 64-deep K-tiles = 128-byte rows, staged in four 16-KiB pieces (A.sub0 / A.sub1 = rows
+// {0..63} / {64..127} of both groups' 128-row halves, B.sub0 / B.sub1 = columns {0..31} / {32..63} of every wave's 64-column block); two K-tiles
+// = 128 KiB.  Chunk c of row r sits at c ^ ((r >> 1) & 7), applied to the DMA source address and to the fragment read.
+#define G256Q_BK 64
+#define G256Q_PIECE 16384
+#define G256Q_SLOT_A0 0
+#define G256Q_SLOT_B0 (1 * G256Q_PIECE)
+#define G256Q_SLOT_B1 (2 * G256Q_PIECE)
+#define G256Q_SLOT_A1 (3 * G256Q_PIECE)
+#define G256Q_BUF_BYTES (4 * G256Q_PIECE)
+#define G256Q_LDS_BYTES (2 * G256Q_BUF_BYTES)
 
-  if (g == 0) {
-    for (int t = 0; t < nk; ++t) {
-      if ((dbg & 16) && t + 3 < nk) issue_tile(t + 3);
-      load_frags(t);  // slot 2t: L(t)
-      if (!(dbg & 16) && t + 3 < nk) issue_tile(t + 3);
-      G256_LGKM0();
-      G256_BARRIER();
-      compute();  // slot 2t+1: C(t)
-      if (t + 1 < nk) wait_tile(t + 1);
-      G256_BARRIER();  // (after the last tile: every stage read is finished -> the epilogue may reuse the LDS)
-    }
-  } else {
-    G256_BARRIER();  // slot 0: group 1 idles, then stays one segment behind
-    for (int t = 0; t < nk; ++t) {
-      if ((dbg & 16) && t + 3 < nk) issue_tile(t + 3);
-      load_frags(t);  // slot 2t+1: L(t)
-      if (!(dbg & 16) && t + 3 < nk) issue_tile(t + 3);
-      G256_LGKM0();
-      if (t + 1 < nk) wait_tile(t + 1);
-      G256_BARRIER();
-      compute();  // slot 2t+2: C(t)
-      if (t + 1 < nk) G256_BARRIER();
-    }
-  }
+// Measurement only (lfm_gemm_select flag 2 with kernel 5): s_memtime stamps of the epilogue, parked here and read back with lfm_gemm_trace_read().
+// One copy per translation unit; dit.hip's is read back.
+#define G256Q_TRACE_MAX 2048
+static __device__ unsigned long long g256q_trace[2][G256Q_TRACE_MAX];
 
-  g256_epilogue(acc, smem, epi, m0, n0, M, N, g, wn, lane, wave, bz, bsC, dbg);
-}
-
-template <class ASrc, class Epi>
-static inline int launch_gemm256_tn(const ASrc& asrc, const half_t* W, long ldw, int M, int N, int K, const Epi& epi, hipStream_t stream,
-                                    int batch = 1, long bsA = 0, long bsW = 0, long bsC = 0) {
-  if (M <= 0 || N <= 0 || K <= 0 || (K % G256_BK) != 0 || (N % 4) != 0) return LFM_ERR_SHAPE;
-  if ((ldw % 8) != 0 || ((uintptr_t)W & 15)) return LFM_ERR_ALIGN;
-  const int tm = cdiv(M, G256_BM), tn = cdiv(N, G256_BN);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm256_tn_kernel<ASrc, Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES) != hipSuccess)
-      return LFM_ERR_LAUNCH;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((gemm256_tn_kernel<ASrc, Epi>), dim3(tm * tn, batch), dim3(512), G256_LDS_BYTES, stream, asrc, W, ldw, M, N, K, tn, epi,
-                     bsA, bsW, bsC, lfm_gemm_selected() == 2 ? lfm_gemm_debug_flags() : (lfm_gemm_debug_flags() & 4));  // other flags belong to v3
-  LFM_CHECK_LAUNCH();
-  return LFM_OK;
-}
+template <int V>
+struct g256q_ic {
+  static constexpr int value = V;
+};

@@ -13,7 +13,7 @@
 //                      C[m = 16 i + (l & 15)][n = 16 j + 4 (l >> 4) + r], r = 0..3: four consecutive n per lane as before;
 //   epilogue           the same LDS-transposed row-major hand-over (shared Epi interface), with the scratch filled from the new map.
 #pragma once
-#include "gemm256q_kernel.h"
+#include "gemm256n_kernel.h"
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(512) void gemm256h_tn_kernel(ASrc asrc, const half_
     constexpr int PH = decltype(PHC)::value;
     constexpr bool SW = decltype(SWC)::value != 0;
     constexpr int I0 = (PH >= 2) ? 4 : 0, J0 = (PH == 1 || PH == 2) ? 2 : 0;
-    if (!(dbg & 8)) __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -643,11 +643,13 @@ static inline int launch_gemm256h_tn(const ASrc& asrc, const half_t* W, long ldw
   if ((ldw % 8) != 0 || ((uintptr_t)W & 15)) return LFM_ERR_ALIGN;
   const int tm = cdiv(M, G256_BM), tn = cdiv(N, G256_BN);
   constexpr int LDS = G256Q_LDS_BYTES + (epi_has_rowstat<Epi>::value ? 2048 : 0);  // + rs[256][2] of the folded LayerNorm consumers
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_set = 0;  // one bit per device: the attribute is per (function, device)
+  int devid = 0;
+  (void)hipGetDevice(&devid);
+  if (!((attr_set >> (devid & 63)) & 1)) {
     if (hipFuncSetAttribute((const void*)gemm256h_tn_kernel<ASrc, Epi, TRACE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return LFM_ERR_LAUNCH;
-    attr_set = true;
+    attr_set |= 1ull << (devid & 63);
   }
   hipLaunchKernelGGL((gemm256h_tn_kernel<ASrc, Epi, TRACE>), dim3(tm * tn, batch), dim3(512), LDS, stream, asrc, W, ldw, M, N, K, tn, epi, bsA,
                      bsW, bsC, lfm_gemm_debug_flags());

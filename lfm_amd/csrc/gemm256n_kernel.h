@@ -23,7 +23,7 @@
 //   WAR  stage (t+2)%3 held tile t-1, whose last reads were retired (lgkmcnt(0)) before its MFMAs, i.e. before the barrier of
 //        iteration t that precedes the DMA issue.
 #pragma once
-#include "gemm256_kernel.h"
+#include "gemm256_common.h"
 
 #define G256N_BN 128
 #define G256N_BK 32

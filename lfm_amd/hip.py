@@ -173,7 +173,7 @@ def require_gpu(t, what):
 
 # ----------------------------------------------------------------------------- thin op wrappers (used by tests)
 def gemm_select(which):
-    """Force a GEMM kernel (0 auto, 1 128x128, 2 ping-pong, 3 quadrant-phased) | ablation flags << 4; A/B measurements
+    """Force a GEMM kernel (0 auto, 1 128x128, 4 256x128, 5 256x256) | ablation flags << 4; A/B measurements
     and parity tests only.  Raises on a value the library rejects (a silently ignored selection invalidates an A/B)."""
     check(lib().lfm_gemm_select(int(which)), "lfm_gemm_select")
 

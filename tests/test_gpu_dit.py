@@ -79,13 +79,16 @@ def _gemm_case(M, N, K, epi):
                                    (512, 256, 192), (256, 512, 320), (768, 512, 576), (512, 128, 96), (384, 132, 160), (256, 128, 32),
                                    (65536, 128, 1152)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
-@pytest.mark.parametrize("kernel", [2, 3, 3 | (1 << 4), 4, 4 | (1024 << 4), 5, 5 | (1024 << 4)])
+@pytest.mark.parametrize("kernel", [4, 4 | (1024 << 4), 5, 5 | (1024 << 4)])
 def test_gemm256_kernels(dev, M, N, K, epi, kernel):
-    """Same checks with a 256-row kernel forced (lfm_gemm_select: 2 = ping-pong, 3 = quadrant-phased, 3 | 1<<4 = its two-barrier schedule, 4 = the
-    256x128 two-workgroups-per-CU kernel, 4 | 1024<<4 = with the 8-byte-store epilogue, 5 = the quadrant-phased kernel on 16x16x32 MFMAs (the default for chip-filling shapes); K covers 1, 2, 3, 5, odd and even numbers of 64- and
-    32-deep K-tiles, i.e. every prologue / tail path; N = 128 / 132 the narrow shapes); repeated launches screen for races."""
+    """Same checks with a 256-row kernel forced (lfm_gemm_select: 4 = the 256x128 two-workgroups-per-CU kernel, 4 | 1024<<4 = with the 8-byte-store
+    epilogue, 5 = the quadrant-phased 256x256 kernel on 16x16x32 MFMAs, the default for chip-filling shapes); K covers 1, 2, 3, 5, odd and even
+    numbers of 64-deep (and, for the 256x128 kernel, 32-deep) K-tiles, i.e. every prologue / tail path; N = 128 / 132 the narrow shapes; repeated
+    launches screen for races."""
     if (kernel & 15) != 4 and M > 8192 and N == 128:
         pytest.skip("the narrow-N convolution shape is the 256x128 kernel's")
+    if (kernel & 15) == 5 and K % 64:
+        pytest.skip("64-deep K-tiles: every K on the reference path is a multiple of 64 (32-deep tails are the 256x128 kernel's)")
     from lfm_amd import hip
 
     A, W, bias, X, gate, ref, tokens = _gemm_case(M, N, K, epi)
@@ -106,7 +109,7 @@ def test_gemm256_kernels(dev, M, N, K, epi, kernel):
         assert torch.equal(o, outs[0])  # deterministic across launches (no data race on the LDS stages)
 
 
-@pytest.mark.parametrize("kernel", [2, 3, 4, 5])
+@pytest.mark.parametrize("kernel", [4, 5])
 def test_gemm256_detects_transpose(dev, kernel):
     from lfm_amd import hip
 
@@ -130,7 +133,7 @@ def _qkv_case(batch, tokens, D):
     return A, W, bias, A.float() @ W.float().t() + bias
 
 
-@pytest.mark.parametrize("kernel", [1, 2, 3, 3 | (1 << 4), 3 | (1024 << 4), 4, 5, 5 | (1024 << 4)])
+@pytest.mark.parametrize("kernel", [1, 4, 5, 5 | (1024 << 4)])
 @pytest.mark.parametrize("batch,tokens,D,hd", [(3, 256, 384, 64), (8, 64, 512, 64), (2, 256, 1024, 64), (2, 256, 1152, 72), (3, 64, 576, 72)])
 def test_gemm_qkv_split(dev, batch, tokens, D, hd, kernel):
     """Fused QKV projection: Q, K row-major, V transposed per head (timm Attention's qkv + reshape + permute, DiT.py:120), with
@@ -346,12 +349,12 @@ def _every_kernel_case(name, batch):
     return m, x, y, t, dit_ref.dit_forward(sd, cfg, t, x, y)
 
 
-@pytest.mark.parametrize("kernel", [1, 2, 3, 3 | (1 << 4), 4, 5])
+@pytest.mark.parametrize("kernel", [1, 4, 5])
 @pytest.mark.parametrize("name,batch", [("DiT-S/2", 5), ("DiT-B/2", 3), ("DiT-XL/2", 2)])
 def test_dit_with_every_gemm_kernel(dev, name, batch, kernel):
     """The same forward with each GEMM kernel forced (auto picks by size, so small test batches would never reach the 256x256
     kernels through the model): covers the fused epilogues in situ, in particular the QKV split with V written transposed
-    (fragment-direct in v1/v2, operand-swapped tiles + transposed epilogue in v3)."""
+    (fragment-direct in the 128x128 kernel, operand-swapped tiles + transposed epilogue in the 256-row ones)."""
     from lfm_amd import hip
     from lfm_amd.models import DiT_models
 

@@ -99,21 +99,43 @@ def test_inpainting_batch_vs_oracle():
     assert torch.equal(out.cpu()[keep], i01[keep])  # pixels outside the hole are the input image, exactly
 
 
-def test_semantic_synthesis_conditioning_shapes():
+def test_semantic_synthesis_batch_vs_oracle():
+    """One batch of the reference loop (downstream_tasks/test_flow_latent_semantic_syn.py:130-140) at 64x64 against the CPU oracle: one-hot label map ->
+    SpatialRescaler (three bilinear x0.5 stages + the 1x1 channel mapper, restated below on the CPU with the same weights) -> 8-channel origin-ADM
+    UNet flow (oracle: unet_ref on the concatenated state), 2 Euler steps -> VAE decode."""
+    from lfm_amd.autoencoder import AutoencoderKL
     from lfm_amd.downstream_tasks import WrapperCondFlow
     from lfm_amd.downstream_tasks.test_flow_latent_semantic_syn import SpatialRescaler, synthesize_batch
-    from lfm_amd.autoencoder import AutoencoderKL
     from lfm_amd.models import get_flow_model
-    from lfm_amd.test_flow_latent import dezero_
 
     dev = torch.device("cuda:0")
     args = Namespace(image_size=64, num_in_channels=8, num_out_channels=4, nf=64, num_res_blocks=1, attn_resolutions=(2,), dropout=0.0,
                      ch_mult=(1, 2), num_classes=None, num_heads=2, num_head_channels=-1, num_head_upsample=-1, layout=False,
                      scale_factor=0.18215, method="euler", step_size=0.5, perturb=False, compute_fid=True, atol=1e-5, rtol=1e-5)
-    torch.manual_seed(0)
-    m = dezero_(get_flow_model(args)).to(dev).eval()
-    vae = AutoencoderKL.from_random(seed=0).to(dev)
-    cs = SpatialRescaler(n_stages=3, in_channels=19, out_channels=4, multiplier=0.5).to(dev)
-    seg = torch.randint(0, 19, (2, 64, 64), generator=torch.Generator().manual_seed(3)).to(dev)
-    img, lat = synthesize_batch(WrapperCondFlow(m), vae, cs, seg, 19, args, generator=torch.Generator(dev).manual_seed(4))
-    assert img.shape == (2, 3, 64, 64) and lat.shape == (2, 4, 8, 8) and bool(torch.isfinite(img).all())
+    cfg = dict(image_size=8, in_channels=8, model_channels=64, out_channels=4, num_res_blocks=1, attention_resolutions=(2,), channel_mult=(1, 2),
+               num_classes=None, num_heads=2, num_head_channels=-1, num_heads_upsample=-1)
+    usd = unet_ref.make_unet_state(cfg, seed=9)
+    m = get_flow_model(args)
+    m.load_state_dict(usd, strict=True)
+    m = m.to(dev).eval()
+    vsd = vae_ref.make_vae_state(seed=3)
+    vae = AutoencoderKL()
+    vae.load_state_dict(vsd, strict=True)
+    vae = vae.to(dev)
+    torch.manual_seed(5)
+    cs = SpatialRescaler(n_stages=3, in_channels=19, out_channels=4, multiplier=0.5)
+    wmap = cs.channel_mapper.weight.detach().clone()
+    seg = torch.randint(0, 19, (2, 64, 64), generator=torch.Generator().manual_seed(3))
+    z0 = torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(4))
+    img, lat = synthesize_batch(WrapperCondFlow(m), vae, cs.to(dev), seg.to(dev), 19, args, z_0=z0.to(dev))
+    # oracle
+    c = F.one_hot(seg, 19).permute(0, 3, 1, 2).float()
+    for _ in range(3):
+        c = F.interpolate(c, scale_factor=0.5, mode="bilinear")
+    cond = F.conv2d(c, wmap)
+    ref_lat = ode_ref.odeint(lambda t, x: unet_ref.unet_forward(usd, cfg, t, torch.cat([x, cond], 1)), z0, torch.tensor([1.0, 0.0]), method="euler",
+                             options={"step_size": 0.5})[-1]
+    ref_img = (vae_ref.vae_decode(vsd, ref_lat / args.scale_factor) + 1) / 2
+    assert img.shape == (2, 3, 64, 64) and lat.shape == (2, 4, 8, 8)
+    assert rel_l2(lat, ref_lat) < 3e-3
+    assert rel_l2(img, ref_img) < 1e-2
