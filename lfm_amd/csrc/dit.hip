@@ -460,6 +460,97 @@ __global__ __launch_bounds__(256) void final_layer_kernel(const float* __restric
   }
 }
 
+// Round 3: the same layer as a skinny MFMA GEMM.  final_layer_kernel above keeps four whole rows per wave in registers (434+ VGPRs: one wave per SIMD)
+// and reduces 64 partial dot products through 63 ds_bpermute exchanges: 64 us for 67 MB = 1.0 TB/s.  Here one wave owns SIXTEEN token rows as ONE
+// v_mfma_f32_16x16x32_f16 row tile and N = p*p*C / 16 column tiles; K = D is walked in 32-deep steps with the operands built in registers in the
+// MFMA fragment layout (lane l: row l & 15, eight consecutive k at 8 (l >> 4)), so
+//   * the LayerNorm statistics are in-lane sums plus two lane exchanges (the four lanes l, l^16, l^32, l^48 share a row);
+//   * X is streamed twice (statistics, then operands): the second pass hits the L2 (64 KiB per wave), HBM sees the 67 MB once;
+//   * fp32 fidelity on an fp16 matrix core: activation and weight are each split into fp16 hi + lo and three MFMAs (hi*hi + lo*hi + hi*lo)
+//     accumulate in fp32 -- the dropped lo*lo term is 2^-22 relative, i.e. the result is the fp32 dot product to rounding, as before.
+// Under CFG a tile holds eight conditional rows and their eight unconditional twins, which land in lanes l and l ^ 32 of the result.
+template <bool CFG, int NT>
+__global__ __launch_bounds__(256) void final_layer_mfma_kernel(const float* __restrict__ X, int M, int D, int tokens, const float* __restrict__ shift,
+                                                               const float* __restrict__ scale, long mod_stride, const float* __restrict__ Wf,
+                                                               const float* __restrict__ bf, int C, int R, int p, float cfg_scale, float* out,
+                                                               const float* base, const float* __restrict__ dt_ptr) {
+  const int lane = threadIdx.x & 63, a = lane & 15, q = lane >> 4;
+  const long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int Mh = CFG ? M / 2 : M;
+  const long ntiles = CFG ? Mh / 8 : M / 16;
+  if (tile >= ntiles) return;
+  const long m = CFG ? tile * 8 + (a & 7) + (a >> 3) * (long)Mh : tile * 16 + a;  // this lane's operand row
+  const float* xr = X + m * D + 8 * q;
+  const int nks = D >> 5;
+  // ---- pass 1: shifted one-pass statistics (shift = the row's first element)
+  const float c0 = X[m * D];
+  float sx = 0.f, sq = 0.f;
+  for (int ks = 0; ks < nks; ++ks) {
+    const f32x4 x0 = *(const f32x4*)(xr + 32 * ks) - c0, x1 = *(const f32x4*)(xr + 32 * ks + 4) - c0;
+    sx += (x0.x + x0.y) + (x0.z + x0.w) + (x1.x + x1.y) + (x1.z + x1.w);
+    sq += (x0.x * x0.x + x0.y * x0.y) + (x0.z * x0.z + x0.w * x0.w) + (x1.x * x1.x + x1.y * x1.y) + (x1.z * x1.z + x1.w * x1.w);
+  }
+  sx += __shfl_xor(sx, 16, 64);
+  sq += __shfl_xor(sq, 16, 64);
+  sx += __shfl_xor(sx, 32, 64);
+  sq += __shfl_xor(sq, 32, 64);
+  const float dl = sx / (float)D, mean = c0 + dl;
+  const float rstd = rsqrtf(fmaxf(sq / (float)D - dl * dl, 0.f) + 1e-6f);
+  const long mo = (m / tokens) * mod_stride + 8 * q;
+  // ---- pass 2: operands + MFMAs
+  f32x4_t acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  auto split = [](const f32x4& lo4, const f32x4& hi4, half8_t& h, half8_t& l) {
+    const float v[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      h[e] = (half_t)v[e];
+      l[e] = (half_t)(v[e] - (float)h[e]);
+    }
+  };
+  for (int ks = 0; ks < nks; ++ks) {
+    const f32x4 x0 = *(const f32x4*)(xr + 32 * ks), x1 = *(const f32x4*)(xr + 32 * ks + 4);
+    const f32x4 s0 = *(const f32x4*)(scale + mo + 32 * ks), s1 = *(const f32x4*)(scale + mo + 32 * ks + 4);
+    const f32x4 h0 = *(const f32x4*)(shift + mo + 32 * ks), h1 = *(const f32x4*)(shift + mo + 32 * ks + 4);
+    const f32x4 a0 = (x0 - mean) * rstd * (1.0f + s0) + h0, a1 = (x1 - mean) * rstd * (1.0f + s1) + h1;
+    half8_t ah, al;
+    split(a0, a1, ah, al);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float* wr = Wf + (long)(t * 16 + a) * D + 32 * ks + 8 * q;  // output column t * 16 + (lane & 15), same k slice
+      half8_t wh, wl;
+      split(*(const f32x4*)wr, *(const f32x4*)(wr + 4), wh, wl);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl, acc[t], 0, 0, 0);
+    }
+  }
+  // ---- lane holds out[row 4 q + r][column o = t * 16 + (lane & 15)], r = 0..3
+  const float dt = base ? *dt_ptr : 0.f;
+  const int grid = R / p;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int o = t * 16 + a;
+    const float bo = bf[o];
+    const int pp = o / (p * C), qq = (o / C) % p, c = o % C;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * q + r;
+      float val = acc[t][r] + bo;
+      if (CFG) {  // rows 0..7 conditional, 8..15 their unconditional twins: lane ^ 32 holds the twin's value
+        const float other = xhalf(val);
+        const float cond = row < 8 ? val : other, uncond = row < 8 ? other : val;
+        val = uncond + cfg_scale * (cond - uncond);
+      }
+      const long mr = CFG ? tile * 8 + (row & 7) + (row >> 3) * (long)Mh : tile * 16 + row;
+      const int n = (int)(mr / tokens), tok = (int)(mr % tokens);
+      const long off = (((long)n * C + c) * R + (tok / grid) * p + pp) * R + (tok % grid) * p + qq;
+      out[off] = base ? base[off] + dt * val : val;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ solver helpers
 __global__ void grid_advance_kernel(const float* ts, const float* dts, int* step, float* t_cur, float* t_next, float* dt_cur) {
   const int s = *step;
@@ -888,7 +979,23 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
   }
   const float* fmod = ws.mod + (long)s->depth * 6 * D;
   const int Mh = cfg ? M / 2 : M;
-  if (cfg)
+  // skinny MFMA GEMM (16 rows per wave) when the shape allows it: whole 16-row tiles inside one image half, 16-column output tiles, D % 32 == 0
+  const int NO = s->in_ch * s->patch * s->patch;
+  const bool fin_mfma = (NO == 16 || NO == 64) && (D % 32 == 0) && (T % 16 == 0) && !(g_gemm_dbg & 1048576);  // flag 1048576: the round-1 kernel (A/B)
+  if (fin_mfma) {
+    const long ntiles = cfg ? Mh / 8 : M / 16;
+#define FIN_LAUNCH(CF, NTT)                                                                                                                 \
+  hipLaunchKernelGGL((final_layer_mfma_kernel<CF, NTT>), dim3(cdiv(ntiles, 4)), dim3(256), 0, st, ws.X, M, D, T, fmod, fmod + D, mstride,   \
+                     w->final_w, w->final_b, s->in_ch, s->res, s->patch, cfg ? c->cfg_scale : 1.0f, c->out, c->axpy_base, c->axpy_dt)
+    if (cfg) {
+      if (NO == 16) FIN_LAUNCH(true, 1);
+      else FIN_LAUNCH(true, 4);
+    } else {
+      if (NO == 16) FIN_LAUNCH(false, 1);
+      else FIN_LAUNCH(false, 4);
+    }
+#undef FIN_LAUNCH
+  } else if (cfg)
     hipLaunchKernelGGL(final_layer_kernel<true>, dim3(cdiv(Mh, 8)), dim3(256), 0, st, ws.X, M, D, T, fmod, fmod + D, mstride, w->final_w,
                        w->final_b, s->in_ch, s->res, s->patch, c->cfg_scale, c->out, c->axpy_base, c->axpy_dt);
   else
