@@ -138,6 +138,110 @@ __global__ __launch_bounds__(320) void patch_embed_kernel(const float* __restric
   }
 }
 
+// Round 3: the patch embedding of the */2 models (K = p*p*C = 16) on v_mfma_f32_16x16x16_f16, fused with the FIRST LayerNorm of the forward.
+// patch_embed_kernel above spends its time on 256 LDS broadcast reads and 1024 scalar FMAs per thread (55 us for 67 MB); the LayerNorm after it
+// re-read the 67 MB it had just written (ln_center_mod_kernel / ln_modulate, 17-20 us).  Here a block of D / 256 waves walks 16-token tiles; wave w
+// owns channels 256 w .. + 255 with its weight fragments (fp16 hi + lo, three MFMAs per tile pair = the fp32 dot product to 2^-22) and bias rows
+// resident in registers.  The W rows of a 32-channel pair are fed through the permutation n = 8 (a >> 2) + 4 e + (a & 3) (a = fragment row, e = which
+// MFMA of the pair), so a lane ends up with EIGHT CONSECUTIVE channels of one token: X leaves as 2 x 16-byte stores (four lanes = one 128-byte
+// line), the fp16 operand of the first qkv GEMM as one.  The row statistics are in-lane sums + two lane exchanges + one LDS hand-over between the
+// waves; the variance is the exact two-pass one (the values stay in registers).  With A == nullptr only X is written.
+__global__ __launch_bounds__(320) void patch_embed_ln_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                             const float* __restrict__ pos, float* __restrict__ X, int M, int xmod, int R, int D,
+                                                             int tiles_per_block, half_t* __restrict__ A, const float* __restrict__ scale,
+                                                             long mod_stride, float* __restrict__ part, int tiles_p, float* __restrict__ cen) {
+  typedef half_t half4v __attribute__((ext_vector_type(4)));
+  __shared__ float red[2][5][16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, a = lane & 15, q = lane >> 4;
+  const int grid = R >> 1, T = grid * grid;
+  // resident weight fragments and bias rows of this wave's 8 channel pairs
+  half4v wh[8][2], wl[8][2];
+  f32x4 bias[8][2];
+#pragma unroll
+  for (int pr = 0; pr < 8; ++pr)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int n = 256 * wv + 32 * pr + 8 * (a >> 2) + 4 * e + (a & 3);  // the W row this lane feeds as fragment row a
+      const f32x4 wf = *(const f32x4*)(w + (long)n * 16 + 4 * q);
+      const float wa[4] = {wf.x, wf.y, wf.z, wf.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        wh[pr][e][i] = (half_t)wa[i];
+        wl[pr][e][i] = (half_t)(wa[i] - (float)wh[pr][e][i]);
+      }
+      bias[pr][e] = *(const f32x4*)(b + 256 * wv + 32 * pr + 8 * q + 4 * e);  // the channels this lane OWNS in the result
+    }
+  for (int it = 0; it < tiles_per_block; ++it) {
+    const long tile = (long)blockIdx.x * tiles_per_block + it;
+    if (tile * 16 >= M) break;  // (whole block)
+    const long m = tile * 16 + a < M ? tile * 16 + a : M - 1;
+    const int tok = (int)(m % T), n_img = (int)(m / T) % xmod;
+    // the token's patch values k = 4 q .. 4 q + 3 = channel q, 2 x 2 pixels
+    const float* xp = x + (((long)n_img * 4 + q) * R + (tok / grid) * 2) * R + (tok % grid) * 2;
+    const f32x2 r0 = *(const f32x2*)xp, r1 = *(const f32x2*)(xp + R);
+    const float xa[4] = {r0.x, r0.y, r1.x, r1.y};
+    half4v xh, xl;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      xh[i] = (half_t)xa[i];
+      xl[i] = (half_t)(xa[i] - (float)xh[i]);
+    }
+    f32x4 val[8][2];
+    float sx = 0.f;
+    const float* prow = pos + (long)tok * D + 256 * wv + 8 * q;
+    float* xrow = X + m * D + 256 * wv + 8 * q;
+    const bool live = tile * 16 + a < M;
+#pragma unroll
+    for (int pr = 0; pr < 8; ++pr)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x16f16(wh[pr][e], xh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x16f16(wl[pr][e], xh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x16f16(wh[pr][e], xl, acc, 0, 0, 0);
+        const f32x4 v = (f32x4){acc[0], acc[1], acc[2], acc[3]} + bias[pr][e] + *(const f32x4*)(prow + 32 * pr + 4 * e);
+        val[pr][e] = v;
+        if (live) *(f32x4*)(xrow + 32 * pr + 4 * e) = v;
+        sx += (v.x + v.y) + (v.z + v.w);
+      }
+    if (!A) continue;
+    sx += __shfl_xor(sx, 16, 64);
+    sx += __shfl_xor(sx, 32, 64);
+    if (q == 0) red[0][wv][a] = sx;
+    __syncthreads();
+    float sum = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) sum += red[0][i][a];
+    const float mean = sum / (float)D;
+    const float* srow = scale + (m / T) * mod_stride + 256 * wv + 8 * q;
+    half_t* arow = A + m * D + 256 * wv + 8 * q;
+    float sq = 0.f;
+#pragma unroll
+    for (int pr = 0; pr < 8; ++pr) {
+      const f32x4 d0 = val[pr][0] - mean, d1 = val[pr][1] - mean;
+      sq += (d0.x * d0.x + d0.y * d0.y) + (d0.z * d0.z + d0.w * d0.w) + (d1.x * d1.x + d1.y * d1.y) + (d1.z * d1.z + d1.w * d1.w);
+      const f32x4 o0 = d0 * (1.0f + *(const f32x4*)(srow + 32 * pr)), o1 = d1 * (1.0f + *(const f32x4*)(srow + 32 * pr + 4));
+      const half8_t h = {(half_t)o0.x, (half_t)o0.y, (half_t)o0.z, (half_t)o0.w, (half_t)o1.x, (half_t)o1.y, (half_t)o1.z, (half_t)o1.w};
+      if (live) *(half8_t*)(arow + 32 * pr) = h;
+    }
+    sq += __shfl_xor(sq, 16, 64);
+    sq += __shfl_xor(sq, 32, 64);
+    if (q == 0) red[1][wv][a] = sq;
+    __syncthreads();
+    if (wv == 0 && q == 0 && live) {
+      float qs = 0.f;
+      for (int i = 0; i < (int)(blockDim.x >> 6); ++i) qs += red[1][i][a];
+      float* pp = part + m * tiles_p * 2;
+      pp[0] = sum;
+      pp[1] = qs;
+      for (int t2 = 1; t2 < tiles_p; ++t2) {
+        pp[2 * t2] = 0.f;
+        pp[2 * t2 + 1] = 0.f;
+      }
+      cen[m] = mean;
+    }
+  }
+}
+
 // Patch sizes with p*p*C > 16 (DiT-*/4, */8): the patch embedding is a real GEMM (K = p*p*C = 64 / 256).  This kernel gathers the patches
 // into the fp16 A operand Ap[m][k], k = (c, pp, q) as x_embedder.proj.weight flattens, and pre-fills the residual stream with the
 // position embedding; the GEMM then adds  1 * (patches W^T + bias)  through the gated-residual epilogue (gate = a row of ones).
@@ -874,7 +978,17 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
   if (rc) return rc;
 
   const int KK = s->in_ch * s->patch * s->patch;
-  if (KK <= PE_MAXK) {
+  // folded LayerNorm-modulate: decided here because the */2 patch embedding can already play the first producer (see below)
+  const int tiles_p = D / 256;
+  const bool fold = g_opt_fold_ln && (D % 256 == 0) && (M % 256 == 0) && (rows == 1 || T % 256 == 0) && (long)(M / 256) * tiles_p >= 192 &&
+                    g_gemm_sel == 0 && (H % 64 == 0) && s->depth >= 1;
+  const bool pe_mfma = s->patch == 2 && s->in_ch == 4 && (D % 256 == 0) && D <= 1280 && (s->res % 2 == 0) && !(g_gemm_dbg & 2097152);  // flag: round-1 kernel
+  if (pe_mfma) {
+    const int tpb = 2;
+    hipLaunchKernelGGL(patch_embed_ln_kernel, dim3(cdiv(M, 16 * tpb)), dim3(64 * (D / 256)), 0, st, c->x, w->patch_w, w->patch_b, w->pos_embed, ws.X,
+                       M, cfg ? B / 2 : B, s->res, D, tpb, fold ? ws.A : (half_t*)nullptr, ws.mod + D, mstride, ws.ln_part, tiles_p, ws.cen[0]);
+    LFM_CHECK_LAUNCH();
+  } else if (KK <= PE_MAXK) {
     hipLaunchKernelGGL(patch_embed_kernel, dim3(cdiv(M, PE_TOK)), dim3(D / 4), 0, st, c->x, w->patch_w, w->patch_b, w->pos_embed, ws.X, M,
                        cfg ? B / 2 : B, s->in_ch, s->res, s->patch, D);
     LFM_CHECK_LAUNCH();
@@ -894,9 +1008,6 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
   // FOLDED LayerNorm-modulate (default; gemm_kernel.h): only where its preconditions hold -- whole 256-row tiles of ONE image each (or one shared
   // modulation row), row partials in D / 256 slots, all four GEMMs chip-filling on the 16x16x32 kernel.  Everything else (small batches, DiT-S / XL
   // widths, patch 4 / 8 token counts with per-image conditioning, forced kernels) takes the separate ln_modulate launches below.
-  const int tiles_p = D / 256;
-  const bool fold = g_opt_fold_ln && (D % 256 == 0) && (M % 256 == 0) && (rows == 1 || T % 256 == 0) && (long)(M / 256) * tiles_p >= 192 &&
-                    g_gemm_sel == 0 && (H % 64 == 0) && s->depth >= 1;
   const long uvs_q = rows == 1 ? 0 : 3 * D, uvs_f = rows == 1 ? 0 : H;
   int cen_cur = 0;
   if (fold) {
@@ -910,9 +1021,11 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
     rc = launch_gemm_auto(ASrcRowMajor{ws.amod + 2L * rows * D, D, 2 * rows, 0}, (const half_t*)w->fc1_w, D, 2 * rows, H, D,
                           EpiUV{ws.uvf, (long)H, w->fc1_b, rows, (long)H}, st, s->depth, 4L * rows * D, (long)H * D, 2L * rows * H);
     if (rc) return rc;
-    hipLaunchKernelGGL(ln_center_mod_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, ws.X, ws.A, M, D, T, ws.mod + D, mstride, ws.ln_part, tiles_p,
-                       ws.cen[0]);
-    LFM_CHECK_LAUNCH();
+    if (!pe_mfma) {  // (the MFMA patch embedding has already written A', the partials and the row means)
+      hipLaunchKernelGGL(ln_center_mod_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, ws.X, ws.A, M, D, T, ws.mod + D, mstride, ws.ln_part, tiles_p,
+                         ws.cen[0]);
+      LFM_CHECK_LAUNCH();
+    }
   }
   auto rowstat_src = [&]() {  // consumer: reads cen[cen_cur], publishes the new row means into the other array, which becomes current
     RowStatSrc r{ws.ln_part, ws.cen[cen_cur], ws.cen[cen_cur ^ 1], tiles_p, 1.0f / (float)D, 1e-6f};
