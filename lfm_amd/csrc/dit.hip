@@ -453,6 +453,63 @@ __global__ __launch_bounds__(256) void mod_rows_f16_kernel(const float* __restri
   *(half4_t*)(Amod + idx * 4) = o;
 }
 
+// u / v rows of the folded path when ONE conditioning row serves the whole batch (scalar time, no labels): a GEMV pair per weight row,
+//   u[n] = sum_k (1 + scale[k]) W[n][k],   v[n] = sum_k shift[k] W[n][k] + bias[n],
+// streamed straight from the fp16 weights with the fp32 modulation vectors in registers (no fp16 rounding of them at all).  One wave = eight
+// weight rows (sixteen 16-byte loads in flight per lane); grid.y = block index.  This is pure weight streaming (352 MB per DiT-L/2 forward):
+// the batched 128x128 MFMA GEMM it replaces for this case moved the same bytes at 4 TB/s with 126 of its 128 tile rows padding.
+#define UV_ROWS 8
+__global__ __launch_bounds__(256) void uv_gemv_kernel(const half_t* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ mod,
+                                                      int N, int D, int scale_off, int shift_off, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, i = blockIdx.y;
+  const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * UV_ROWS;
+  if (n0 >= N) return;
+  const int nch = D >> 3;  // 16-byte chunks per row
+  const float* sc = mod + (long)i * 6 * D + scale_off;
+  const float* sh = mod + (long)i * 6 * D + shift_off;
+  f32x4 au[LN_MAXP][2], av[LN_MAXP][2];
+#pragma unroll
+  for (int j = 0; j < LN_MAXP; ++j) {
+    const int c = lane + 64 * j;
+    if (c < nch) {
+      au[j][0] = *(const f32x4*)(sc + 8 * c) + 1.0f;
+      au[j][1] = *(const f32x4*)(sc + 8 * c + 4) + 1.0f;
+      av[j][0] = *(const f32x4*)(sh + 8 * c);
+      av[j][1] = *(const f32x4*)(sh + 8 * c + 4);
+    }
+  }
+  const half_t* wb = W + ((long)i * N + n0) * D;
+  half8_t wv[UV_ROWS][LN_MAXP];
+#pragma unroll
+  for (int r = 0; r < UV_ROWS; ++r)
+#pragma unroll
+    for (int j = 0; j < LN_MAXP; ++j) {
+      const int c = lane + 64 * j;
+      if (c < nch && n0 + r < N) wv[r][j] = *(const half8_t*)(wb + (long)r * D + 8 * c);
+    }
+  float* ob = out + (long)i * 2 * N;
+#pragma unroll
+  for (int r = 0; r < UV_ROWS; ++r) {
+    float u = 0.f, v = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXP; ++j) {
+      if (lane + 64 * j < nch && n0 + r < N) {
+        const half8_t h = wv[r][j];
+        const f32x4 w0 = {(float)h[0], (float)h[1], (float)h[2], (float)h[3]}, w1 = {(float)h[4], (float)h[5], (float)h[6], (float)h[7]};
+        const f32x4 pu = au[j][0] * w0 + au[j][1] * w1, pv = av[j][0] * w0 + av[j][1] * w1;
+        u += (pu.x + pu.y) + (pu.z + pu.w);
+        v += (pv.x + pv.y) + (pv.z + pv.w);
+      }
+    }
+    u = wave_sum_dpp(u);
+    v = wave_sum_dpp(v);
+    if (lane == 0 && n0 + r < N) {
+      ob[n0 + r] = u;
+      ob[N + n0 + r] = v + bias[(long)i * N + n0 + r];
+    }
+  }
+}
+
 #include "attention_kernel.h"  // dit_attention_kernel<T, JQ, HD> + attention_launch
 
 // ------------------------------------------------------------------ final layer + unpatchify + solver update
@@ -589,7 +646,8 @@ __global__ __launch_bounds__(256) void final_layer_mfma_kernel(const float* __re
   // ---- pass 1: shifted one-pass statistics (shift = the row's first element)
   const float c0 = X[m * D];
   float sx = 0.f, sq = 0.f;
-  for (int ks = 0; ks < nks; ++ks) {
+#pragma unroll 8
+  for (int ks = 0; ks < nks; ++ks) {  // (unrolled: 16 loads of 16 B in flight per lane -- four waves per CU have to cover the HBM latency)
     const f32x4 x0 = *(const f32x4*)(xr + 32 * ks) - c0, x1 = *(const f32x4*)(xr + 32 * ks + 4) - c0;
     sx += (x0.x + x0.y) + (x0.z + x0.w) + (x1.x + x1.y) + (x1.z + x1.w);
     sq += (x0.x * x0.x + x0.y * x0.y) + (x0.z * x0.z + x0.w * x0.w) + (x1.x * x1.x + x1.y * x1.y) + (x1.z * x1.z + x1.w * x1.w);
@@ -613,6 +671,7 @@ __global__ __launch_bounds__(256) void final_layer_mfma_kernel(const float* __re
       l[e] = (half_t)(v[e] - (float)h[e]);
     }
   };
+#pragma unroll 4
   for (int ks = 0; ks < nks; ++ks) {
     const f32x4 x0 = *(const f32x4*)(xr + 32 * ks), x1 = *(const f32x4*)(xr + 32 * ks + 4);
     const f32x4 s0 = *(const f32x4*)(scale + mo + 32 * ks), s1 = *(const f32x4*)(scale + mo + 32 * ks + 4);
@@ -1011,16 +1070,25 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
   const long uvs_q = rows == 1 ? 0 : 3 * D, uvs_f = rows == 1 ? 0 : H;
   int cen_cur = 0;
   if (fold) {
-    const long nmod = (long)s->depth * 4 * rows * (D / 4);
-    hipLaunchKernelGGL(mod_rows_f16_kernel, dim3(cdiv(nmod, 256)), dim3(256), 0, st, ws.mod, mstride, s->depth, rows, D, ws.amod);
-    LFM_CHECK_LAUNCH();
-    // u, v of every block in two batched GEMMs (batch = depth): [2 rows x D] x [D x 3D] and [2 rows x D] x [D x H]
-    rc = launch_gemm_auto(ASrcRowMajor{ws.amod, D, 2 * rows, 0}, (const half_t*)w->qkv_w, D, 2 * rows, 3 * D, D,
-                          EpiUV{ws.uvq, 3L * D, w->qkv_b, rows, 3L * D}, st, s->depth, 4L * rows * D, 3L * D * D, 2L * rows * 3 * D);
-    if (rc) return rc;
-    rc = launch_gemm_auto(ASrcRowMajor{ws.amod + 2L * rows * D, D, 2 * rows, 0}, (const half_t*)w->fc1_w, D, 2 * rows, H, D,
-                          EpiUV{ws.uvf, (long)H, w->fc1_b, rows, (long)H}, st, s->depth, 4L * rows * D, (long)H * D, 2L * rows * H);
-    if (rc) return rc;
+    if (rows == 1 && D <= 8 * 64 * LN_MAXP) {  // one shared conditioning row: weight-streaming GEMVs (u, v of every block)
+      hipLaunchKernelGGL(uv_gemv_kernel, dim3(cdiv(3 * D, 4 * UV_ROWS), s->depth), dim3(256), 0, st, (const half_t*)w->qkv_w, w->qkv_b, ws.mod, 3 * D, D,
+                         D, 0, ws.uvq);
+      LFM_CHECK_LAUNCH();
+      hipLaunchKernelGGL(uv_gemv_kernel, dim3(cdiv(H, 4 * UV_ROWS), s->depth), dim3(256), 0, st, (const half_t*)w->fc1_w, w->fc1_b, ws.mod, H, D, 4 * D,
+                         3 * D, ws.uvf);
+      LFM_CHECK_LAUNCH();
+    } else {
+      const long nmod = (long)s->depth * 4 * rows * (D / 4);
+      hipLaunchKernelGGL(mod_rows_f16_kernel, dim3(cdiv(nmod, 256)), dim3(256), 0, st, ws.mod, mstride, s->depth, rows, D, ws.amod);
+      LFM_CHECK_LAUNCH();
+      // u, v of every block in two batched GEMMs (batch = depth): [2 rows x D] x [D x 3D] and [2 rows x D] x [D x H]
+      rc = launch_gemm_auto(ASrcRowMajor{ws.amod, D, 2 * rows, 0}, (const half_t*)w->qkv_w, D, 2 * rows, 3 * D, D,
+                            EpiUV{ws.uvq, 3L * D, w->qkv_b, rows, 3L * D}, st, s->depth, 4L * rows * D, 3L * D * D, 2L * rows * 3 * D);
+      if (rc) return rc;
+      rc = launch_gemm_auto(ASrcRowMajor{ws.amod + 2L * rows * D, D, 2 * rows, 0}, (const half_t*)w->fc1_w, D, 2 * rows, H, D,
+                            EpiUV{ws.uvf, (long)H, w->fc1_b, rows, (long)H}, st, s->depth, 4L * rows * D, (long)H * D, 2L * rows * H);
+      if (rc) return rc;
+    }
     if (!pe_mfma) {  // (the MFMA patch embedding has already written A', the partials and the row means)
       hipLaunchKernelGGL(ln_center_mod_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, ws.X, ws.A, M, D, T, ws.mod + D, mstride, ws.ln_part, tiles_p,
                          ws.cen[0]);
