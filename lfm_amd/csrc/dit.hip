@@ -630,24 +630,27 @@ __global__ __launch_bounds__(256) void final_layer_kernel(const float* __restric
 //   * fp32 fidelity on an fp16 matrix core: activation and weight are each split into fp16 hi + lo and three MFMAs (hi*hi + lo*hi + hi*lo)
 //     accumulate in fp32 -- the dropped lo*lo term is 2^-22 relative, i.e. the result is the fp32 dot product to rounding, as before.
 // Under CFG a tile holds eight conditional rows and their eight unconditional twins, which land in lanes l and l ^ 32 of the result.
+// (D % 128 == 0: the four waves of a block take the 32-deep k-steps round-robin.)
 template <bool CFG, int NT>
 __global__ __launch_bounds__(256) void final_layer_mfma_kernel(const float* __restrict__ X, int M, int D, int tokens, const float* __restrict__ shift,
                                                                const float* __restrict__ scale, long mod_stride, const float* __restrict__ Wf,
                                                                const float* __restrict__ bf, int C, int R, int p, float cfg_scale, float* out,
                                                                const float* base, const float* __restrict__ dt_ptr) {
-  const int lane = threadIdx.x & 63, a = lane & 15, q = lane >> 4;
-  const long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  // one BLOCK per 16-row tile; its four waves split K (k-steps wv, wv + 4, ...) so that sixteen waves per CU cover the memory latency, and
+  // combine their partial statistics / partial accumulators through the LDS in a fixed order
+  __shared__ float st_s[4][16][2];
+  __shared__ float acc_s[4][NT][64][4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, a = lane & 15, q = lane >> 4;
+  const long tile = blockIdx.x;
   const int Mh = CFG ? M / 2 : M;
-  const long ntiles = CFG ? Mh / 8 : M / 16;
-  if (tile >= ntiles) return;
   const long m = CFG ? tile * 8 + (a & 7) + (a >> 3) * (long)Mh : tile * 16 + a;  // this lane's operand row
   const float* xr = X + m * D + 8 * q;
   const int nks = D >> 5;
   // ---- pass 1: shifted one-pass statistics (shift = the row's first element)
   const float c0 = X[m * D];
   float sx = 0.f, sq = 0.f;
-#pragma unroll 8
-  for (int ks = 0; ks < nks; ++ks) {  // (unrolled: 16 loads of 16 B in flight per lane -- four waves per CU have to cover the HBM latency)
+#pragma unroll 4
+  for (int ks = wv; ks < nks; ks += 4) {
     const f32x4 x0 = *(const f32x4*)(xr + 32 * ks) - c0, x1 = *(const f32x4*)(xr + 32 * ks + 4) - c0;
     sx += (x0.x + x0.y) + (x0.z + x0.w) + (x1.x + x1.y) + (x1.z + x1.w);
     sq += (x0.x * x0.x + x0.y * x0.y) + (x0.z * x0.z + x0.w * x0.w) + (x1.x * x1.x + x1.y * x1.y) + (x1.z * x1.z + x1.w * x1.w);
@@ -656,10 +659,17 @@ __global__ __launch_bounds__(256) void final_layer_mfma_kernel(const float* __re
   sq += __shfl_xor(sq, 16, 64);
   sx += __shfl_xor(sx, 32, 64);
   sq += __shfl_xor(sq, 32, 64);
+  if (q == 0) {
+    st_s[wv][a][0] = sx;
+    st_s[wv][a][1] = sq;
+  }
+  __syncthreads();
+  sx = (st_s[0][a][0] + st_s[1][a][0]) + (st_s[2][a][0] + st_s[3][a][0]);
+  sq = (st_s[0][a][1] + st_s[1][a][1]) + (st_s[2][a][1] + st_s[3][a][1]);
   const float dl = sx / (float)D, mean = c0 + dl;
   const float rstd = rsqrtf(fmaxf(sq / (float)D - dl * dl, 0.f) + 1e-6f);
   const long mo = (m / tokens) * mod_stride + 8 * q;
-  // ---- pass 2: operands + MFMAs
+  // ---- pass 2: operands + MFMAs (X again, now from the L2)
   f32x4_t acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -671,8 +681,8 @@ __global__ __launch_bounds__(256) void final_layer_mfma_kernel(const float* __re
       l[e] = (half_t)(v[e] - (float)h[e]);
     }
   };
-#pragma unroll 4
-  for (int ks = 0; ks < nks; ++ks) {
+#pragma unroll 2
+  for (int ks = wv; ks < nks; ks += 4) {
     const f32x4 x0 = *(const f32x4*)(xr + 32 * ks), x1 = *(const f32x4*)(xr + 32 * ks + 4);
     const f32x4 s0 = *(const f32x4*)(scale + mo + 32 * ks), s1 = *(const f32x4*)(scale + mo + 32 * ks + 4);
     const f32x4 h0 = *(const f32x4*)(shift + mo + 32 * ks), h1 = *(const f32x4*)(shift + mo + 32 * ks + 4);
@@ -689,18 +699,24 @@ __global__ __launch_bounds__(256) void final_layer_mfma_kernel(const float* __re
       acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl, acc[t], 0, 0, 0);
     }
   }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) *(f32x4_t*)acc_s[wv][t][lane] = acc[t];
+  __syncthreads();
+  if (wv != 0) return;
   // ---- lane holds out[row 4 q + r][column o = t * 16 + (lane & 15)], r = 0..3
   const float dt = base ? *dt_ptr : 0.f;
   const int grid = R / p;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
+    const f32x4_t tot = (*(const f32x4_t*)acc_s[0][t][lane] + *(const f32x4_t*)acc_s[1][t][lane]) +
+                        (*(const f32x4_t*)acc_s[2][t][lane] + *(const f32x4_t*)acc_s[3][t][lane]);
     const int o = t * 16 + a;
     const float bo = bf[o];
     const int pp = o / (p * C), qq = (o / C) % p, c = o % C;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = 4 * q + r;
-      float val = acc[t][r] + bo;
+      float val = tot[r] + bo;
       if (CFG) {  // rows 0..7 conditional, 8..15 their unconditional twins: lane ^ 32 holds the twin's value
         const float other = xhalf(val);
         const float cond = row < 8 ? val : other, uncond = row < 8 ? other : val;
@@ -1162,11 +1178,11 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
   const int Mh = cfg ? M / 2 : M;
   // skinny MFMA GEMM (16 rows per wave) when the shape allows it: whole 16-row tiles inside one image half, 16-column output tiles, D % 32 == 0
   const int NO = s->in_ch * s->patch * s->patch;
-  const bool fin_mfma = (NO == 16 || NO == 64) && (D % 32 == 0) && (T % 16 == 0) && !(g_gemm_dbg & 1048576);  // flag 1048576: the round-1 kernel (A/B)
+  const bool fin_mfma = (NO == 16 || NO == 64) && (D % 32 == 0) && (T % 16 == 0) && (M % 16 == 0) && !(g_gemm_dbg & 1048576);  // flag 1048576: the round-1 kernel (A/B)
   if (fin_mfma) {
     const long ntiles = cfg ? Mh / 8 : M / 16;
 #define FIN_LAUNCH(CF, NTT)                                                                                                                 \
-  hipLaunchKernelGGL((final_layer_mfma_kernel<CF, NTT>), dim3(cdiv(ntiles, 4)), dim3(256), 0, st, ws.X, M, D, T, fmod, fmod + D, mstride,   \
+  hipLaunchKernelGGL((final_layer_mfma_kernel<CF, NTT>), dim3((unsigned)ntiles), dim3(256), 0, st, ws.X, M, D, T, fmod, fmod + D, mstride,   \
                      w->final_w, w->final_b, s->in_ch, s->res, s->patch, cfg ? c->cfg_scale : 1.0f, c->out, c->axpy_base, c->axpy_dt)
     if (cfg) {
       if (NO == 16) FIN_LAUNCH(true, 1);

@@ -49,6 +49,18 @@ struct epi_column_aux<Epi, decltype((void)Epi::column_aux)> {
   static constexpr bool value = Epi::column_aux;
 };
 
+// epilogues that accumulate something per lane across their store8 calls (GroupNorm partial sums of the convolution outputs, vae.hip) provide
+// finish_tile(m0, n0, g, wn, lane): called once per wave after the row-major hand-over, in which a lane always owns the SAME eight columns
+// n0 + 64 wn + 8 (lane & 7) and rows of the 128-row half g
+template <class Epi, class = void>
+struct epi_has_finish_tile {
+  static constexpr bool value = false;
+};
+template <class Epi>
+struct epi_has_finish_tile<Epi, decltype((void)&Epi::finish_tile)> {
+  static constexpr bool value = true;
+};
+
 // The row-major path of the epilogue: each wave transposes its accumulators through a private LDS scratch, see g256_epilogue.
 // fp16 outputs (store8): a lane re-reads EIGHT consecutive columns of a row (two ds_read_b128) and issues ONE 16-byte store, so a
 // store instruction covers 8 rows x one full 128-B line -- half the store instructions of the 4-column form.  The fp16 epilogues
@@ -243,6 +255,7 @@ __device__ __forceinline__ void g256_epilogue(f32x16 (&acc)[4][2], char* smem, E
     }
   }
   g256_epilogue_rows<BN>(acc, smem, epi, m0, n0, M, N, g, wn, lane, wave, (dbg & 1024) != 0);  // flag 1024: the 8-byte-store epilogue (A/B)
+  if constexpr (epi_has_finish_tile<Epi>::value) epi.finish_tile(m0, n0, g, wn, lane);
 }
 
 #define G256_BARRIER()                  \

@@ -401,6 +401,7 @@ __device__ __forceinline__ void g256h_epilogue(f32x4_t (&acc)[8][4], char* smem,
     }
   }
   g256h_epilogue_rows<BN, TRACE>(acc, smem, epi, m0, n0, M, N, g, wn, lane, wave, (dbg & 1024) != 0, tr);
+  if constexpr (epi_has_finish_tile<Epi>::value) epi.finish_tile(m0, n0, g, wn, lane);
   g256h_stamp<TRACE>(tr, g, wn, lane, 17);
 }
 

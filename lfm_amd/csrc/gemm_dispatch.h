@@ -6,6 +6,20 @@
 // two-per-CU kernel (gemm256n_kernel.h) for chip-filling problems that are only 128 columns wide (or where it measured faster, see
 // lfm_gemm_prefers_v4), the 128x128 kernel otherwise.  lfm_gemm_select() (0 auto, 1 / 4 / 5 force a kernel) exists for A/B measurements and
 // for parity tests of all kernels.
+// which kernel launch_gemm_auto takes for a shape: 1 = 128x128, 4 = 256x128, 5 = 256x256 (callers that depend on the epilogue's lane mapping ask)
+static inline int gemm_auto_choice(int M, int N, int K, int batch = 1) {
+  const long tiles256 = (long)cdiv(M, 256) * cdiv(N, 256) * batch;
+  const int sel = lfm_gemm_selected();
+  const bool big = tiles256 >= 192 && N >= 256 && M >= 256;
+  if ((K % G256N_BK) == 0) {
+    const long tiles128 = (long)cdiv(M, 256) * cdiv(N, G256N_BN) * batch;
+    const bool narrow = N > 64 && N < 256 && tiles128 >= 256;
+    if (sel == 4 || (sel == 0 && (narrow || (big && lfm_gemm_prefers_v4(M, N, K))))) return 4;
+  }
+  if ((sel == 5 || (sel == 0 && big)) && (K % G256Q_BK) == 0) return 5;
+  return 1;
+}
+
 template <class ASrc, class Epi>
 static inline int launch_gemm_auto(const ASrc& asrc, const half_t* W, long ldw, int M, int N, int K, const Epi& epi, hipStream_t stream,
                                    int batch = 1, long bsA = 0, long bsW = 0, long bsC = 0) {

@@ -119,6 +119,63 @@ struct EpiConvF16 {  // out = acc + bias (+ residual)  -> fp16 NHWC
   }
 };
 
+// EpiConvF16 that also leaves the GroupNorm statistics of what it stores (round 3): the next layer of every resnet is a GroupNorm over exactly this
+// tensor, and its statistics pass (gn_stats_kernel) re-read it from HBM just to add it up.  In the row-major hand-over of the 256-row kernels a lane
+// owns the same eight output columns for all of its rows, so it keeps (sum, sum of squares) of the ROUNDED fp16 values per half-octet (a group is
+// >= 4 channels wide) in four registers, folds the eight lanes that share its columns at the end of the tile, and writes one fixed slot per
+// (image, 128-row slab, half-octet): part[n][slab][C / 4][2], the layout gn_finish_kernel folds in a fixed order -- deterministic, no atomics.
+// Host-side preconditions (conv3): HW % 256 == 0 (a tile lies in one image), the 256x128 or 256x256 kernel, 16-byte-store path.
+struct EpiConvStatsF16 {
+  half_t* C;
+  long ldc;
+  const float* bias;
+  const half_t* resid;
+  float* part;  // [n][slabs][ldc / 4][2]
+  int HW, slabs;
+  mutable float s0, q0, s1, q1;
+  typedef EpiConvF16::Aux Aux;
+  __device__ __forceinline__ Aux load(int m, int n) const {
+    Aux a;
+    a.b = *(const f32x4*)(bias + n);
+    if (resid) a.r = *(const half4_t*)(resid + (long)m * ldc + n);
+    else a.r = (half4_t){0, 0, 0, 0};
+    return a;
+  }
+  __device__ __forceinline__ void store(int m, int n, f32x4 v, const Aux& a) const {  // (4-column path: not used with statistics, kept for the interface)
+    v += a.b;
+    half4_t h = {(half_t)(v.x + (float)a.r.x), (half_t)(v.y + (float)a.r.y), (half_t)(v.z + (float)a.r.z), (half_t)(v.w + (float)a.r.w)};
+    *(half4_t*)(C + (long)m * ldc + n) = h;
+  }
+  __device__ __forceinline__ bool wide_ok() const { return true; }  // checked on the host
+  __device__ __forceinline__ void store8(int m, int n, f32x4 lo, f32x4 hi, const Aux& al, const Aux& ah) const {
+    lo += al.b;
+    hi += ah.b;
+    const half8_t h = {(half_t)(lo.x + (float)al.r.x), (half_t)(lo.y + (float)al.r.y), (half_t)(lo.z + (float)al.r.z), (half_t)(lo.w + (float)al.r.w),
+                       (half_t)(hi.x + (float)ah.r.x), (half_t)(hi.y + (float)ah.r.y), (half_t)(hi.z + (float)ah.r.z), (half_t)(hi.w + (float)ah.r.w)};
+    *(half8_t*)(C + (long)m * ldc + n) = h;
+    const float f0 = (float)h[0], f1 = (float)h[1], f2 = (float)h[2], f3 = (float)h[3], f4 = (float)h[4], f5 = (float)h[5], f6 = (float)h[6], f7 = (float)h[7];
+    s0 += (f0 + f1) + (f2 + f3);
+    q0 += (f0 * f0 + f1 * f1) + (f2 * f2 + f3 * f3);
+    s1 += (f4 + f5) + (f6 + f7);
+    q1 += (f4 * f4 + f5 * f5) + (f6 * f6 + f7 * f7);
+  }
+  __device__ __forceinline__ void finish_tile(int m0, int n0, int g, int wn, int lane) const {
+    float a = s0, b = q0, c = s1, d = q1;
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {  // the eight lanes lane & 7, + 8, .., + 56 own the same columns
+      a += __shfl_xor(a, o, 64);
+      b += __shfl_xor(b, o, 64);
+      c += __shfl_xor(c, o, 64);
+      d += __shfl_xor(d, o, 64);
+    }
+    if (lane < 8) {
+      const int img = m0 / HW, slab = ((m0 - img * HW) >> 8) * 2 + g;
+      float* o = part + (((long)img * slabs + slab) * (ldc >> 2) + ((n0 + wn * 64 + lane * 8) >> 2)) * 2;
+      *(f32x4*)o = (f32x4){a, b, c, d};
+    }
+  }
+};
+
 struct EpiTransposeF16 {  // per image: Ct[img][n][m % T] = acc + bias[n]   (V^T for the mid attention)
   half_t* Ct;
   const float* bias;
@@ -369,7 +426,10 @@ static VaeWs vae_carve(int R, int chunk, void* ws) {
   w.b2 = (half_t*)take(act);
   w.b3 = (half_t*)take(act);
   w.stats = (float*)take((size_t)chunk * 64 * 4);
-  w.part = (float*)take((size_t)chunk * VGN_MAX_SLABS * 128 * 2 * 4);
+  // the larger of: the statistics kernel's slabs (VGN_MAX_SLABS x C / 4 <= 128 half-octets) and the convolution epilogues' 128-row slabs
+  // (2 HW / 256 per image x C / 4 half-octets: at most (8R)^2 * 256 / 512 for the 256-channel tensor at full resolution)
+  const size_t part_conv = (size_t)(8 * R) * (8 * R) * 256 / 512, part_stats = (size_t)VGN_MAX_SLABS * 128;
+  w.part = (float*)take((size_t)chunk * (part_conv > part_stats ? part_conv : part_stats) * 2 * 4);
   w.zeros = (half_t*)take(256);
   w.S = (float*)take((size_t)chunk * T * T * 4);
   w.total = off;
@@ -387,14 +447,18 @@ extern "C" size_t lfm_vae_workspace_bytes(int R, int chunk) {
     if (_rc) return _rc; \
   } while (0)
 
+// ready_slabs > 0: the convolution that produced x already left its partial sums in `part` (EpiConvStatsF16), in that many slabs per image
 static int gn(const half_t* x, half_t* y, float* stats, float* part, const float* g, const float* b, int n, int HW, int C, bool silu,
-              hipStream_t st) {
+              hipStream_t st, int ready_slabs = 0) {
   if (C % 128 || 256 % (C / 8) || C > 512) return LFM_ERR_SHAPE;  // groups of >= 4 channels, octet-per-thread mapping
-  int ppb = 1024;
-  if (cdiv(HW, ppb) > VGN_MAX_SLABS) ppb = cdiv(HW, VGN_MAX_SLABS);
-  const int slabs = cdiv(HW, ppb);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(slabs, n), dim3(256), 0, st, x, part, HW, C, ppb);
-  LFM_CHECK_LAUNCH();
+  int slabs = ready_slabs;
+  if (!ready_slabs) {
+    int ppb = 1024;
+    if (cdiv(HW, ppb) > VGN_MAX_SLABS) ppb = cdiv(HW, VGN_MAX_SLABS);
+    slabs = cdiv(HW, ppb);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(slabs, n), dim3(256), 0, st, x, part, HW, C, ppb);
+    LFM_CHECK_LAUNCH();
+  }
   hipLaunchKernelGGL(gn_finish_kernel, dim3(cdiv(n * 32, 64)), dim3(64), 0, st, part, stats, slabs, C, n * 32);
   LFM_CHECK_LAUNCH();
   const long total8 = (long)n * HW * C / 8;
@@ -405,26 +469,41 @@ static int gn(const half_t* x, half_t* y, float* stats, float* part, const float
 }
 
 // out[n,H,W,Cout] = conv3x3(in (optionally nearest-2x upsampled)) + bias (+ resid)
+// *stat_slabs (optional): set to the number of partial-sum slabs per image this convolution left in `part` for the GroupNorm that follows, or 0
 static int conv3(const half_t* in, const half_t* w, const float* b, const half_t* resid, half_t* out, const half_t* zeros, int n, int H, int W,
-                 int Cin, int Cout, bool ups, hipStream_t st) {
+                 int Cin, int Cout, bool ups, hipStream_t st, float* part = nullptr, int* stat_slabs = nullptr) {
   if (Cin % 64 || Cout % 4) return LFM_ERR_SHAPE;
   const int M = n * H * W;
+  if (stat_slabs) *stat_slabs = 0;
+  const int HW = H * W, kern = gemm_auto_choice(M, Cout, 9 * Cin);
+  if (part && stat_slabs && (HW % 256) == 0 && (kern == 4 || kern == 5) && (Cout % (kern == 4 ? 128 : 256)) == 0 && (Cout % 128) == 0 &&
+      !(((uintptr_t)out | (uintptr_t)resid) & 15) && !(lfm_gemm_debug_flags() & (1024 | 4194304))) {  // flag 4194304: the separate statistics pass (A/B)
+    *stat_slabs = 2 * (HW / 256);
+    EpiConvStatsF16 es{out, Cout, b, resid, part, HW, *stat_slabs, 0.f, 0.f, 0.f, 0.f};
+    if (ups) return launch_gemm_auto(ASrcConv3x3<1>{in, zeros, H, W, Cin, M, 0, 0}, w, 9L * Cin, M, Cout, 9 * Cin, es, st);
+    return launch_gemm_auto(ASrcConv3x3<0>{in, zeros, H, W, Cin, M, 0, 0}, w, 9L * Cin, M, Cout, 9 * Cin, es, st);
+  }
   EpiConvF16 epi{out, Cout, b, resid};
   if (ups) return launch_gemm_auto(ASrcConv3x3<1>{in, zeros, H, W, Cin, M, 0, 0}, w, 9L * Cin, M, Cout, 9 * Cin, epi, st);
   return launch_gemm_auto(ASrcConv3x3<0>{in, zeros, H, W, Cin, M, 0, 0}, w, 9L * Cin, M, Cout, 9 * Cin, epi, st);
 }
 
-static int resnet(const lfm_vae_resnet* r, half_t*& x, half_t*& t1, half_t*& t2, half_t*& t3, const VaeWs& ws, int n, int H, int W, hipStream_t st) {
+// x_slabs: in = partial-sum slabs per image already in ws.part for x (0 = none), out = the same for the result
+static int resnet(const lfm_vae_resnet* r, half_t*& x, half_t*& t1, half_t*& t2, half_t*& t3, const VaeWs& ws, int n, int H, int W, hipStream_t st,
+                  int* x_slabs = nullptr) {
   const int HW = H * W, M = n * HW;
-  RC(gn(x, t1, ws.stats, ws.part, r->n1_g, r->n1_b, n, HW, r->cin, true, st));
-  RC(conv3(t1, (const half_t*)r->c1_w, r->c1_b, nullptr, t2, ws.zeros, n, H, W, r->cin, r->cout, false, st));
-  RC(gn(t2, t1, ws.stats, ws.part, r->n2_g, r->n2_b, n, HW, r->cout, true, st));
+  int mid_slabs = 0, out_slabs = 0;
+  RC(gn(x, t1, ws.stats, ws.part, r->n1_g, r->n1_b, n, HW, r->cin, true, st, x_slabs ? *x_slabs : 0));
+  RC(conv3(t1, (const half_t*)r->c1_w, r->c1_b, nullptr, t2, ws.zeros, n, H, W, r->cin, r->cout, false, st, ws.part, &mid_slabs));
+  RC(gn(t2, t1, ws.stats, ws.part, r->n2_g, r->n2_b, n, HW, r->cout, true, st, mid_slabs));
   const half_t* skip = x;
   if (r->sc_w) {  // 1x1 conv shortcut
     RC(launch_gemm_auto(ASrcRowMajor{x, r->cin, M, 0}, (const half_t*)r->sc_w, r->cin, M, r->cout, r->cin, EpiConvF16{t3, r->cout, r->sc_b, nullptr}, st));
     skip = t3;
   }
-  RC(conv3(t1, (const half_t*)r->c2_w, r->c2_b, skip, t2, ws.zeros, n, H, W, r->cout, r->cout, false, st));
+  RC(conv3(t1, (const half_t*)r->c2_w, r->c2_b, skip, t2, ws.zeros, n, H, W, r->cout, r->cout, false, st, x_slabs ? ws.part : nullptr,
+           x_slabs ? &out_slabs : nullptr));
+  if (x_slabs) *x_slabs = out_slabs;
   half_t* o = t2;  // result in t2; rotate buffers so x is the result
   t2 = x;
   x = o;
@@ -435,9 +514,9 @@ static int resnet(const lfm_vae_resnet* r, half_t*& x, half_t*& t1, half_t*& t2,
 // -> to_out + x, all on the GEMM kernel.  x is replaced by the result (buffers rotate).
 static int mid_attention(const float* at_g, const float* at_b, const void* q_w, const float* q_b, const void* k_w, const float* k_b, const void* v_w,
                          const float* v_b, const void* o_w, const float* o_b, half_t*& x, half_t*& t1, half_t*& t2, half_t*& t3, const VaeWs& ws,
-                         int n, int T, hipStream_t st) {
+                         int n, int T, hipStream_t st, int x_slabs = 0) {
   const int M = n * T, C = 512;
-  RC(gn(x, t1, ws.stats, ws.part, at_g, at_b, n, T, C, false, st));
+  RC(gn(x, t1, ws.stats, ws.part, at_g, at_b, n, T, C, false, st, x_slabs));
   half_t* Qb = t2;                 // [M, C]
   half_t* Kb = t2 + (size_t)M * C;  // [M, C]
   half_t* Vt = t3;                 // [n, C, T]
@@ -482,21 +561,23 @@ extern "C" int lfm_vae_decode(const lfm_vae_weights* w, void* workspace, size_t 
                        w->cin_w, w->cin_b, x, n, R, 512);
     LFM_CHECK_LAUNCH();
     int H = R;
-    RC(resnet(&w->mid[0], x, t1, t2, t3, ws, n, H, H, st));
-    RC(mid_attention(w->at_g, w->at_b, w->q_w, w->q_b, w->k_w, w->k_b, w->v_w, w->v_b, w->o_w, w->o_b, x, t1, t2, t3, ws, n, T, st));
-    RC(resnet(&w->mid[1], x, t1, t2, t3, ws, n, H, H, st));
+    int xs = 0;  // partial-sum slabs per image that the producer of x left in ws.part (0 = none: the GroupNorm runs its own statistics pass)
+    RC(resnet(&w->mid[0], x, t1, t2, t3, ws, n, H, H, st, &xs));
+    RC(mid_attention(w->at_g, w->at_b, w->q_w, w->q_b, w->k_w, w->k_b, w->v_w, w->v_b, w->o_w, w->o_b, x, t1, t2, t3, ws, n, T, st, xs));
+    xs = 0;
+    RC(resnet(&w->mid[1], x, t1, t2, t3, ws, n, H, H, st, &xs));
     for (int i = 0; i < 4; ++i) {
-      for (int j = 0; j < 3; ++j) RC(resnet(&w->up[i][j], x, t1, t2, t3, ws, n, H, H, st));
+      for (int j = 0; j < 3; ++j) RC(resnet(&w->up[i][j], x, t1, t2, t3, ws, n, H, H, st, &xs));
       if (i < 3) {
         const int C = w->up[i][2].cout;
         H *= 2;
-        RC(conv3(x, (const half_t*)w->ups_w[i], w->ups_b[i], nullptr, t1, ws.zeros, n, H, H, C, C, true, st));
+        RC(conv3(x, (const half_t*)w->ups_w[i], w->ups_b[i], nullptr, t1, ws.zeros, n, H, H, C, C, true, st, ws.part, &xs));
         half_t* o = t1;
         t1 = x;
         x = o;
       }
     }
-    RC(gn(x, t1, ws.stats, ws.part, w->no_g, w->no_b, n, H * H, 128, true, st));
+    RC(gn(x, t1, ws.stats, ws.part, w->no_g, w->no_b, n, H * H, 128, true, st, xs));
     const int M = n * H * H;
     RC(launch_gemm_tn(ASrcConv3x3<0>{t1, ws.zeros, H, H, 128, M, 0, 0}, (const half_t*)w->cout_w, 9L * 128, M, 4, 9 * 128,
                       EpiConvOutNCHW{out + (long)n0 * 3 * H * H, w->cout_b, H * H}, st));
