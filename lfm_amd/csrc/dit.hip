@@ -18,6 +18,7 @@ int lfm_gemm_prefers_v4(int M, int N, int K) {
   return 0;
 }
 static int g_opt_fold_ln = 1;
+
 extern "C" int lfm_set_option(int key, int value) {  // key 1 (LFM_OPT_FOLD_LN): adaLN LayerNorm-modulate folded into the GEMM epilogues (default 1)
   if (key == 1) {
     g_opt_fold_ln = value != 0;
@@ -941,6 +942,19 @@ extern "C" int lfm_gemm_f16(const void* A, long lda, const void* W, long ldw, vo
 #ifdef LFM_MEASURE
       if (g_gemm_sel == 5 && (g_gemm_dbg & 2) && K % G256Q_BK == 0)  // measurement: the epilogue-stamped build of the 16x16x32 kernel
         return launch_gemm256h_tn<ASrcRowMajor, EpiBiasGeluF16, true>(a, (const half_t*)W, ldw, M, N, K, EpiBiasGeluF16{(half_t*)C, ldc, bias}, st);
+      if (g_gemm_sel == 5 && ((g_gemm_dbg >> 21) & 7) && K % G256Q_BK == 0) {  // measurement: main-loop ablations (flags 1..4 << 21)
+        const EpiBiasGeluF16 e{(half_t*)C, ldc, bias};
+        switch ((g_gemm_dbg >> 21) & 7) {
+          case 1: return launch_gemm256h_tn<ASrcRowMajor, EpiBiasGeluF16, false, 1>(a, (const half_t*)W, ldw, M, N, K, e, st);
+          case 2: return launch_gemm256h_tn<ASrcRowMajor, EpiBiasGeluF16, false, 2>(a, (const half_t*)W, ldw, M, N, K, e, st);
+          case 3: return launch_gemm256h_tn<ASrcRowMajor, EpiBiasGeluF16, false, 3>(a, (const half_t*)W, ldw, M, N, K, e, st);
+          case 4: return launch_gemm256h_tn<ASrcRowMajor, EpiBiasGeluF16, false, 4>(a, (const half_t*)W, ldw, M, N, K, e, st);
+          case 5: return launch_gemm256h_tn<ASrcRowMajor, EpiBiasGeluF16, false, 5>(a, (const half_t*)W, ldw, M, N, K, e, st);
+          case 6: return launch_gemm256h_tn<ASrcRowMajor, EpiBiasGeluF16, false, 6>(a, (const half_t*)W, ldw, M, N, K, e, st);
+          default: return (g_gemm_dbg & (1 << 24)) ? launch_gemm256h_tn<ASrcRowMajor, EpiBiasGeluF16, false, 8>(a, (const half_t*)W, ldw, M, N, K, e, st)
+                                                   : launch_gemm256h_tn<ASrcRowMajor, EpiBiasGeluF16, false, 7>(a, (const half_t*)W, ldw, M, N, K, e, st);
+        }
+      }
 #endif
       return launch_gemm_auto(a, (const half_t*)W, ldw, M, N, K, EpiBiasGeluF16{(half_t*)C, ldc, bias}, st);
     case 2: return launch_gemm_auto(a, (const half_t*)W, ldw, M, N, K, EpiBiasF32{(float*)C, ldc, bias}, st);

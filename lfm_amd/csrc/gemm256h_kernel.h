@@ -405,7 +405,22 @@ __device__ __forceinline__ void g256h_epilogue(f32x4_t (&acc)[8][4], char* smem,
   g256h_stamp<TRACE>(tr, g, wn, lane, 17);
 }
 
-template <class ASrc, class Epi, bool TRACE = false>
+// Round 3, where the main loop goes (tools/mainloop_ablation.py on an LFM_MEASURE build, profiles/r03_mainloop_ablation.txt; epilogue off, fc2 shape
+// M 16384 x N 1024 x K 4096): full loop 97.5 us (1410 TFLOP/s); without the LDS-DMA issues 82.4; without the fragment reads 69.9; with neither 60.6
+// (2267 TFLOP/s, constant operands); barriers: free (60.0 without them, 60.1 with one per K-tile); static priority for the second wave group: WORSE
+// (110 us); accumulators pinned to D = C registers through inline-asm MFMAs: nothing (the compiler rotates them through D != C register tuples, which
+// costs nothing).  So the LOAD part of a phase (~450-600 cycles: six fragment reads on average + two LDS-DMA issues of 60-185 cycles each) is what
+// keeps the matrix pipe at 62 % -- a phase is 256 + L, not 512.  Tried on that evidence and NOT kept: a software-pipelined loop in which every wave
+// issues the next step's six reads and its two LDS-DMAs between its own MFMAs (in-place refill of the A fragments, one counted lgkmcnt(5) per group
+// of four MFMAs; bit-identical results).  With both wave groups on the same instruction stream all eight waves hit the LDS-DMA issue together and
+// the pipe starved (fc2 122 vs 116 us); staggering the groups needs two copies of the loop, which the register allocator could not fit in 256
+// VGPRs (136-168 B of scratch, 180+ us) -- the structure is right, it wants hand-allocated registers.  Kept from it: ASrcRowMajor rows as 32-bit
+// offsets from a uniform base (SGPR base + VGPR offset LDS-DMAs), which took this kernel from 256 VGPRs + 12 B of scratch to 252 VGPRs and none.
+// ABL (LFM_MEASURE builds only; results are garbage, timings are the point): 1 = no LDS-DMA after the prologue, 2 = no fragment reads,
+// 3 = neither (the bare MFMA stream + barriers), 4 = static priority (s_setprio 1 for the second wave group, no per-phase flips),
+// 5 = 3 without the per-phase barriers (the bare MFMA stream), 6 = 3 with one barrier per K-tile instead of per phase,
+// 7 = 5 with the accumulators pinned (inline-asm MFMA, D = C), 8 = the full kernel with pinned accumulators
+template <class ASrc, class Epi, bool TRACE = false, int ABL = 0>
 __global__ __launch_bounds__(512) void gemm256h_tn_kernel(ASrc asrc, const half_t* __restrict__ W, long ldw, int M, int N, int K, int tiles_n,
                                                            Epi epi, long bsA, long bsW, long bsC, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -435,11 +450,14 @@ __global__ __launch_bounds__(512) void gemm256h_tn_kernel(ASrc asrc, const half_
     }
   const int nk = K / G256Q_BK;
   const int dma_off = wave * 1024;
+  bool dma_on = true;  // (ABL 1 / 3 turn it off after the prologue)
   auto issue_a = [&](int s, char* slot) {
+    if ((ABL == 1 || ABL == 3 || (ABL >= 5 && ABL <= 7)) && !dma_on) return;
     glds16(asrc.ptr(arow[s][0], cswz), slot + dma_off);
     glds16(asrc.ptr(arow[s][1], cswz), slot + 8192 + dma_off);
   };
   auto issue_b = [&](int s, int kt, char* slot) {
+    if ((ABL == 1 || ABL == 3 || (ABL >= 5 && ABL <= 7)) && !dma_on) return;
     glds16(wrow[s][0] + kt * G256Q_BK, slot + dma_off);
     glds16(wrow[s][1] + kt * G256Q_BK, slot + 8192 + dma_off);
   };
@@ -462,7 +480,8 @@ __global__ __launch_bounds__(512) void gemm256h_tn_kernel(ASrc asrc, const half_
   half8_t af[4][2], wf[4][2];  // A: [16-row tile of the current sub][k32 step];  W: [16-column tile 0..3 (sub0: 0,1; sub1: 2,3)][k32 step]
   auto lds_read = [&](half8_t& dst, int addr, auto OFFC) {
     constexpr int OFF = decltype(OFFC)::value;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+    if constexpr (ABL == 2 || ABL == 3 || (ABL >= 5 && ABL <= 7)) asm volatile("" : "+v"(dst));  // (ablation: the fragment keeps whatever it held)
+    else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
   };
 #define G256H_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define G256H_LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
@@ -510,7 +529,9 @@ __global__ __launch_bounds__(512) void gemm256h_tn_kernel(ASrc asrc, const half_
     } else {
       if (s2) issue_b(0, t + 2, cur + G256Q_SLOT_B0);
     }
-    if (s2) G256H_VMCNT(6);  // pieces allowed in flight: 3 3 3 3 | 3 3 2 1 | 0 0 0 0
+    if constexpr (ABL == 1 || ABL == 3 || (ABL >= 5 && ABL <= 7)) {
+      G256H_VMCNT(0);
+    } else if (s2) G256H_VMCNT(6);  // pieces allowed in flight: 3 3 3 3 | 3 3 2 1 | 0 0 0 0
     else if (s1) {
       if constexpr (PH < 2) G256H_VMCNT(6);
       else if constexpr (PH == 2) G256H_VMCNT(4);
@@ -522,7 +543,7 @@ __global__ __launch_bounds__(512) void gemm256h_tn_kernel(ASrc asrc, const half_
     constexpr int PH = decltype(PHC)::value;
     constexpr bool SW = decltype(SWC)::value != 0;
     constexpr int I0 = (PH >= 2) ? 4 : 0, J0 = (PH == 1 || PH == 2) ? 2 : 0;
-    __builtin_amdgcn_s_setprio(1);
+    if constexpr (ABL != 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -560,12 +581,15 @@ __global__ __launch_bounds__(512) void gemm256h_tn_kernel(ASrc asrc, const half_
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j2 = 0; j2 < 2; ++j2) {
-          if constexpr (SW) acc[I0 + i4][J0 + j2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i4][ks], wf[J0 + j2][ks], acc[I0 + i4][J0 + j2], 0, 0, 0);
+          if constexpr (ABL == 7 || ABL == 8) {  // (experiment) the accumulator pinned: D and C the SAME registers
+            if constexpr (SW) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[I0 + i4][J0 + j2]) : "v"(af[i4][ks]), "v"(wf[J0 + j2][ks]));
+            else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[I0 + i4][J0 + j2]) : "v"(wf[J0 + j2][ks]), "v"(af[i4][ks]));
+          } else if constexpr (SW) acc[I0 + i4][J0 + j2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i4][ks], wf[J0 + j2][ks], acc[I0 + i4][J0 + j2], 0, 0, 0);
           else acc[I0 + i4][J0 + j2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[J0 + j2][ks], af[i4][ks], acc[I0 + i4][J0 + j2], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-    __builtin_amdgcn_s_setprio(0);
+    if constexpr (ABL != 4) __builtin_amdgcn_s_setprio(0);
   };
 
   // ---- prologue: pieces A0(0) B0(0) B1(0) A1(0) [A0(1) B0(1)]
@@ -587,6 +611,22 @@ __global__ __launch_bounds__(512) void gemm256h_tn_kernel(ASrc asrc, const half_
   if constexpr (epi_has_rowstat<Epi>::value) g256h_rowstat_finish(epi, rsr, smem, m0, M, tile_n);
   if (nk > 1) G256H_VMCNT(6);
   else G256H_VMCNT(2);
+  if constexpr (ABL == 1 || ABL == 3 || (ABL >= 5 && ABL <= 7)) {
+    G256H_VMCNT(0);
+    dma_on = false;
+  }
+  if constexpr (ABL == 2 || ABL == 3 || (ABL >= 5 && ABL <= 7)) {  // defined fragment contents for the ablated reads
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        af[i][ks] = (half8_t){1, 2, 3, 4, 5, 6, 7, 8};
+        wf[i][ks] = (half8_t){1, -1, 1, -1, 1, -1, 1, -1};
+      }
+  }
+  if constexpr (ABL == 4) {
+    if (g == 1) __builtin_amdgcn_s_setprio(1);
+  }
   G256_BARRIER();
   // ONE barrier per phase: group 0 runs MFMA(p), LOAD(p+1); group 1 runs LOAD(p), MFMA(p) (hazard analysis: gemm256q_kernel.h)
   auto run = [&](auto GC, auto SWC) {
@@ -606,7 +646,12 @@ __global__ __launch_bounds__(512) void gemm256h_tn_kernel(ASrc asrc, const half_
           load_part(PHC, BUFC, t, s1, s2);
           mfma_part(PHC, SWC);
         }
-        G256_BARRIER();
+        if constexpr (ABL == 5 || ABL == 7) {
+        } else if constexpr (ABL == 6) {
+          if constexpr (PH == 3) G256_BARRIER();
+        } else {
+          G256_BARRIER();
+        }
       };
       phase(g256q_ic<0>{});
       phase(g256q_ic<1>{});
@@ -634,12 +679,14 @@ __global__ __launch_bounds__(512) void gemm256h_tn_kernel(ASrc asrc, const half_
   }
 #undef G256H_VMCNT
 #undef G256H_LGKM
+  if constexpr (ABL == 7 || ABL == 8) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");  // inline-asm MFMAs: their results must have landed
   g256h_epilogue<G256_BN, TRACE>(acc, smem, epi, m0, n0, M, N, g, wn, lane, wave, bz, bsC, dbg, swapped);
 }
 
-template <class ASrc, class Epi, bool TRACE = false>
+template <class ASrc, class Epi, bool TRACE = false, int ABL = 0>
 static inline int launch_gemm256h_tn(const ASrc& asrc, const half_t* W, long ldw, int M, int N, int K, const Epi& epi, hipStream_t stream,
                                      int batch = 1, long bsA = 0, long bsW = 0, long bsC = 0) {
+  if (!asrc_fits(asrc, 0)) return LFM_ERR_SHAPE;
   if (M <= 0 || N <= 0 || K <= 0 || (K % G256Q_BK) != 0 || (N % 4) != 0) return LFM_ERR_SHAPE;
   if ((ldw % 8) != 0 || ((uintptr_t)W & 15)) return LFM_ERR_ALIGN;
   const int tm = cdiv(M, G256_BM), tn = cdiv(N, G256_BN);
@@ -648,11 +695,11 @@ static inline int launch_gemm256h_tn(const ASrc& asrc, const half_t* W, long ldw
   int devid = 0;
   (void)hipGetDevice(&devid);
   if (!((attr_set >> (devid & 63)) & 1)) {
-    if (hipFuncSetAttribute((const void*)gemm256h_tn_kernel<ASrc, Epi, TRACE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemm256h_tn_kernel<ASrc, Epi, TRACE, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return LFM_ERR_LAUNCH;
     attr_set |= 1ull << (devid & 63);
   }
-  hipLaunchKernelGGL((gemm256h_tn_kernel<ASrc, Epi, TRACE>), dim3(tm * tn, batch), dim3(512), LDS, stream, asrc, W, ldw, M, N, K, tn, epi, bsA,
+  hipLaunchKernelGGL((gemm256h_tn_kernel<ASrc, Epi, TRACE, ABL>), dim3(tm * tn, batch), dim3(512), LDS, stream, asrc, W, ldw, M, N, K, tn, epi, bsA,
                      bsW, bsC, lfm_gemm_debug_flags());
   LFM_CHECK_LAUNCH();
   return LFM_OK;

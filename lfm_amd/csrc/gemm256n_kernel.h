@@ -184,6 +184,7 @@ __global__ __launch_bounds__(256, 2) void gemm256n_tn_kernel(ASrc asrc, const ha
 template <class ASrc, class Epi>
 static inline int launch_gemm256n_tn(const ASrc& asrc, const half_t* W, long ldw, int M, int N, int K, const Epi& epi, hipStream_t stream,
                                      int batch = 1, long bsA = 0, long bsW = 0, long bsC = 0) {
+  if (!asrc_fits(asrc, 0)) return LFM_ERR_SHAPE;
   if (M <= 0 || N <= 0 || K <= 0 || (K % G256N_BK) != 0 || (N % 4) != 0) return LFM_ERR_SHAPE;
   if ((ldw % 8) != 0 || ((uintptr_t)W & 15)) return LFM_ERR_ALIGN;
   const int tm = cdiv(M, G256_BM), tn = cdiv(N, G256N_BN);

@@ -34,18 +34,30 @@ struct ASrcRowMajor {
   long lda;
   int M;
   __device__ __forceinline__ void init(int bz, long bs) { A += (long)bz * bs; }
+  // a row is a 32-BIT element offset from the (uniform) base A + k0: an LDS-DMA address is then SGPR base + VGPR offset -- one register per row
+  // instead of a 64-bit pointer and no 64-bit VALU add per issue (the 256x256 kernels are register-bound).  M * lda < 2^31 (checked at launch).
   struct Row {
-    const half_t* p;
+    unsigned off;
   };
   __device__ __forceinline__ Row row(int m) const {
     Row r;
-    r.p = A + (long)(m < M ? m : M - 1) * lda;
+    r.off = (unsigned)((m < M ? m : M - 1) * (int)lda);
     return r;
   }
   int k0;
   __device__ __forceinline__ void begin_tile(int kt, int bk) { k0 = kt * bk; }
-  __device__ __forceinline__ const half_t* ptr(const Row& r, int koff) const { return r.p + k0 + koff; }
+  __device__ __forceinline__ const half_t* ptr(const Row& r, int koff) const { return (A + k0) + (r.off + (unsigned)koff); }
+  bool fits() const { return (long)M * lda < (1L << 31); }
 };
+// A sources with addressing limits say so through fits(); every launcher asks
+template <class ASrc>
+static inline auto asrc_fits(const ASrc& a, int) -> decltype(a.fits()) {
+  return a.fits();
+}
+template <class ASrc>
+static inline bool asrc_fits(const ASrc&, long) {
+  return true;
+}
 
 // ------------------------------------------------------------------ epilogues
 // Two-phase so the interior-tile path can issue ALL its loads before the first store (the compiler
@@ -621,6 +633,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(ASrc asrc, const half_t
 template <class ASrc, class Epi>
 static inline int launch_gemm_tn(const ASrc& asrc, const half_t* W, long ldw, int M, int N, int K, const Epi& epi,
                                  hipStream_t stream, int batch = 1, long bsA = 0, long bsW = 0, long bsC = 0) {
+  if (!asrc_fits(asrc, 0)) return LFM_ERR_SHAPE;
   if (M <= 0 || N <= 0 || K <= 0 || (K % GEMM_BK) != 0 || (N % 4) != 0) return LFM_ERR_SHAPE;
   if ((ldw % 8) != 0 || ((uintptr_t)W & 15)) return LFM_ERR_ALIGN;
   const int tm = cdiv(M, GEMM_BM), tn = cdiv(N, GEMM_BN);

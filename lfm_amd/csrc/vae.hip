@@ -334,20 +334,26 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict_
     o[3] = q[1];
   }
 }
-__global__ void gn_finish_kernel(const float* __restrict__ part, float* __restrict__ stats, int slabs, int C, int total) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (n, g)
+// one WAVE per (image, group): lane l folds slabs l, l + 64, ... in order, then a fixed-tree wave sum (deterministic).  (One thread per
+// (image, group) walking all slabs serially took 75 us once the convolution epilogues started to deliver 512 slabs per image.)
+__global__ __launch_bounds__(256) void gn_finish_kernel(const float* __restrict__ part, float* __restrict__ stats, int slabs, int C, int total) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;  // (n, g)
   if (i >= total) return;
   const int n = i >> 5, g = i & 31, hpg = C / 128;  // half-octets per group = (C/32)/4
   float sum = 0.f, sq = 0.f;
-  for (int b = 0; b < slabs; ++b) {
+  for (int b = lane; b < slabs; b += 64) {
     const float* p = part + (((long)n * slabs + b) * (C / 4) + g * hpg) * 2;
     for (int h = 0; h < hpg; ++h) {
       sum += p[2 * h];
       sq += p[2 * h + 1];
     }
   }
-  stats[(long)i * 2] = sum;
-  stats[(long)i * 2 + 1] = sq;
+  sum = wave_sum(sum);
+  sq = wave_sum(sq);
+  if (lane == 0) {
+    stats[(long)i * 2] = sum;
+    stats[(long)i * 2 + 1] = sq;
+  }
 }
 
 template <bool SILU>
@@ -459,7 +465,7 @@ static int gn(const half_t* x, half_t* y, float* stats, float* part, const float
     hipLaunchKernelGGL(gn_stats_kernel, dim3(slabs, n), dim3(256), 0, st, x, part, HW, C, ppb);
     LFM_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(gn_finish_kernel, dim3(cdiv(n * 32, 64)), dim3(64), 0, st, part, stats, slabs, C, n * 32);
+  hipLaunchKernelGGL(gn_finish_kernel, dim3(cdiv(n * 32, 4)), dim3(256), 0, st, part, stats, slabs, C, n * 32);
   LFM_CHECK_LAUNCH();
   const long total8 = (long)n * HW * C / 8;
   if (silu) hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(cdiv(total8, 256)), dim3(256), 0, st, x, y, stats, g, b, HW, C, total8);
