@@ -32,11 +32,11 @@ sys.path.insert(0, ROOT)
 MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense fp16/bf16 (MI355X_MICROARCH.md)
 CONFIG3_FIELD_GAIN = 100.0  # output-layer scale of config 3's synthetic field (see --field-gain)
 
-# L2-miss traffic of the dominant GEMM of config 2 (fc1 + GELU, M 16384 x N 4096 x K 1024) per launch, from separate rocprofv3 PMC
-# passes of the shipped kernel: FETCH_SIZE x 2 (gfx950 correction for 16-B-per-lane streams, MI355X_MICROARCH.md) + WRITE_SIZE, KiB.
-# These are fabric-side request counters: Infinity-Cache hits are INCLUDED (the whole working set of this GEMM fits the 256 MiB cache),
-# so this is an upper bound on HBM bytes, not HBM bytes.  Source file named in `traffic_source`.
-FC1_TRAFFIC = {"fetch_kib": 99674.2, "write_kib": 133120.0, "source": "profiles/r02_gemm_pmc.txt (fc1_fetch / fc1_write passes)"}
+# L2-miss traffic of the dominant GEMM of config 2 (fc1: M 16384 x N 4096 x K 1024, folded-LayerNorm + GELU epilogue) per launch, from separate
+# rocprofv3 PMC passes of the shipped kernel IN SITU (inside DiT-L/2 batch-64 forwards, tools/profile_round.sh): FETCH_SIZE x 2 (gfx950 correction
+# for 16-B-per-lane streams, MI355X_MICROARCH.md) + WRITE_SIZE, KiB.  These are fabric-side request counters: Infinity-Cache hits are INCLUDED (the
+# whole working set of this GEMM fits the 256 MiB cache), so this is an upper bound on HBM bytes, not HBM bytes.  Source file named in `traffic_source`.
+FC1_TRAFFIC = {"fetch_kib": 99343.1, "write_kib": 131136.0, "source": "profiles/r03_final_pmc_in_situ.txt (EpiModGeluF16: fetch / write passes)"}
 
 
 def parse():
@@ -241,7 +241,8 @@ def build_workload(a, dev, rank):
 
 
 def roofline_dit(model, lat, rows, dev):
-    """Dominant kernel of the DiT configurations: the fc1 MFMA GEMM + GELU epilogue (gemm256h_tn_kernel<ASrcRowMajor, EpiBiasGeluF16>).
+    """Dominant kernel of the DiT configurations: the fc1 MFMA GEMM + GELU epilogue (gemm256h_tn_kernel<ASrcRowMajor, EpiModGeluF16> when the
+    LayerNorm-modulate is folded into the GEMM epilogues -- every chip-filling batch -- else <.., EpiBiasGeluF16>).
     Timed LIVE and IN SITU: eager forwards of the real model on the solver's latents with one HIP event pair recorded around every
     block's fc1 launch on the launching stream (lfm_profile_fc1; a captured graph cannot be bracketed)."""
     import ctypes as C
@@ -268,7 +269,8 @@ def roofline_dit(model, lat, rows, dev):
     ach = 2.0 * M * H * D / dur / 1e12
     r = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
          "algorithmic_bytes": 2.0 * (M * D + H * D + M * H), "algorithmic_flop": 2.0 * M * H * D,
-         "kernel": "gemm256h_tn_kernel<ASrcRowMajor,EpiBiasGeluF16> (DiT fc1 + GELU)", "shape": {"M": M, "N": H, "K": D}, "avg_launch_us": dur * 1e6,
+         "kernel": "gemm256h_tn_kernel<ASrcRowMajor,EpiModGeluF16 | EpiBiasGeluF16> (DiT fc1: folded-LayerNorm correction + bias + GELU epilogue)",
+         "shape": {"M": M, "N": H, "K": D}, "avg_launch_us": dur * 1e6,
          "launches_timed": len(durs)}
     if (M, H, D) == (16384, 4096, 1024):
         r["traffic"] = (2 * FC1_TRAFFIC["fetch_kib"] + FC1_TRAFFIC["write_kib"]) * 1024

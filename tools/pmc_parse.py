@@ -7,14 +7,14 @@ for path in sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True))
     acc = collections.defaultdict(list); dur = collections.defaultdict(dict)
     for r in csv.DictReader(open(path)):
         if sub not in r["Kernel_Name"]: continue
-        key = (r["Kernel_Name"][:40], r["Grid_Size"])
+        key = (r["Kernel_Name"][:80], r["Grid_Size"])
         acc[(key, r["Counter_Name"])].append(float(r["Counter_Value"]))
         dur[key][r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     for key in dur:
         ds = list(dur[key].values())[1:] or list(dur[key].values())
         us = sum(ds) / len(ds)
         out = {c: sum(v[1:] or v) / len(v[1:] or v) for (k, c), v in acc.items() if k == key}
-        line = f"{path.split('/')[-2]:>10s} {key[0][:28]} grid={key[1]:>8s} n={len(ds)} avg_us={us:8.1f}"
+        line = f"{path.split('/')[-2]:>10s} {key[0][:78]} grid={key[1]:>8s} n={len(ds)} avg_us={us:8.1f}"
         if "GRBM_GUI_ACTIVE" in out: line += f" clk={out['GRBM_GUI_ACTIVE'] / 8 / us / 1e3:5.2f}GHz"
         print(line)
         for c, v in sorted(out.items()):
