@@ -136,6 +136,9 @@ int lfm_set_option(int key, int value);
 int lfm_gemm_trace_read(unsigned long long* host_out, int n_per_group);
 /* Measurement only: s_memtime stamps of the attention kernel's trace build (select flags 33554432 | 67108864; slot map in csrc/attention_kernel.h). */
 int lfm_attention_trace_read(unsigned long long* host_out, int n);
+/* Measurement only (LFM_MEASURE builds, same trace build): per attention workgroup {HW_ID | XCC_ID << 32, start, loads landed, end} -- which CU it ran on
+ * and when; host_out receives 4 x n_wg values (n_wg <= 2048). */
+int lfm_attention_wg_trace_read(unsigned long long* host_out, int n_wg);
 int lfm_profile_fc1_read(float* host_ms_out, int max_n);
 
 /* A fp16 [M,D] = LayerNorm(X fp32 [M,D], eps 1e-6, no affine) * (1 + scale[img]) + shift[img]
