@@ -413,8 +413,12 @@ __device__ __forceinline__ void g256h_epilogue(f32x4_t (&acc)[8][4], char* smem,
 // keeps the matrix pipe at 62 % -- a phase is 256 + L, not 512.  Tried on that evidence and NOT kept: a software-pipelined loop in which every wave
 // issues the next step's six reads and its two LDS-DMAs between its own MFMAs (in-place refill of the A fragments, one counted lgkmcnt(5) per group
 // of four MFMAs; bit-identical results).  With both wave groups on the same instruction stream all eight waves hit the LDS-DMA issue together and
-// the pipe starved (fc2 122 vs 116 us); staggering the groups needs two copies of the loop, which the register allocator could not fit in 256
-// VGPRs (136-168 B of scratch, 180+ us) -- the structure is right, it wants hand-allocated registers.  Kept from it: ASrcRowMajor rows as 32-bit
+// the pipe starved (fc2 122 vs 116 us); staggering the groups with two copies of the loop did not fit the register allocator's 256 VGPRs (136-168 B
+// of scratch, 180+ us); staggering only the LDS-DMA issue behind a uniform branch (one loop copy, 44 B of scratch) was as slow as un-staggered.  The
+// same ablation on the pipelined loop (profiles/r03_mainloop_ablation_incl_pipelined.txt) settles it: its bare MFMA + waits + barriers skeleton runs
+// in 69.6 us, the loop in 116.3, without the LDS-DMAs in 92.4 -- reads and DMAs cost as much BETWEEN the MFMAs as they do in a LOAD part of their
+// own (~30 cycles of the issuing wave per ds_read_b128, 60-185 per LDS-DMA, and the partner wave does not win that time back).  With a 128x64 wave
+// tile the loop needs 0.375 fragment reads and 0.125 LDS-DMAs per MFMA; only a larger wave tile (fewer operand bytes per MFMA) changes that.  Kept from it: ASrcRowMajor rows as 32-bit
 // offsets from a uniform base (SGPR base + VGPR offset LDS-DMAs), which took this kernel from 256 VGPRs + 12 B of scratch to 252 VGPRs and none.
 // ABL (LFM_MEASURE builds only; results are garbage, timings are the point): 1 = no LDS-DMA after the prologue, 2 = no fragment reads,
 // 3 = neither (the bare MFMA stream + barriers), 4 = static priority (s_setprio 1 for the second wave group, no per-phase flips),
