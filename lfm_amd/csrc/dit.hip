@@ -1160,10 +1160,14 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
       if (rc) return rc;
     }
   }
+  bool a_ready = false;  // latency mode: the previous split-K finish already wrote this LayerNorm's output
   for (int i = 0; i < (fold ? 0 : s->depth); ++i) {
     const float* mod = ws.mod + (long)i * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
-    rc = ln_modulate_launch(ws.X, ws.A, M, D, T, mod, mod + D, mstride, st);
-    if (rc) return rc;
+    if (!a_ready) {
+      rc = ln_modulate_launch(ws.X, ws.A, M, D, T, mod, mod + D, mstride, st);
+      if (rc) return rc;
+    }
+    a_ready = false;
     const EpiQKV e_qkv = EpiQKV::make(Qb, Kb, Vb, w->qkv_b + (size_t)i * 3 * D, D, D / s->heads, T);
     rc = launch_gemm_splitk(ws.A, D, (const half_t*)w->qkv_w + (size_t)i * 3 * D * D, D, M, 3 * D, D, e_qkv, ws.slab, ws.slab_bytes, st);
     if (rc == 1) rc = launch_gemm_auto(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->qkv_w + (size_t)i * 3 * D * D, D, M, 3 * D, D, e_qkv, st);
@@ -1171,10 +1175,14 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
     rc = attention_launch(Qb, Kb, Vb, ws.A, B, s->heads, D / s->heads, T, st);
     if (rc) return rc;
     const EpiGateResidF32 e_proj{ws.X, D, w->proj_b + (size_t)i * D, mod + 2 * D, mstride, T};
-    rc = launch_gemm_splitk(ws.A, D, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D, e_proj, ws.slab, ws.slab_bytes, st);
-    if (rc == 1) rc = launch_gemm_auto(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D, e_proj, st);
-    if (rc) return rc;
-    rc = ln_modulate_launch(ws.X, ws.A, M, D, T, mod + 3 * D, mod + 4 * D, mstride, st);
+    // small M: split-K whose finish kernel is also the LayerNorm-modulate in front of fc1 (its input ws.A is consumed by the slab GEMM before the finish writes it)
+    rc = launch_gemm_splitk_resid_ln(ws.A, D, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D, e_proj, ws.A, mod + 3 * D, mod + 4 * D, mstride, ws.slab,
+                                     ws.slab_bytes, st);
+    if (rc == 1) {
+      rc = launch_gemm_auto(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D, e_proj, st);
+      if (rc) return rc;
+      rc = ln_modulate_launch(ws.X, ws.A, M, D, T, mod + 3 * D, mod + 4 * D, mstride, st);
+    }
     if (rc) return rc;
     const bool prof = g_prof_on && g_prof_count < LFM_PROF_MAX;
     if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_count], st);
@@ -1184,7 +1192,10 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
     if (rc) return rc;
     if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_count++ + 1], st);
     const EpiGateResidF32 e_fc2{ws.X, D, w->fc2_b + (size_t)i * D, mod + 5 * D, mstride, T};
-    rc = launch_gemm_splitk(ws.QKVH, H, (const half_t*)w->fc2_w + (size_t)i * D * H, H, M, D, H, e_fc2, ws.slab, ws.slab_bytes, st);
+    const bool more = i + 1 < s->depth;  // ... and the one in front of the NEXT block's qkv (its shift_msa / scale_msa)
+    rc = launch_gemm_splitk_resid_ln(ws.QKVH, H, (const half_t*)w->fc2_w + (size_t)i * D * H, H, M, D, H, e_fc2, more ? ws.A : (half_t*)nullptr, mod + 6 * D, mod + 7 * D,
+                                     mstride, ws.slab, ws.slab_bytes, st);
+    if (rc == LFM_OK) a_ready = more;
     if (rc == 1) rc = launch_gemm_auto(ASrcRowMajor{ws.QKVH, H, M, 0}, (const half_t*)w->fc2_w + (size_t)i * D * H, H, M, D, H, e_fc2, st);
     if (rc) return rc;
   }

@@ -666,6 +666,60 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
   epi.store(m, n, v, epi.load(m, n));
 }
 
+// Latency mode (round 3): the finish of a split-K gated-residual GEMM (proj, fc2) owns WHOLE rows when one block takes one row, so it can also be
+// the LayerNorm-modulate that follows (DiT.py:129-130): X' = X + gate (sum of slabs + bias), written back, then A = fp16(LN(X') (1 + scale) + shift)
+// for the next GEMM -- exact two-pass statistics, the row stays in registers.  Removes both ln_modulate launches of a block at batch 1 (a launch +
+// one dependent HBM round trip each at this size).  Block = 256 threads, thread t owns columns 4 t + 1024 j.
+#define SPLITK_LN_MAXJ 2  // N <= 2048
+static __global__ __launch_bounds__(256) void splitk_finish_resid_ln_kernel(const float* __restrict__ slabs, int S, long slice_stride, int N, float* __restrict__ X,
+                                                                     long ldx, const float* __restrict__ bias, const float* __restrict__ gate,
+                                                                     long gate_stride, int tokens, half_t* __restrict__ A, const float* __restrict__ shift,
+                                                                     const float* __restrict__ scale, long mod_stride) {
+  __shared__ float red[4];
+  const int m = blockIdx.x, img = m / tokens, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  f32x4 x[SPLITK_LN_MAXJ];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < SPLITK_LN_MAXJ; ++j) {
+    const int n = threadIdx.x * 4 + 1024 * j;
+    x[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (n < N) {
+      const float* p = slabs + (long)m * N + n;
+      f32x4 v = *(const f32x4*)p;
+      for (int q = 1; q < S; ++q) v += *(const f32x4*)(p + (long)q * slice_stride);
+      x[j] = *(const f32x4*)(X + (long)m * ldx + n) + *(const f32x4*)(gate + (long)img * gate_stride + n) * (v + *(const f32x4*)(bias + n));
+      *(f32x4*)(X + (long)m * ldx + n) = x[j];
+      s += (x[j].x + x[j].y) + (x[j].z + x[j].w);
+    }
+  }
+  if (!A) return;
+  s = wave_sum(s);
+  if (lane == 0) red[wv] = s;
+  __syncthreads();
+  const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)N;
+  __syncthreads();
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < SPLITK_LN_MAXJ; ++j)
+    if (threadIdx.x * 4 + 1024 * j < N) {
+      x[j] -= mean;
+      q += (x[j].x * x[j].x + x[j].y * x[j].y) + (x[j].z * x[j].z + x[j].w * x[j].w);
+    }
+  q = wave_sum(q);
+  if (lane == 0) red[wv] = q;
+  __syncthreads();
+  const float rstd = rsqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)N + 1e-6f);
+#pragma unroll
+  for (int j = 0; j < SPLITK_LN_MAXJ; ++j) {
+    const int n = threadIdx.x * 4 + 1024 * j;
+    if (n < N) {
+      const f32x4 o = x[j] * rstd * (1.0f + *(const f32x4*)(scale + (long)img * mod_stride + n)) + *(const f32x4*)(shift + (long)img * mod_stride + n);
+      const half4_t h = {(half_t)o.x, (half_t)o.y, (half_t)o.z, (half_t)o.w};
+      *(half4_t*)(A + (long)m * N + n) = h;
+    }
+  }
+}
+
 // slices for a GEMM of this size: only when the 128x128 tiling leaves most of the chip idle; slices >= 128 deep; slabs fit
 static inline int splitk_slices(int M, int N, int K, size_t slab_bytes) {
   const long tiles = (long)cdiv(M, 128) * cdiv(N, 128);
@@ -697,4 +751,22 @@ template <class Epi>
 static inline int launch_gemm_splitk(const half_t* A, long lda, const half_t* W, long ldw, int M, int N, int K, const Epi& epi, float* slab,
                                      size_t slab_bytes, hipStream_t stream) {
   return launch_gemm_splitk_src(ASrcRowMajor{A, lda, M, 0}, W, ldw, M, N, K, epi, slab, slab_bytes, stream);
+}
+
+// split-K gated-residual GEMM whose finish is also the following LayerNorm-modulate (A_out may be null: plain finish).  Returns 1 if split-K does
+// not apply to the shape (the caller takes the ordinary GEMM + ln_modulate path).
+static inline int launch_gemm_splitk_resid_ln(const half_t* A, long lda, const half_t* W, long ldw, int M, int N, int K, const EpiGateResidF32& e,
+                                              half_t* A_out, const float* shift, const float* scale, long mod_stride, float* slab, size_t slab_bytes,
+                                              hipStream_t stream) {
+  if (!slab || lfm_gemm_selected_v1_ok() == 0 || N > 1024 * SPLITK_LN_MAXJ || (N % 4) != 0) return 1;
+  const int S = splitk_slices(M, N, K, slab_bytes);
+  if (S < 2) return 1;
+  const int ks = K / S;
+  const long stride = (long)M * N;
+  int rc = launch_gemm_tn(ASrcRowMajor{A, lda, M, 0}, W, ldw, M, N, ks, EpiSlabF32{slab, (long)N, stride}, stream, S, ks, ks, 0);
+  if (rc) return rc;
+  hipLaunchKernelGGL(splitk_finish_resid_ln_kernel, dim3(M), dim3(256), 0, stream, slab, S, stride, N, e.X, e.ldx, e.bias, e.gate, e.gate_stride, e.tokens, A_out,
+                     shift, scale, mod_stride);
+  LFM_CHECK_LAUNCH();
+  return LFM_OK;
 }

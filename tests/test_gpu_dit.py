@@ -311,6 +311,8 @@ def test_dit_patch4_matches_reference_golden(dev, golden_dir):
     ("DiT-B/2", 6, dict(num_classes=1000, label_dropout=0.1)),   # config 4 shape (class-conditional)
     ("DiT-L/2", 3, dict(num_classes=1, label_dropout=0.0)),      # config 2 shape
     ("DiT-S/2", 1, dict(num_classes=1, label_dropout=0.0)),      # batch 1 (--measure_time mode): a single 256-row tile
+    ("DiT-L/2", 1, dict(num_classes=1, label_dropout=0.0)),      # the reference's --measure_time configuration: split-K GEMMs whose finish is also the LayerNorm
+    ("DiT-XL/2", 2, dict(num_classes=1000, label_dropout=0.1)),  # 1152-wide rows (two column groups per thread in the fused finish), one conditioning row per image
     ("DiT-S/2", 65, dict(num_classes=10, label_dropout=0.1)),    # ragged everywhere: 65 M-tiles, N = 1152/384 not multiples of 256
 ])
 def test_dit_matches_oracle_fullsize(dev, name, batch, kw):
