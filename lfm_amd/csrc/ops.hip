@@ -4,6 +4,7 @@
 // general GroupNorm(32) with optional FiLM scale-shift and SiLU, channel concat, small-T attention, timestep embedding.
 #include "../../include/lfm_hip.h"
 #include "gemm_dispatch.h"
+#include "conv_halo_kernel.h"
 
 // ------------------------------------------------------------------ implicit-GEMM A source, NHWC fp16, 3x3, pad 1
 // MODE 0: same size.  MODE 1: input is nearest-2x upsampled on the fly (Upsample, unet.py:73-100).
@@ -156,6 +157,12 @@ extern "C" int lfm_conv3x3_f16_ws(const void* in, const void* w, const float* bi
   const half_t* wi = (const half_t*)w;
   const half_t* xi = (const half_t*)in;
   float* ws = (float*)workspace;
+  // plain and upsample-fused 3x3 convolutions on 16-aligned maps that fill the chip: the halo-tiled direct kernel (conv_halo_kernel.h);
+  // flag 8388608: the implicit GEMM instead (A/B and parity tests)
+  if (mode != 2 && lfm_gemm_selected() == 0 && !(lfm_gemm_debug_flags() & 8388608) && !(((uintptr_t)out | (uintptr_t)resid) & 15)) {
+    const int rc = mode == 1 ? launch_conv3x3_halo<1>(xi, z, wi, N, H, W, Cin, Cout, epi, st) : launch_conv3x3_halo<0>(xi, z, wi, N, H, W, Cin, Cout, epi, st);
+    if (rc != 1) return rc;
+  }
   if (mode == 0) return conv3x3_mode<0>(xi, z, wi, epi, H, W, Cin, Cout, M, ws, workspace_bytes, st);
   if (mode == 1) return conv3x3_mode<1>(xi, z, wi, epi, H, W, Cin, Cout, M, ws, workspace_bytes, st);
   return conv3x3_mode<2>(xi, z, wi, epi, H, W, Cin, Cout, M, ws, workspace_bytes, st);

@@ -6,6 +6,7 @@
 // by the per-lane LDS-DMA source address.  GroupNorm statistics / apply+SiLU are bandwidth-bound side kernels.
 #include "../../include/lfm_hip.h"
 #include "gemm_dispatch.h"
+#include "conv_halo_kernel.h"
 
 // ------------------------------------------------------------------ implicit-GEMM A source: 3x3 conv, pad 1, NHWC
 // UPS=1: the convolution runs on the nearest-2x upsampled image (diffusers Upsample2D) without materialising it.
@@ -159,7 +160,8 @@ struct EpiConvStatsF16 {
     s1 += (f4 + f5) + (f6 + f7);
     q1 += (f4 * f4 + f5 * f5) + (f6 * f6 + f7 * f7);
   }
-  __device__ __forceinline__ void finish_tile(int m0, int n0, int g, int wn, int lane) const {
+  // fold the eight lanes that own the same columns and write the wave's slot: columns ncol0 + 8 (lane & 7) .. + 7 of slab `slab` of image `img`
+  __device__ __forceinline__ void finish_slab(int img, int slab, int ncol0, int lane) const {
     float a = s0, b = q0, c = s1, d = q1;
 #pragma unroll
     for (int o = 8; o < 64; o <<= 1) {  // the eight lanes lane & 7, + 8, .., + 56 own the same columns
@@ -169,10 +171,13 @@ struct EpiConvStatsF16 {
       d += __shfl_xor(d, o, 64);
     }
     if (lane < 8) {
-      const int img = m0 / HW, slab = ((m0 - img * HW) >> 8) * 2 + g;
-      float* o = part + (((long)img * slabs + slab) * (ldc >> 2) + ((n0 + wn * 64 + lane * 8) >> 2)) * 2;
+      float* o = part + (((long)img * slabs + slab) * (ldc >> 2) + ((ncol0 + lane * 8) >> 2)) * 2;
       *(f32x4*)o = (f32x4){a, b, c, d};
     }
+  }
+  __device__ __forceinline__ void finish_tile(int m0, int n0, int g, int wn, int lane) const {
+    const int img = m0 / HW;
+    finish_slab(img, ((m0 - img * HW) >> 8) * 2 + g, n0 + wn * 64, lane);
   }
 };
 
@@ -482,6 +487,20 @@ static int conv3(const half_t* in, const half_t* w, const float* b, const half_t
   const int M = n * H * W;
   if (stat_slabs) *stat_slabs = 0;
   const int HW = H * W, kern = gemm_auto_choice(M, Cout, 9 * Cin);
+  // every 3x3 convolution on a 16-aligned map: the halo-tiled direct kernel (conv_halo_kernel.h; 1.1-1.2 PFLOP/s where the implicit GEMM reaches
+  // 0.65-1.05, profiles/r03_halo_conv_probe.txt); flag 8388608: the implicit GEMM instead (A/B)
+  if (lfm_gemm_selected() == 0 && !(((uintptr_t)out | (uintptr_t)resid) & 15) && !(lfm_gemm_debug_flags() & 8388608)) {
+    int rc;
+    if (part && stat_slabs && (HW % 256) == 0 && !(lfm_gemm_debug_flags() & 4194304)) {
+      EpiConvStatsF16 es{out, Cout, b, resid, part, HW, 2 * (HW / 256), 0.f, 0.f, 0.f, 0.f};
+      rc = ups ? launch_conv3x3_halo<1>(in, zeros, w, n, H, W, Cin, Cout, es, st) : launch_conv3x3_halo<0>(in, zeros, w, n, H, W, Cin, Cout, es, st);
+      if (rc == 0) *stat_slabs = es.slabs;
+    } else {
+      EpiConvF16 ep{out, Cout, b, resid};
+      rc = ups ? launch_conv3x3_halo<1>(in, zeros, w, n, H, W, Cin, Cout, ep, st) : launch_conv3x3_halo<0>(in, zeros, w, n, H, W, Cin, Cout, ep, st);
+    }
+    if (rc != 1) return rc;
+  }
   if (part && stat_slabs && (HW % 256) == 0 && (kern == 4 || kern == 5) && (Cout % (kern == 4 ? 128 : 256)) == 0 && (Cout % 128) == 0 &&
       !(((uintptr_t)out | (uintptr_t)resid) & 15) && !(lfm_gemm_debug_flags() & (1024 | 4194304))) {  // flag 4194304: the separate statistics pass (A/B)
     *stat_slabs = 2 * (HW / 256);

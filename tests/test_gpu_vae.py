@@ -72,3 +72,46 @@ def test_vae_encode_matches_oracle(N, S, chunk):
     img = vae.decode(dist.mode()).sample
     ref_img = vae_ref.vae_decode(sd, ref[:, :4])
     assert rel_l2(img, ref_img) < 1e-2
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,mode", [(2, 48, 48, 128, 128, 0), (2, 32, 64, 64, 128, 0), (1, 64, 32, 256, 256, 0), (3, 16, 16, 192, 128, 0),
+                                                  (2, 32, 32, 128, 384, 1), (1, 96, 32, 64, 128, 1)])
+def test_halo_conv_matches_torch_and_the_implicit_gemm(N, H, W, Cin, Cout, mode):
+    """conv_halo_kernel.h (the VAE decoder's 128-channel 3x3 convolutions) through the C ABI: against the fp32 torch convolution of the same
+    fp16-rounded operands, and against the implicit-GEMM kernel on identical inputs (same products, another summation order: within 2 fp16
+    ulps of the output range).  Shapes cover border and interior tiles, the XCD tile remap on and off, 2 / 4 / 6 / 8 channel quarters,
+    one to three 128-channel output blocks, with and without the fused residual; mode 1 = the nearest-2x upsample fused into the gather
+    (H, W are the output size)."""
+    import torch.nn.functional as F
+
+    from lfm_amd import hip
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(N * 1000 + H + Cin)
+    L = hip.lib()
+    x = torch.randn(N, Cin, H >> mode, W >> mode, generator=g).half()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).half()
+    b = torch.randn(Cout, generator=g) * 0.1
+    res = torch.randn(N, Cout, H, W, generator=g).half()
+    xin = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(dev)
+    bd = b.to(dev)
+    rd = res.permute(0, 2, 3, 1).contiguous().to(dev)
+
+    def run(flags, resid):
+        out = torch.full((N * H * W, Cout), float("nan"), dtype=torch.float16, device=dev)
+        hip.gemm_select(flags << 4)
+        try:
+            hip.check(L.lfm_conv3x3_f16(hip.ptr(xin), hip.ptr(wp), hip.ptr(bd), hip.ptr(resid), hip.ptr(out), N, H, W, Cin, Cout, mode,
+                                        hip.stream_ptr()), "conv")
+        finally:
+            hip.gemm_select(0)
+        return out.reshape(N, H, W, Cout).permute(0, 3, 1, 2).float().cpu()
+
+    xs = F.interpolate(x.float(), scale_factor=2, mode="nearest") if mode else x.float()
+    ref = F.conv2d(xs, w.float(), b, padding=1)
+    for resid, r in ((None, ref), (rd, ref + res.float())):
+        halo, gemm = run(16777216, resid), run(8388608, resid)  # flags: the halo kernel at any size / the implicit GEMM
+        assert torch.isfinite(halo).all()
+        assert rel_l2(halo, r) < 1e-3
+        assert float((halo - gemm).abs().max()) <= 2 * 2.0 ** -10 * float(r.abs().max())
