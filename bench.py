@@ -309,7 +309,7 @@ def roofline_adm(B, dev):
     ach = 2.0 * M * Cout * K / dur / 1e12
     return {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
             "algorithmic_bytes": 2.0 * (M * Cin + Cout * K + M * Cout), "algorithmic_flop": 2.0 * M * Cout * K,
-            "kernel": "gemm256h_tn_kernel<ASrcConv<0>,EpiResidF16> (3x3 conv 256->256 at 64x64, implicit GEMM)", "shape": {"M": M, "N": Cout, "K": K},
+            "kernel": "conv3x3_halo_kernel<EpiResidF16,0> (3x3 conv 256->256 at 64x64, halo-tiled direct kernel)", "shape": {"M": M, "N": Cout, "K": K},
             "avg_launch_us": dur * 1e6, "launches_timed": 10}
 
 

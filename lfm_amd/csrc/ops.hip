@@ -124,11 +124,12 @@ static const half_t* zero_page() {
 // 32 tiles of 128x128 on 256 CUs, hundreds of K-tiles in sequence.  With a caller-provided workspace the K range is sliced over
 // blockIdx.y (fp32 slabs, summed in a fixed order by a finish kernel that applies the real epilogue -- deterministic), as for the
 // batch-1 DiT GEMMs.  workspace may be NULL (no split-K).
+#define CONV_SPLITK_MAX_TILES 128  // 8x8 maps at batch 32 x 1024 channels = 128 tiles: two slices fill the chip
 extern "C" size_t lfm_conv3x3_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
   const long M = (long)N * H * W;
   if (M <= 0 || Cout <= 0 || Cin <= 0) return 0;
   const long tiles = (long)cdiv(M, 128) * cdiv(Cout, 128);
-  if (tiles > 64) return 0;
+  if (tiles > CONV_SPLITK_MAX_TILES) return 0;
   int s = 1;
   while (tiles * (s * 2) <= 256 && (9L * Cin) / (s * 2) >= 128 && ((9L * Cin) / (s * 2)) % 64 == 0) s *= 2;
   return s < 2 ? 0 : (size_t)s * M * Cout * 4;
@@ -138,7 +139,7 @@ template <int MODE>
 static int conv3x3_mode(const half_t* xi, const half_t* z, const half_t* wi, const EpiResidF16& epi, int H, int W, int Cin, int Cout, int M, float* ws,
                         size_t ws_bytes, hipStream_t st) {
   ASrcConv<MODE> a{xi, z, H, W, Cin, M, 0, 0, 0, 0};
-  const int rc = launch_gemm_splitk_src(a, wi, 9L * Cin, M, Cout, 9 * Cin, epi, ws, ws_bytes, st);
+  const int rc = launch_gemm_splitk_src(a, wi, 9L * Cin, M, Cout, 9 * Cin, epi, ws, ws_bytes, st, CONV_SPLITK_MAX_TILES);
   if (rc != 1) return rc;
   return launch_gemm_auto(a, wi, 9L * Cin, M, Cout, 9 * Cin, epi, st);
 }
@@ -303,15 +304,24 @@ __global__ __launch_bounds__(256) void gn_stats_rows_kernel(const half_t* __rest
   float s[2] = {0.f, 0.f}, q[2] = {0.f, 0.f};
   if (prow < rows) {
     const half_t* base = x + (long)n * HW * C + oct * 8;
-    for (int p = p0 + prow; p < p1; p += rows) {
-      const half8_t v = *(const half8_t*)(base + (long)p * C);
+    auto add = [&](const half8_t& v) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float f = (float)v[j];
         s[j >> 2] += f;
         q[j >> 2] += f * f;
       }
+    };
+    int p = p0 + prow;
+    for (; p + 3 * rows < p1; p += 4 * rows) {  // four independent loads in flight (one per iteration ran at 1.5 TB/s), summed in pixel order
+      const half8_t v0 = *(const half8_t*)(base + (long)p * C), v1 = *(const half8_t*)(base + (long)(p + rows) * C);
+      const half8_t v2 = *(const half8_t*)(base + (long)(p + 2 * rows) * C), v3 = *(const half8_t*)(base + (long)(p + 3 * rows) * C);
+      add(v0);
+      add(v1);
+      add(v2);
+      add(v3);
     }
+    for (; p < p1; p += rows) add(*(const half8_t*)(base + (long)p * C));
   }
   red[0][tid] = s[0];
   red[1][tid] = s[1];
@@ -495,7 +505,7 @@ extern "C" int lfm_groupnorm_f16(const void* x, void* y, const float* gamma, con
   float* ab = (float*)((char*)scratch + gn_part_bytes(N, C));
   int slabs, rows;
   if (cpg % 4 == 0 && C / 8 <= 256) {
-    int ppb = HW >= 4096 ? 512 : (HW >= 256 ? 64 : HW);
+    int ppb = HW >= 4096 ? 128 : (HW >= 256 ? 64 : HW);  // (512 pixels per block at 64x64 maps left 256 blocks: one per CU)
     if (cdiv(HW, ppb) > GN_MAX_SLABS) ppb = cdiv(HW, GN_MAX_SLABS);
     slabs = cdiv(HW, ppb);
     rows = 1;
