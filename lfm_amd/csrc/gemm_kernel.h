@@ -721,13 +721,14 @@ static __global__ __launch_bounds__(256) void splitk_finish_resid_ln_kernel(cons
 }
 
 // slices for a GEMM of this size: only when the 128x128 tiling leaves most of the chip idle; slices >= 128 deep; slabs fit
-// max_tiles: the 3x3 convolutions of the UNets' 8x8 maps (128 tiles, K = 9216 .. 18432) also split (two slices: 84 -> ~50 us each on the celeb512
-// UNet); the DiT linears keep 64 (their K is 1024 .. 4096: the finish kernel would eat the gain).
-static inline int splitk_slices(int M, int N, int K, size_t slab_bytes, int max_tiles = 64) {
+// max_tiles / max_wg: the 3x3 convolutions of the UNets' 16x16 maps (celeb512 at batch 32: 8192 rows x 512 columns = 256 tiles = ONE four-wave
+// workgroup per CU, K = 4608 .. 9216) also split, into two slices = two workgroups per CU (90 us each unsplit); the DiT linears keep 64 / 256
+// (their K is 1024 .. 4096: the finish kernel would eat the gain).
+static inline int splitk_slices(int M, int N, int K, size_t slab_bytes, int max_tiles = 64, int max_wg = 256) {
   const long tiles = (long)cdiv(M, 128) * cdiv(N, 128);
   if (tiles > max_tiles || (K % 128) != 0 || (N % 4) != 0) return 1;
   int s = 1;
-  while (tiles * (s * 2) <= 256 && K / (s * 2) >= 128 && (K / (s * 2)) % 64 == 0 && (size_t)(s * 2) * M * N * 4 <= slab_bytes) s *= 2;
+  while (tiles * (s * 2) <= max_wg && K / (s * 2) >= 128 && (K / (s * 2)) % 64 == 0 && (size_t)(s * 2) * M * N * 4 <= slab_bytes) s *= 2;
   return s;
 }
 
@@ -736,9 +737,9 @@ static inline int splitk_slices(int M, int N, int K, size_t slab_bytes, int max_
 // pointer; an implicit-GEMM convolution source starts its tap / channel walk there), W advances by ks columns.
 template <class ASrc, class Epi>
 static inline int launch_gemm_splitk_src(const ASrc& asrc, const half_t* W, long ldw, int M, int N, int K, const Epi& epi, float* slab,
-                                         size_t slab_bytes, hipStream_t stream, int max_tiles = 64) {
+                                         size_t slab_bytes, hipStream_t stream, int max_tiles = 64, int max_wg = 256) {
   if (!slab || lfm_gemm_selected_v1_ok() == 0) return 1;
-  const int S = splitk_slices(M, N, K, slab_bytes, max_tiles);
+  const int S = splitk_slices(M, N, K, slab_bytes, max_tiles, max_wg);
   if (S < 2) return 1;
   const int ks = K / S;
   const long stride = (long)M * N;

@@ -124,14 +124,15 @@ static const half_t* zero_page() {
 // 32 tiles of 128x128 on 256 CUs, hundreds of K-tiles in sequence.  With a caller-provided workspace the K range is sliced over
 // blockIdx.y (fp32 slabs, summed in a fixed order by a finish kernel that applies the real epilogue -- deterministic), as for the
 // batch-1 DiT GEMMs.  workspace may be NULL (no split-K).
-#define CONV_SPLITK_MAX_TILES 128  // 8x8 maps at batch 32 x 1024 channels = 128 tiles: two slices fill the chip
+#define CONV_SPLITK_MAX_TILES 256  // 16x16 maps at batch 32 x 512 channels = 256 tiles of 128x128: two slices = two workgroups per CU
+#define CONV_SPLITK_MAX_WG 512
 extern "C" size_t lfm_conv3x3_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
   const long M = (long)N * H * W;
   if (M <= 0 || Cout <= 0 || Cin <= 0) return 0;
   const long tiles = (long)cdiv(M, 128) * cdiv(Cout, 128);
   if (tiles > CONV_SPLITK_MAX_TILES) return 0;
   int s = 1;
-  while (tiles * (s * 2) <= 256 && (9L * Cin) / (s * 2) >= 128 && ((9L * Cin) / (s * 2)) % 64 == 0) s *= 2;
+  while (tiles * (s * 2) <= CONV_SPLITK_MAX_WG && (9L * Cin) / (s * 2) >= 128 && ((9L * Cin) / (s * 2)) % 64 == 0) s *= 2;
   return s < 2 ? 0 : (size_t)s * M * Cout * 4;
 }
 
@@ -139,7 +140,7 @@ template <int MODE>
 static int conv3x3_mode(const half_t* xi, const half_t* z, const half_t* wi, const EpiResidF16& epi, int H, int W, int Cin, int Cout, int M, float* ws,
                         size_t ws_bytes, hipStream_t st) {
   ASrcConv<MODE> a{xi, z, H, W, Cin, M, 0, 0, 0, 0};
-  const int rc = launch_gemm_splitk_src(a, wi, 9L * Cin, M, Cout, 9 * Cin, epi, ws, ws_bytes, st, CONV_SPLITK_MAX_TILES);
+  const int rc = launch_gemm_splitk_src(a, wi, 9L * Cin, M, Cout, 9 * Cin, epi, ws, ws_bytes, st, CONV_SPLITK_MAX_TILES, CONV_SPLITK_MAX_WG);
   if (rc != 1) return rc;
   return launch_gemm_auto(a, wi, 9L * Cin, M, Cout, 9 * Cin, epi, st);
 }
@@ -353,6 +354,7 @@ __global__ void gn_coef_kernel(const float* __restrict__ part, int slabs, int ro
   float sum = 0.f, sq = 0.f;  // every channel of a group folds the same slots in the same order: identical, deterministic statistics
   if (rows) {
     const int h0 = g * (cpg / 4), h1 = h0 + cpg / 4, Q = C / 4;
+#pragma unroll 4
     for (int b = 0; b < slabs; ++b) {
       const float* p = part + ((long)n * slabs + b) * Q * 2;
       for (int h = h0; h < h1; ++h) {
@@ -421,16 +423,26 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const half_t* __restrict_
   const int c0 = blockIdx.x * CW + oct * 8;         // first channel of this thread's octet
   const half_t* xb = x + (long)n * HW * C + c0;
   float s = 0.f, q = 0.f;
-  if (prow < rows)
-    for (int p = prow; p < HW; p += rows) {
-      const half8_t v = *(const half8_t*)(xb + (long)p * C);
+  if (prow < rows) {
+    auto add = [&](const half8_t& v) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float f = (float)v[j];
         s += f;
         q += f * f;
       }
+    };
+    int p = prow;
+    for (; p + 3 * rows < HW; p += 4 * rows) {  // four loads in flight per thread (the block is alone on its CU: latency, not bandwidth, bound it)
+      const half8_t v0 = *(const half8_t*)(xb + (long)p * C), v1 = *(const half8_t*)(xb + (long)(p + rows) * C);
+      const half8_t v2 = *(const half8_t*)(xb + (long)(p + 2 * rows) * C), v3 = *(const half8_t*)(xb + (long)(p + 3 * rows) * C);
+      add(v0);
+      add(v1);
+      add(v2);
+      add(v3);
     }
+    for (; p < HW; p += rows) add(*(const half8_t*)(xb + (long)p * C));
+  }
   red[0][tid] = s;
   red[1][tid] = q;
   __syncthreads();
@@ -463,8 +475,7 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const half_t* __restrict_
     }
   }
   half_t* yb = y + (long)n * HW * C + c0;
-  for (int p = prow; p < HW; p += rows) {
-    const half8_t v = *(const half8_t*)(xb + (long)p * C);
+  auto apply = [&](const half8_t& v, int p) {
     half8_t o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -473,7 +484,17 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const half_t* __restrict_
       o[j] = (half_t)f;
     }
     *(half8_t*)(yb + (long)p * C) = o;
+  };
+  int p = prow;
+  for (; p + 3 * rows < HW; p += 4 * rows) {
+    const half8_t v0 = *(const half8_t*)(xb + (long)p * C), v1 = *(const half8_t*)(xb + (long)(p + rows) * C);
+    const half8_t v2 = *(const half8_t*)(xb + (long)(p + 2 * rows) * C), v3 = *(const half8_t*)(xb + (long)(p + 3 * rows) * C);
+    apply(v0, p);
+    apply(v1, p + rows);
+    apply(v2, p + 2 * rows);
+    apply(v3, p + 3 * rows);
   }
+  for (; p < HW; p += rows) apply(*(const half8_t*)(xb + (long)p * C), p);
 }
 
 #define GN_MAX_SLABS 64  // pixel slabs per image: bounds the partial buffer independently of HW
@@ -505,7 +526,7 @@ extern "C" int lfm_groupnorm_f16(const void* x, void* y, const float* gamma, con
   float* ab = (float*)((char*)scratch + gn_part_bytes(N, C));
   int slabs, rows;
   if (cpg % 4 == 0 && C / 8 <= 256) {
-    int ppb = HW >= 4096 ? 128 : (HW >= 256 ? 64 : HW);  // (512 pixels per block at 64x64 maps left 256 blocks: one per CU)
+    int ppb = HW >= 4096 ? 256 : (HW >= 256 ? 64 : HW);  // (512 pixels per block at 64x64 maps left 256 blocks: one per CU; 128 made gn_coef's serial slab walk the longer kernel)
     if (cdiv(HW, ppb) > GN_MAX_SLABS) ppb = cdiv(HW, GN_MAX_SLABS);
     slabs = cdiv(HW, ppb);
     rows = 1;
@@ -671,9 +692,120 @@ __global__ __launch_bounds__(256) void attention_small_kernel(const half_t* __re
   }
 }
 
+// MFMA path for the shapes the big UNets use (T = 64 / 256 tokens = 8x8 / 16x16 maps, ch = 64 / 128 per head).  The VALU kernel above was written for
+// "T <= 64, FLOPs negligible"; the celeb512 UNet attends at 16x16 (T = 256, ch = 128: 4.3 GFLOP per call at batch 32) and spent 5 % of an evaluation there
+// (85-104 us per call = 45 TFLOP/s).  One workgroup = 64 queries of one (image, head), a wave = 16 queries:
+//   K [T][ch] and V^T [ch][T] of the head in LDS (padded rows; V is transposed while it is staged, two keys per dword);
+//   S^T = K Q^T on v_mfma_f32_16x16x32_f16 with K as the A operand: lane (q = lane >> 4, j = lane & 15) ends up with the scores of ONE query j
+//   at keys 16 tile + 4 q + r -- the whole softmax row of a query lives in four lanes (two xor-shuffles per reduction), and
+//   O^T = V^T P^T takes P straight from those registers as the B operand: the 8 k-slots of lane q in key step kt are keys 32 kt + 4 q + r and
+//   32 kt + 16 + 4 q + r, which is what the two 8-byte V^T reads of the A operand fetch.  No transposition of P, no cross-lane traffic for O;
+//   fp32 scores / softmax, P and V in fp16 (as the DiT attention kernel), 1 / sum applied to the fp32 accumulators.
+template <int CH, int T>
+__global__ __launch_bounds__(256) void attention_unet_mfma_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out, int heads, float scale) {
+  constexpr int KS = CH * 2 + 16, VS = T * 2 + 16;  // LDS row strides in bytes (16 B of padding: consecutive rows start 4 banks apart)
+  extern __shared__ __attribute__((aligned(16))) char smraw[];
+  char* Ks = smraw;            // [T][KS]
+  char* Vt = smraw + T * KS;   // [CH][VS]
+  const int head = blockIdx.x, n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int C = heads * CH, ldq = 3 * C;
+  const half_t* base = qkv + (long)n * T * ldq + head * 3 * CH;
+  // ---- stage K (16-byte chunks) and V^T (two keys x 8 channels per item -> eight dword writes)
+  for (int e = tid; e < T * (CH / 8); e += 256) {
+    const int t = e / (CH / 8), c8 = e - t * (CH / 8);
+    *(half8_t*)(Ks + t * KS + c8 * 16) = *(const half8_t*)(base + (long)t * ldq + CH + c8 * 8);
+  }
+  for (int e = tid; e < (T / 2) * (CH / 8); e += 256) {
+    const int tp = e % (T / 2), c8 = e / (T / 2);  // consecutive lanes: consecutive key pairs of one channel octet (conflict-free dword writes)
+    const half8_t v0 = *(const half8_t*)(base + (long)(2 * tp) * ldq + 2 * CH + c8 * 8);
+    const half8_t v1 = *(const half8_t*)(base + (long)(2 * tp + 1) * ldq + 2 * CH + c8 * 8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *(half2_t*)(Vt + (c8 * 8 + i) * VS + tp * 4) = (half2_t){v0[i], v1[i]};
+  }
+  // ---- this wave's 16 queries as the B operand of S^T: lane (q, j) holds Q[q0 + j][32 ks + 8 q .. + 7]
+  const int j = lane & 15, q = lane >> 4;
+  const int q0 = blockIdx.z * 64 + wave * 16;
+  half8_t qf[CH / 32];
+#pragma unroll
+  for (int ks = 0; ks < CH / 32; ++ks) qf[ks] = *(const half8_t*)(base + (long)(q0 + j) * ldq + ks * 32 + q * 8);
+  __syncthreads();
+  // ---- S^T tiles: st[tile][r] = score of query j at key 16 tile + 4 q + r
+  f32x4 st[T / 16];
+#pragma unroll
+  for (int tile = 0; tile < T / 16; ++tile) {
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < CH / 32; ++ks) {
+      const half8_t kf = *(const half8_t*)(Ks + (tile * 16 + j) * KS + (ks * 4 + q) * 16);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ks], a, 0, 0, 0);
+    }
+    st[tile] = a;
+  }
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int tile = 0; tile < T / 16; ++tile) mx = fmaxf(fmaxf(fmaxf(st[tile].x, st[tile].y), fmaxf(st[tile].z, st[tile].w)), mx);
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const float sl = scale * 1.4426950408889634f, mo = mx * sl;
+  float sum = 0.f;
+  half4_t pf[T / 16];
+#pragma unroll
+  for (int tile = 0; tile < T / 16; ++tile) {
+    const float e0 = __builtin_amdgcn_exp2f(st[tile].x * sl - mo), e1 = __builtin_amdgcn_exp2f(st[tile].y * sl - mo);
+    const float e2 = __builtin_amdgcn_exp2f(st[tile].z * sl - mo), e3 = __builtin_amdgcn_exp2f(st[tile].w * sl - mo);
+    sum += (e0 + e1) + (e2 + e3);
+    pf[tile] = (half4_t){(half_t)e0, (half_t)e1, (half_t)e2, (half_t)e3};
+  }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
+  // ---- O^T = V^T P^T: channel tile ct, key step kt (32 keys = score tiles 2 kt, 2 kt + 1)
+  half_t* ob = out + ((long)n * T + q0 + j) * C + head * CH;
+#pragma unroll
+  for (int ct = 0; ct < CH / 16; ++ct) {
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < T / 32; ++kt) {
+      const char* vr = Vt + (ct * 16 + j) * VS + (kt * 32 + q * 4) * 2;
+      const half4_t va = *(const half4_t*)vr, vb = *(const half4_t*)(vr + 32);
+      const half8_t vf = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+      const half4_t pa = pf[2 * kt], pb = pf[2 * kt + 1];
+      const half8_t pp = {pa[0], pa[1], pa[2], pa[3], pb[0], pb[1], pb[2], pb[3]};
+      o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pp, o, 0, 0, 0);
+    }
+    // lane holds O[query j][channels 16 ct + 4 q .. + 3]
+    *(half4_t*)(ob + ct * 16 + q * 4) = (half4_t){(half_t)(o.x * inv), (half_t)(o.y * inv), (half_t)(o.z * inv), (half_t)(o.w * inv)};
+  }
+}
+
+template <int CH, int T>
+static int launch_attention_unet_mfma(const half_t* qkv, half_t* out, int N, int heads, hipStream_t st) {
+  constexpr int LDS = T * (CH * 2 + 16) + CH * (T * 2 + 16);
+  static unsigned long long attr_set = 0;
+  int devid = 0;
+  (void)hipGetDevice(&devid);
+  if (!((attr_set >> (devid & 63)) & 1)) {
+    if (hipFuncSetAttribute((const void*)attention_unet_mfma_kernel<CH, T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+      return LFM_ERR_LAUNCH;
+    attr_set |= 1ull << (devid & 63);
+  }
+  hipLaunchKernelGGL((attention_unet_mfma_kernel<CH, T>), dim3(heads, N, T / 64), dim3(256), LDS, st, qkv, out, heads, 1.0f / sqrtf((float)CH));
+  LFM_CHECK_LAUNCH();
+  return LFM_OK;
+}
+
 extern "C" int lfm_attention_small_f16(const void* qkv, void* out, int N, int T, int heads, int ch, lfm_stream_t stream) {
   if (!qkv || !out) return LFM_ERR_ARG;
   if (N <= 0 || T <= 0 || heads <= 0 || ch <= 0) return LFM_ERR_SHAPE;
+  if (!(((uintptr_t)qkv | (uintptr_t)out) & 15) && !(lfm_gemm_debug_flags() & 16)) {  // flag 16: the VALU kernel (A/B)
+    const half_t* qi = (const half_t*)qkv;
+    half_t* oi = (half_t*)out;
+    hipStream_t st = (hipStream_t)stream;
+    if (T == 256 && ch == 128) return launch_attention_unet_mfma<128, 256>(qi, oi, N, heads, st);
+    if (T == 256 && ch == 64) return launch_attention_unet_mfma<64, 256>(qi, oi, N, heads, st);
+    if (T == 64 && ch == 128) return launch_attention_unet_mfma<128, 64>(qi, oi, N, heads, st);
+    if (T == 64 && ch == 64) return launch_attention_unet_mfma<64, 64>(qi, oi, N, heads, st);
+  }
   const int QB = T < 64 ? T : 64;  // queries per workgroup
   const size_t lds = (size_t)QB * (T + 1) * 4 + (size_t)2 * T * (ch + 2) * 2;
   if (lds > 160 * 1024) return LFM_ERR_SHAPE;  // every reference config has T <= 64 (8x8 / 4x4 feature maps)

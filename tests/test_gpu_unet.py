@@ -245,3 +245,40 @@ def test_unet_options_match_reference_golden(golden_dir, which):
     got = m(rec["t"].to(dev), rec["x"].to(dev))
     assert float(rec["v"].abs().mean()) > 1e-2
     assert rel_l2(got, rec["v"]) < 3e-3
+
+
+@pytest.mark.parametrize("N,heads,ch,T", [(2, 4, 128, 256), (3, 2, 64, 256), (2, 4, 64, 64), (1, 8, 128, 64), (2, 2, 96, 64)])
+def test_unet_attention_mfma_vs_torch_and_the_valu_kernel(N, heads, ch, T):
+    """QKVAttentionLegacy (unet.py:310-334) on the MFMA kernel (T = 64 / 256, ch = 64 / 128) against fp32 torch on the same fp16 operands and
+    against the VALU kernel (flag 16); any other shape (ch = 96 here) must still take the VALU kernel and agree with torch.  Scores have a
+    realistic spread (|s| up to ~8 after scaling), so a wrong max / sum would show."""
+    from lfm_amd import hip
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(N + heads + ch + T)
+    L = hip.lib()
+    qkv = (torch.randn(N, heads * 3 * ch, T, generator=g) * 1.6).half()
+    q, k, v = qkv.float().reshape(N * heads, 3 * ch, T).split(ch, dim=1)
+    wgt = torch.softmax(torch.einsum("bct,bcs->bts", q * ch ** -0.25, k * ch ** -0.25), -1)
+    ref = torch.einsum("bts,bcs->bct", wgt, v).reshape(N, heads * ch, T)
+    tok = qkv.permute(0, 2, 1).reshape(N * T, heads * 3 * ch).contiguous().to(dev)
+
+    def run(flags):
+        out = torch.full((N * T, heads * ch), float("nan"), dtype=torch.float16, device=dev)
+        hip.gemm_select(flags << 4)
+        try:
+            hip.check(L.lfm_attention_small_f16(hip.ptr(tok), hip.ptr(out), N, T, heads, ch, hip.stream_ptr()), "attn")
+        finally:
+            hip.gemm_select(0)
+        return out.reshape(N, T, heads * ch).permute(0, 2, 1).float().cpu()
+
+    got = run(0)
+    assert torch.isfinite(got).all()
+    assert rel_l2(got, ref) < 2e-3
+    if 64 * (T + 1) * 4 + 2 * T * (ch + 2) * 2 <= 160 * 1024:  # the VALU kernel keeps K, V and a score block in the LDS: T = 256 x ch = 128 does not fit
+        valu = run(16)
+        assert rel_l2(valu, ref) < 2e-3
+        assert rel_l2(got, valu) < 2e-3
+    else:
+        with pytest.raises(hip.LfmHipError):
+            run(16)
