@@ -218,7 +218,10 @@ int lfm_images_to_uint8_mode(const float* x, uint8_t* out, int N, int H, int W, 
  *
  * lfm_conv3x3_f16: out[N,H,W,Cout] = conv3x3(in, pad 1) + bias (+ resid); w fp16 [Cout][ky*3+kx][Cin], Cin % 64 == 0.
  *   mode 0: in is [N,H,W,Cin] (ResBlock convs, unet.py:171-175,193-198);  mode 1: in is [N,H/2,W/2,Cin], nearest-2x upsampled on
- *   the fly (Upsample, :73-100);  mode 2: in is [N,2H,2W,Cin], stride 2 (Downsample, :103-128). */
+ *   the fly (Upsample, :73-100);  mode 2: in is [N,2H,2W,Cin], stride 2 (Downsample, :103-128).
+ *   Kernel choice (same result up to the fp32 summation order): modes 0 / 1 with H, W multiples of 16, Cout % 128 == 0 and at least 256
+ *   (16x16-pixel tile, 128-channel block) pairs run on the halo-tiled direct kernel (csrc/conv_halo_kernel.h); everything else is an
+ *   implicit GEMM (split-K with a workspace for the small maps). */
 int lfm_conv3x3_f16(const void* in, const void* w, const float* bias, const void* resid, void* out, int N, int H, int W, int Cin, int Cout,
                     int mode, lfm_stream_t stream);
 /* The same with a caller-owned workspace of lfm_conv3x3_workspace_bytes(...) bytes (0 = none needed): small-M / huge-K convolutions (the
@@ -249,7 +252,9 @@ int lfm_concat_channels_f16(const void* a, const void* b, void* out, long pixels
 /* y = x + e[n][c] broadcast over the pixels of image n (ResBlock without scale-shift norm: h + emb_out[..., None, None], unet.py:233-235);
  * x, y fp16 NHWC [N*HW, C], e fp32 rows e_stride apart */
 int lfm_add_image_vec_f16(const void* x, const float* e, long e_stride, void* y, int N, int HW, int C, lfm_stream_t stream);
-/* QKVAttentionLegacy (unet.py:310-334): qkv fp16 [N*T, 3C], columns [head][q|k|v][ch]; out fp16 [N*T, C] columns [head][ch] */
+/* QKVAttentionLegacy (unet.py:310-334): qkv fp16 [N*T, 3C], columns [head][q|k|v][ch]; out fp16 [N*T, C] columns [head][ch].
+ * T = 64 / 256 with ch = 64 / 128 (16-byte aligned pointers): MFMA kernel; any other shape: a VALU kernel that keeps K, V and a 64-query score
+ * block in the LDS (LFM_ERR_SHAPE when that exceeds 160 KiB). */
 int lfm_attention_small_f16(const void* qkv, void* out, int N, int T, int heads, int ch, lfm_stream_t stream);
 /* emb = time_embed(timestep_embedding(t, F)) (+ label_emb[y]) (nn.py:103-121, unet.py:633-641): fp32 [N,E] and fp16 silu(emb).
  * label_table has label_rows rows; a label outside [0, label_rows) (an IndexError in the reference) poisons its row with NaN. */

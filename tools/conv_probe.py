@@ -10,6 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lfm_amd import hip
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+EXTRA = [int(f) for f in sys.argv[2:]]  # further debug flags to A/B on the halo kernel
 dev = torch.device("cuda:0")
 L = hip.lib()
 SHAPES = [(64, 256, 256, 128, 128), (64, 256, 256, 256, 128), (64, 128, 128, 256, 256), (32, 64, 64, 256, 256), (32, 64, 64, 128, 128),
@@ -24,7 +25,7 @@ for N, H, W, Cin, Cout in SHAPES:
     out = torch.empty(N * H * W, Cout, device=dev, dtype=torch.float16)
     flop = 2.0 * N * H * W * Cout * 9 * Cin
     res = {}
-    for name, flags in (("implicit", 8388608), ("halo", 0)):
+    for name, flags in (("implicit", 8388608), ("halo", 0)) + tuple((f"halo+flag{f}", f) for f in EXTRA):
         hip.gemm_select(flags << 4)
         for _ in range(2):
             hip.check(L.lfm_conv3x3_f16(hip.ptr(x), hip.ptr(w), hip.ptr(b), None, hip.ptr(out), N, H, W, Cin, Cout, 0, hip.stream_ptr()), "conv")
