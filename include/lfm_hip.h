@@ -238,11 +238,19 @@ int lfm_conv3x3_out_f32(const void* in, const void* w4, const float* bias4, floa
 /* C fp16 [M,N] = A[M,K] W[N,K]^T + bias (+ resid fp16 [M,N]): 1x1 convs / Conv1d(k=1) / skip connections (unet.py:204,266,276) */
 int lfm_linear_f16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N, int K, const float* bias,
                    const void* resid, lfm_stream_t stream);
+/* The same with A = the channel concat [A1 (K1 columns) | A2 (K2 columns)] of two dense fp16 tensors read in place: the 1x1 skip convolution of an
+ * output-block ResBlock, whose input is th.cat([h, hs.pop()], dim=1) (unet.py:649 + :236).  K1 % 64 == 0, K2 % 8 == 0. */
+int lfm_linear2_f16(const void* A1, int K1, const void* A2, int K2, const void* W, long ldw, void* C, long ldc, int M, int N, const float* bias,
+                    const void* resid, lfm_stream_t stream);
 /* y = silu?( GroupNorm(groups <= 32)(x; gamma, beta, eps) * (1 + scale[n]) + shift[n] );  film = fp32 [N][scale(C) | shift(C)] rows film_stride apart,
  * or NULL (nn.py:17-19,93-100; scale-shift-norm unet.py:228-233).  scratch: lfm_groupnorm_scratch_bytes(N, C) bytes. */
 size_t lfm_groupnorm_scratch_bytes(int N, int C);
 int lfm_groupnorm_f16(const void* x, void* y, const float* gamma, const float* beta, const float* film, long film_stride, void* scratch, int N,
                       int HW, int C, int groups, float eps, int silu, lfm_stream_t stream);
+/* The same on the channel concat [xa (Ca channels) | xb (Cb channels)] read in place (groups may straddle the seam); y is dense [N*HW, Ca + Cb];
+ * scratch: lfm_groupnorm_scratch_bytes(N, Ca + Cb).  Ca % 8 == Cb % 8 == 0.  Bit-identical to lfm_concat_channels_f16 + lfm_groupnorm_f16. */
+int lfm_groupnorm2_f16(const void* xa, int Ca, const void* xb, int Cb, void* y, const float* gamma, const float* beta, const float* film,
+                       long film_stride, void* scratch, int N, int HW, int groups, float eps, int silu, lfm_stream_t stream);
 /* y[N,Ho,Wo,C] = 2x2 mean of x[N,2Ho,2Wo,C]: EDM Conv2d(down=True) with the [1,1] resample filter (models/EDM.py:96-98,122-125) */
 int lfm_avgpool2_f16(const void* x, void* y, int N, int Ho, int Wo, int C, lfm_stream_t stream);
 /* y[N,Ho,Wo,C] = nearest-2x upsample of x[N,Ho/2,Wo/2,C]: EDM Conv2d(up=True, kernel=0) skip path (models/EDM.py:117-121) */

@@ -49,6 +49,30 @@ struct ASrcRowMajor {
   __device__ __forceinline__ const half_t* ptr(const Row& r, int koff) const { return (A + k0) + (r.off + (unsigned)koff); }
   bool fits() const { return (long)M * lda < (1L << 31); }
 };
+// A = [A1 | A2]: the K range [0, Ca) from A1 [M, Ca], [Ca, Ca + Cb) from A2 [M, Cb] (dense rows); Ca is a multiple of every kernel's K-tile depth,
+// so a K-tile lies in one of the two.  Not batched.
+struct ASrcRowMajor2 {
+  const half_t* A;
+  const half_t* B;
+  int Ca, Cb, M;
+  int k0;
+  __device__ __forceinline__ void init(int, long) {}
+  struct Row {
+    unsigned ra, rb;
+  };
+  __device__ __forceinline__ Row row(int m) const {
+    const int mm = m < M ? m : M - 1;
+    Row r;
+    r.ra = (unsigned)(mm * Ca);
+    r.rb = (unsigned)(mm * Cb);
+    return r;
+  }
+  __device__ __forceinline__ void begin_tile(int kt, int bk) { k0 = kt * bk; }
+  __device__ __forceinline__ const half_t* ptr(const Row& r, int koff) const {
+    return k0 < Ca ? (A + k0) + (r.ra + (unsigned)koff) : (B + (k0 - Ca)) + (r.rb + (unsigned)koff);
+  }
+  bool fits() const { return (long)M * (Ca > Cb ? Ca : Cb) < (1L << 31); }
+};
 // A sources with addressing limits say so through fits(); every launcher asks
 template <class ASrc>
 static inline auto asrc_fits(const ASrc& a, int) -> decltype(a.fits()) {

@@ -194,6 +194,17 @@ extern "C" int lfm_linear_f16(const void* A, long lda, const void* W, long ldw, 
                           EpiResidF16{(half_t*)C, ldc, bias, (const half_t*)resid}, (hipStream_t)stream);
 }
 
+// C = [A1 | A2] W^T + bias (+ resid): the 1x1 skip convolution of a ResBlock whose input is the channel concat of two tensors (unet.py:649 + :236),
+// read in place: the K range [0, K1) comes from A1 [M, K1], [K1, K1 + K2) from A2 [M, K2].  K1 % 64 == 0 (a K-tile never straddles the seam).
+extern "C" int lfm_linear2_f16(const void* A1, int K1, const void* A2, int K2, const void* W, long ldw, void* C, long ldc, int M, int N,
+                               const float* bias, const void* resid, lfm_stream_t stream) {
+  if (!A1 || !A2 || !W || !C) return LFM_ERR_ARG;
+  if (K1 <= 0 || K2 <= 0 || (K1 % 64) || (K2 % 8)) return LFM_ERR_SHAPE;
+  if (((uintptr_t)A1 | (uintptr_t)A2) & 15) return LFM_ERR_ALIGN;
+  return launch_gemm_auto(ASrcRowMajor2{(const half_t*)A1, (const half_t*)A2, K1, K2, M, 0}, (const half_t*)W, ldw, M, N, K1 + K2,
+                          EpiResidF16{(half_t*)C, ldc, bias, (const half_t*)resid}, (hipStream_t)stream);
+}
+
 // ------------------------------------------------------------------ first conv: fp32 NCHW (Cin <= 16) -> fp16 NHWC
 // Weights are transposed into LDS as [k = (c,ky,kx)][Cout] so the 8 output channels of a thread are two float4 reads per tap;
 // a block walks CI_PIX pixels (threads = Cout/8 channel-octets x pixel rows), input taps are L1-served broadcast loads.
@@ -252,18 +263,32 @@ extern "C" int lfm_conv3x3_in_f32(const float* x_nchw, const float* w, const flo
 // 2) coef : per (n, c): folds the partials of its group in a FIXED order (deterministic: the reference is; atomics are not), then
 //           a = rstd*gamma*(1+scale),  b = (beta - mean*rstd*gamma)*(1+scale) + shift     (FiLM optional)
 // 3) apply: y = silu?(x*a + b), 8 channels per thread
+// GroupNorm input = the channel concat [a | b] of two NHWC tensors read in place (th.cat([h, hs.pop()], dim=1) feeding a ResBlock's first
+// GroupNorm, unet.py:649 + :171: the concatenated tensor is never materialised); b == nullptr: a alone (Ca == C).  Ca % 8 == 0.
+struct GnIn {
+  const half_t* a;
+  const half_t* b;
+  int Ca, Cb;
+  __device__ __forceinline__ const half_t* at(long pix, int c) const { return c < Ca ? a + pix * Ca + c : b + pix * Cb + (c - Ca); }
+  // a thread that owns channel c of every pixel of image n: first pixel's address and the row stride of the tensor that holds c
+  __device__ __forceinline__ const half_t* column(long pix0, int c, long& stride) const {
+    const bool fa = c < Ca;
+    stride = fa ? Ca : Cb;
+    return fa ? a + pix0 * Ca + c : b + pix0 * Cb + (c - Ca);
+  }
+};
+
 template <int VEC>
-__global__ __launch_bounds__(256) void gn_stats_general_kernel(const half_t* __restrict__ x, float* __restrict__ part, int HW, int C, int cpg,
+__global__ __launch_bounds__(256) void gn_stats_general_kernel(GnIn in, float* __restrict__ part, int HW, int C, int cpg,
                                                                int pix_per_block, int G) {
   const int g = blockIdx.x, n = blockIdx.y;
   const int p0 = blockIdx.z * pix_per_block, p1 = min(p0 + pix_per_block, HW);
   const int vpp = cpg / VEC;  // vectors per pixel in this group
   const long total = (long)(p1 - p0) * vpp;
-  const half_t* base = x + (long)n * HW * C + g * cpg;
   float s = 0.f, q = 0.f;
   for (long e = threadIdx.x; e < total; e += 256) {
     const int p = p0 + (int)(e / vpp), v = (int)(e % vpp);
-    const half_t* ptr = base + (long)p * C + v * VEC;
+    const half_t* ptr = in.at((long)n * HW + p, g * cpg + v * VEC);
     if (VEC == 4) {
       const half4_t h = *(const half4_t*)ptr;
 #pragma unroll
@@ -295,7 +320,7 @@ __global__ __launch_bounds__(256) void gn_stats_general_kernel(const half_t* __r
 
 // fast path (cpg % 4 == 0, C/8 <= 256): a block reads a slab of pixels with FULL rows (coalesced); thread = channel octet x pixel
 // row; per half-octet partial sums are folded through LDS (fixed order) and leave as slot [n][slab][half-octet] of the partial buffer.
-__global__ __launch_bounds__(256) void gn_stats_rows_kernel(const half_t* __restrict__ x, float* __restrict__ part, int HW, int C, int pix_per_block) {
+__global__ __launch_bounds__(256) void gn_stats_rows_kernel(GnIn in, float* __restrict__ part, int HW, int C, int pix_per_block) {
   __shared__ float red[4][256];
   const int n = blockIdx.y, c8n = C / 8, tid = threadIdx.x;
   const int rows = 256 / c8n;
@@ -304,7 +329,8 @@ __global__ __launch_bounds__(256) void gn_stats_rows_kernel(const half_t* __rest
   const int p1 = min(p0 + pix_per_block, HW);
   float s[2] = {0.f, 0.f}, q[2] = {0.f, 0.f};
   if (prow < rows) {
-    const half_t* base = x + (long)n * HW * C + oct * 8;
+    long XS;  // row stride of the tensor that holds this thread's octet
+    const half_t* base = in.column((long)n * HW, oct * 8, XS);
     auto add = [&](const half8_t& v) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -315,14 +341,14 @@ __global__ __launch_bounds__(256) void gn_stats_rows_kernel(const half_t* __rest
     };
     int p = p0 + prow;
     for (; p + 3 * rows < p1; p += 4 * rows) {  // four independent loads in flight (one per iteration ran at 1.5 TB/s), summed in pixel order
-      const half8_t v0 = *(const half8_t*)(base + (long)p * C), v1 = *(const half8_t*)(base + (long)(p + rows) * C);
-      const half8_t v2 = *(const half8_t*)(base + (long)(p + 2 * rows) * C), v3 = *(const half8_t*)(base + (long)(p + 3 * rows) * C);
+      const half8_t v0 = *(const half8_t*)(base + (long)p * XS), v1 = *(const half8_t*)(base + (long)(p + rows) * XS);
+      const half8_t v2 = *(const half8_t*)(base + (long)(p + 2 * rows) * XS), v3 = *(const half8_t*)(base + (long)(p + 3 * rows) * XS);
       add(v0);
       add(v1);
       add(v2);
       add(v3);
     }
-    for (; p < p1; p += rows) add(*(const half8_t*)(base + (long)p * C));
+    for (; p < p1; p += rows) add(*(const half8_t*)(base + (long)p * XS));
   }
   red[0][tid] = s[0];
   red[1][tid] = s[1];
@@ -383,14 +409,14 @@ __global__ void gn_coef_kernel(const float* __restrict__ part, int slabs, int ro
 }
 
 template <bool SILU>
-__global__ __launch_bounds__(256) void gn_affine_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, const float* __restrict__ ab,
+__global__ __launch_bounds__(256) void gn_affine_kernel(GnIn in, half_t* __restrict__ y, const float* __restrict__ ab,
                                                         int HW, int C, long total8) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total8) return;
   const int c8n = C / 8;
   const int c0 = (int)(i % c8n) * 8;
   const int n = (int)(i / ((long)c8n * HW));
-  const half8_t v = ((const half8_t*)x)[i];
+  const half8_t v = *(const half8_t*)in.at(i / c8n, c0);
   const f32x4* p = (const f32x4*)(ab + ((long)n * C + c0) * 2);
   half8_t o;
 #pragma unroll
@@ -412,7 +438,7 @@ __global__ __launch_bounds__(256) void gn_affine_kernel(const half_t* __restrict
 // per-channel a, b (FiLM folded) held in registers.  cpg % 8 == 0, HW <= 1024: the GroupNorms of the UNets' lower resolutions, where the
 // three-kernel path is launch-bound.
 template <bool SILU>
-__global__ __launch_bounds__(256) void gn_fused_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void gn_fused_kernel(GnIn in, half_t* __restrict__ y, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float* __restrict__ film, long film_stride, int HW,
                                                        int C, int cpg, int gpb, float eps) {
   __shared__ float red[2][256];
@@ -421,7 +447,8 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const half_t* __restrict_
   const int CW = gpb * cpg, o8 = CW >> 3;          // channels / octets of this block
   const int oct = tid % o8, prow = tid / o8, rows = 256 / o8;
   const int c0 = blockIdx.x * CW + oct * 8;         // first channel of this thread's octet
-  const half_t* xb = x + (long)n * HW * C + c0;
+  long XS;  // row stride of the tensor that holds this thread's octet
+  const half_t* xb = in.column((long)n * HW, c0, XS);
   float s = 0.f, q = 0.f;
   if (prow < rows) {
     auto add = [&](const half8_t& v) {
@@ -434,14 +461,14 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const half_t* __restrict_
     };
     int p = prow;
     for (; p + 3 * rows < HW; p += 4 * rows) {  // four loads in flight per thread (the block is alone on its CU: latency, not bandwidth, bound it)
-      const half8_t v0 = *(const half8_t*)(xb + (long)p * C), v1 = *(const half8_t*)(xb + (long)(p + rows) * C);
-      const half8_t v2 = *(const half8_t*)(xb + (long)(p + 2 * rows) * C), v3 = *(const half8_t*)(xb + (long)(p + 3 * rows) * C);
+      const half8_t v0 = *(const half8_t*)(xb + (long)p * XS), v1 = *(const half8_t*)(xb + (long)(p + rows) * XS);
+      const half8_t v2 = *(const half8_t*)(xb + (long)(p + 2 * rows) * XS), v3 = *(const half8_t*)(xb + (long)(p + 3 * rows) * XS);
       add(v0);
       add(v1);
       add(v2);
       add(v3);
     }
-    for (; p < HW; p += rows) add(*(const half8_t*)(xb + (long)p * C));
+    for (; p < HW; p += rows) add(*(const half8_t*)(xb + (long)p * XS));
   }
   red[0][tid] = s;
   red[1][tid] = q;
@@ -487,14 +514,14 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const half_t* __restrict_
   };
   int p = prow;
   for (; p + 3 * rows < HW; p += 4 * rows) {
-    const half8_t v0 = *(const half8_t*)(xb + (long)p * C), v1 = *(const half8_t*)(xb + (long)(p + rows) * C);
-    const half8_t v2 = *(const half8_t*)(xb + (long)(p + 2 * rows) * C), v3 = *(const half8_t*)(xb + (long)(p + 3 * rows) * C);
+    const half8_t v0 = *(const half8_t*)(xb + (long)p * XS), v1 = *(const half8_t*)(xb + (long)(p + rows) * XS);
+    const half8_t v2 = *(const half8_t*)(xb + (long)(p + 2 * rows) * XS), v3 = *(const half8_t*)(xb + (long)(p + 3 * rows) * XS);
     apply(v0, p);
     apply(v1, p + rows);
     apply(v2, p + 2 * rows);
     apply(v3, p + 3 * rows);
   }
-  for (; p < HW; p += rows) apply(*(const half8_t*)(xb + (long)p * C), p);
+  for (; p < HW; p += rows) apply(*(const half8_t*)(xb + (long)p * XS), p);
 }
 
 #define GN_MAX_SLABS 64  // pixel slabs per image: bounds the partial buffer independently of HW
@@ -504,9 +531,9 @@ static inline size_t gn_part_bytes(int N, int C) {
 }
 extern "C" size_t lfm_groupnorm_scratch_bytes(int N, int C) { return gn_part_bytes(N, C) + (size_t)N * C * 8 + 256; }
 
-extern "C" int lfm_groupnorm_f16(const void* x, void* y, const float* gamma, const float* beta, const float* film, long film_stride, void* scratch,
-                                 int N, int HW, int C, int groups, float eps, int silu, lfm_stream_t stream) {
-  if (!x || !y || !gamma || !beta || !scratch) return LFM_ERR_ARG;
+static int groupnorm_impl(const GnIn& in, void* y, const float* gamma, const float* beta, const float* film, long film_stride, void* scratch, int N, int HW,
+                          int C, int groups, float eps, int silu, lfm_stream_t stream) {
+  if (!in.a || !y || !gamma || !beta || !scratch) return LFM_ERR_ARG;
   if (N <= 0 || HW <= 0 || groups <= 0 || groups > 32 || C % groups || C % 8) return LFM_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   const int G = groups, cpg = C / G;
@@ -517,8 +544,8 @@ extern "C" int lfm_groupnorm_f16(const void* x, void* y, const float* gamma, con
     int gpb = 1;
     while (gpb * 2 <= G && G % (gpb * 2) == 0 && (long)N * (G / (gpb * 2)) >= 256 && gpb * 2 * cpg <= 2048) gpb *= 2;
     dim3 grid(G / gpb, N);
-    if (silu) hipLaunchKernelGGL(gn_fused_kernel<true>, grid, dim3(256), 0, st, (const half_t*)x, (half_t*)y, gamma, beta, film, film_stride, HW, C, cpg, gpb, eps);
-    else hipLaunchKernelGGL(gn_fused_kernel<false>, grid, dim3(256), 0, st, (const half_t*)x, (half_t*)y, gamma, beta, film, film_stride, HW, C, cpg, gpb, eps);
+    if (silu) hipLaunchKernelGGL(gn_fused_kernel<true>, grid, dim3(256), 0, st, in, (half_t*)y, gamma, beta, film, film_stride, HW, C, cpg, gpb, eps);
+    else hipLaunchKernelGGL(gn_fused_kernel<false>, grid, dim3(256), 0, st, in, (half_t*)y, gamma, beta, film, film_stride, HW, C, cpg, gpb, eps);
     LFM_CHECK_LAUNCH();
     return LFM_OK;
   }
@@ -530,25 +557,39 @@ extern "C" int lfm_groupnorm_f16(const void* x, void* y, const float* gamma, con
     if (cdiv(HW, ppb) > GN_MAX_SLABS) ppb = cdiv(HW, GN_MAX_SLABS);
     slabs = cdiv(HW, ppb);
     rows = 1;
-    hipLaunchKernelGGL(gn_stats_rows_kernel, dim3(slabs, N), dim3(256), 0, st, (const half_t*)x, part, HW, C, ppb);
+    hipLaunchKernelGGL(gn_stats_rows_kernel, dim3(slabs, N), dim3(256), 0, st, in, part, HW, C, ppb);
   } else {
     int ppb = 2048;
     if (cdiv(HW, ppb) > GN_MAX_SLABS) ppb = cdiv(HW, GN_MAX_SLABS);
     slabs = cdiv(HW, ppb);
     rows = 0;
     dim3 grid(G, N, slabs);
-    if (cpg % 4 == 0) hipLaunchKernelGGL(gn_stats_general_kernel<4>, grid, dim3(256), 0, st, (const half_t*)x, part, HW, C, cpg, ppb, G);
-    else hipLaunchKernelGGL(gn_stats_general_kernel<1>, grid, dim3(256), 0, st, (const half_t*)x, part, HW, C, cpg, ppb, G);
+    if (cpg % 4 == 0) hipLaunchKernelGGL(gn_stats_general_kernel<4>, grid, dim3(256), 0, st, in, part, HW, C, cpg, ppb, G);
+    else hipLaunchKernelGGL(gn_stats_general_kernel<1>, grid, dim3(256), 0, st, in, part, HW, C, cpg, ppb, G);
   }
   LFM_CHECK_LAUNCH();
   hipLaunchKernelGGL(gn_coef_kernel, dim3(cdiv((long)N * C, 256)), dim3(256), 0, st, part, slabs, rows, gamma, beta, film, film_stride, ab, N, C,
                      cpg, (float)HW * (float)cpg, eps, G);
   LFM_CHECK_LAUNCH();
   const long total8 = (long)N * HW * C / 8;
-  if (silu) hipLaunchKernelGGL(gn_affine_kernel<true>, dim3(cdiv(total8, 256)), dim3(256), 0, st, (const half_t*)x, (half_t*)y, ab, HW, C, total8);
-  else hipLaunchKernelGGL(gn_affine_kernel<false>, dim3(cdiv(total8, 256)), dim3(256), 0, st, (const half_t*)x, (half_t*)y, ab, HW, C, total8);
+  if (silu) hipLaunchKernelGGL(gn_affine_kernel<true>, dim3(cdiv(total8, 256)), dim3(256), 0, st, in, (half_t*)y, ab, HW, C, total8);
+  else hipLaunchKernelGGL(gn_affine_kernel<false>, dim3(cdiv(total8, 256)), dim3(256), 0, st, in, (half_t*)y, ab, HW, C, total8);
   LFM_CHECK_LAUNCH();
   return LFM_OK;
+}
+
+extern "C" int lfm_groupnorm_f16(const void* x, void* y, const float* gamma, const float* beta, const float* film, long film_stride, void* scratch,
+                                 int N, int HW, int C, int groups, float eps, int silu, lfm_stream_t stream) {
+  return groupnorm_impl(GnIn{(const half_t*)x, nullptr, C, 0}, y, gamma, beta, film, film_stride, scratch, N, HW, C, groups, eps, silu, stream);
+}
+// GroupNorm of the channel concat [xa (Ca channels) | xb (Cb channels)] without materialising it; y is dense [N*HW, Ca + Cb]
+extern "C" int lfm_groupnorm2_f16(const void* xa, int Ca, const void* xb, int Cb, void* y, const float* gamma, const float* beta, const float* film,
+                                  long film_stride, void* scratch, int N, int HW, int groups, float eps, int silu, lfm_stream_t stream) {
+  if (!xa || !xb) return LFM_ERR_ARG;
+  if (Ca <= 0 || Cb <= 0 || (Ca % 8) || (Cb % 8)) return LFM_ERR_SHAPE;
+  if (((uintptr_t)xa | (uintptr_t)xb) & 15) return LFM_ERR_ALIGN;
+  return groupnorm_impl(GnIn{(const half_t*)xa, (const half_t*)xb, Ca, Cb}, y, gamma, beta, film, film_stride, scratch, N, HW, Ca + Cb, groups, eps, silu,
+                        stream);
 }
 
 // ------------------------------------------------------------------ 2x2 average pooling, stride 2 (EDM Conv2d(down=True) with

@@ -114,6 +114,10 @@ def lib():
     L.lfm_groupnorm_scratch_bytes.argtypes = [I, I]
     L.lfm_groupnorm_f16.restype = I
     L.lfm_groupnorm_f16.argtypes = [V, V, V, V, V, LG, V, I, I, I, I, F, I, V]
+    L.lfm_groupnorm2_f16.restype = I
+    L.lfm_groupnorm2_f16.argtypes = [V, I, V, I, V, V, V, V, LG, V, I, I, I, F, I, V]
+    L.lfm_linear2_f16.restype = I
+    L.lfm_linear2_f16.argtypes = [V, I, V, I, V, LG, V, LG, I, I, V, V, V]
     L.lfm_avgpool2_f16.restype = I
     L.lfm_avgpool2_f16.argtypes = [V, V, I, I, I, I, V]
     L.lfm_upsample2_f16.restype = I

@@ -245,6 +245,33 @@ class UNetModel(nn.Module):
                                               1 if silu else 0, hip.stream_ptr(x.device)), "lfm_groupnorm_f16")
         return y
 
+    def _gn2(self, xa, xb, N, HW, gb, film, silu):
+        """GroupNorm of the channel concat [xa | xb] read in place (``th.cat([h, hs.pop()], dim=1)`` is never materialised, unet.py:649)."""
+        Ca, Cb = xa.shape[1], xb.shape[1]
+        y = torch.empty(xa.shape[0], Ca + Cb, dtype=torch.float16, device=xa.device)
+        need = hip.lib().lfm_groupnorm_scratch_bytes(N, Ca + Cb)
+        if self._scratch is None or self._scratch.numel() < need or self._scratch.device != xa.device:
+            self._scratch = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=xa.device)
+            self._gen += 1
+        hip.check(hip.lib().lfm_groupnorm2_f16(hip.ptr(xa), Ca, hip.ptr(xb), Cb, hip.ptr(y), hip.ptr(gb[0]), hip.ptr(gb[1]), hip.ptr(film),
+                                               film.stride(0) if film is not None else 0, hip.ptr(self._scratch), N, HW, 32, 1e-5,
+                                               1 if silu else 0, hip.stream_ptr(xa.device)), "lfm_groupnorm2_f16")
+        return y
+
+    def _linear2(self, xa, xb, wb):
+        M, Nout = xa.shape[0], wb[0].shape[0]
+        out = torch.empty(M, Nout, dtype=torch.float16, device=xa.device)
+        hip.check(hip.lib().lfm_linear2_f16(hip.ptr(xa), xa.shape[1], hip.ptr(xb), xb.shape[1], hip.ptr(wb[0]), wb[0].stride(0), hip.ptr(out), Nout, M, Nout,
+                                            hip.ptr(wb[1]), None, hip.stream_ptr(xa.device)), "lfm_linear2_f16")
+        return out
+
+    def _cat(self, pair):
+        h, skip = pair
+        cat = torch.empty(h.shape[0], h.shape[1] + skip.shape[1], dtype=torch.float16, device=h.device)
+        hip.check(hip.lib().lfm_concat_channels_f16(hip.ptr(h), hip.ptr(skip), hip.ptr(cat), h.shape[0], h.shape[1], skip.shape[1],
+                                                    hip.stream_ptr(h.device)), "lfm_concat_channels_f16")
+        return cat
+
     def _conv(self, x, wb, N, H, W, Cin, Cout, mode=0, resid=None):
         out = torch.empty(N * H * W, Cout, dtype=torch.float16, device=x.device)
         L = hip.lib()
@@ -268,7 +295,16 @@ class UNetModel(nn.Module):
     def _resblock(self, name, m, h, N, H, W, emb_silu):
         p = self._packed[name]
         Cin, Cout = m.channels, m.out_channels
-        t1 = self._gn(h, N, H * W, Cin, p["gn1"], None, True)
+        pair = None
+        if isinstance(h, tuple):  # (h, skip) of an output block: read in place by the first GroupNorm and the 1x1 skip convolution
+            if m.updown or p["skip"] is None or h[0].shape[1] % 64 or h[1].shape[1] % 8:
+                h = self._cat(h)  # resampled / identity-skip inputs need the tensor itself
+            else:
+                pair = h
+        if pair is not None:
+            t1 = self._gn2(pair[0], pair[1], N, H * W, p["gn1"], None, True)
+        else:
+            t1 = self._gn(h, N, H * W, Cin, p["gn1"], None, True)
         if m.updown:  # in_rest -> h_upd / x_upd -> in_conv (unet.py:219-224): nearest 2x or 2x2 mean on both branches
             H2, W2 = (H * 2, W * 2) if m.h_upd.up else (H // 2, W // 2)
             t1, h = self._resample(t1, N, H2, W2, Cin, m.h_upd.up), self._resample(h, N, H2, W2, Cin, m.h_upd.up)
@@ -283,7 +319,10 @@ class UNetModel(nn.Module):
             hip.check(hip.lib().lfm_add_image_vec_f16(hip.ptr(a), hip.ptr(emb_out), emb_out.stride(0), hip.ptr(a2), N, H * W, Cout,
                                                       hip.stream_ptr(a.device)), "lfm_add_image_vec_f16")
             t2 = self._gn(a2, N, H * W, Cout, p["gn2"], None, True)
-        skip = h if p["skip"] is None else self._linear(h, p["skip"])
+        if pair is not None:
+            skip = self._linear2(pair[0], pair[1], p["skip"])
+        else:
+            skip = h if p["skip"] is None else self._linear(h, p["skip"])
         return self._conv(t2, p["c2"], N, H, W, Cout, Cout, resid=skip)
 
     def _resample(self, x, N, Ho, Wo, C, up):
@@ -371,10 +410,11 @@ class UNetModel(nn.Module):
         h, H, W = self._run_block("middle_block", self.middle_block, h, N, H, W, emb_silu)
         for i, block in enumerate(self.output_blocks):
             skip, cs = hs.pop()
-            cat = torch.empty(h.shape[0], h.shape[1] + cs, dtype=torch.float16, device=dev)
-            hip.check(L.lfm_concat_channels_f16(hip.ptr(h), hip.ptr(skip), hip.ptr(cat), h.shape[0], h.shape[1], cs, hip.stream_ptr(dev)),
-                      "lfm_concat_channels_f16")
-            h, H, W = self._run_block(f"output_blocks.{i}", block, cat, N, H, W, emb_silu)
+            first = block[0]
+            if isinstance(first, ResBlock):  # th.cat([h, hs.pop()], dim=1) (unet.py:649) is consumed in place by the ResBlock's GroupNorm and skip conv
+                h, H, W = self._run_block(f"output_blocks.{i}", block, (h, skip), N, H, W, emb_silu)
+            else:
+                h, H, W = self._run_block(f"output_blocks.{i}", block, self._cat((h, skip)), N, H, W, emb_silu)
         t1 = self._gn(h, N, H * W, h.shape[1], self._packed["gn_out"], None, True)
         out = torch.empty(N, self.out_channels, H, W, device=dev)
         co = self._packed["conv_out"]

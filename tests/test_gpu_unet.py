@@ -282,3 +282,42 @@ def test_unet_attention_mfma_vs_torch_and_the_valu_kernel(N, heads, ch, T):
     else:
         with pytest.raises(hip.LfmHipError):
             run(16)
+
+
+@pytest.mark.parametrize("N,HW,Ca,Cb,film_on", [(2, 256, 1024, 512, True), (2, 4096, 256, 256, True), (3, 64, 64, 32, False), (2, 1024, 512, 256, True),
+                                                 (1, 8192, 128, 256, False)])
+def test_two_source_groupnorm_and_linear_equal_the_concatenated_path(N, HW, Ca, Cb, film_on):
+    """lfm_groupnorm2_f16 / lfm_linear2_f16 read th.cat([h, skip], dim=1) (unet.py:649) in place: bit-identical to lfm_concat_channels_f16 followed
+    by lfm_groupnorm_f16 / lfm_linear_f16.  Shapes: groups straddling the seam (1024 + 512: 48-wide groups) on the fused small-map kernel, the
+    three-kernel path at 64x64, the general kernel (96 channels: groups of 3), and a wide map."""
+    from lfm_amd import hip
+
+    dev = torch.device("cuda:0")
+    L = hip.lib()
+    g = torch.Generator().manual_seed(N + HW + Ca + Cb)
+    C = Ca + Cb
+    xa = (torch.randn(N * HW, Ca, generator=g) * 1.3 + 0.2).half().to(dev)
+    xb = (torch.randn(N * HW, Cb, generator=g) * 0.7 - 0.4).half().to(dev)
+    cat = torch.empty(N * HW, C, dtype=torch.float16, device=dev)
+    hip.check(L.lfm_concat_channels_f16(hip.ptr(xa), hip.ptr(xb), hip.ptr(cat), N * HW, Ca, Cb, hip.stream_ptr()), "cat")
+    assert torch.equal(cat, torch.cat([xa, xb], dim=1))
+    gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)).to(dev), (0.2 * torch.randn(C, generator=g)).to(dev)
+    film = (torch.randn(N, 2 * C, generator=g) * 0.3).to(dev) if film_on else None
+    scr = torch.empty(L.lfm_groupnorm_scratch_bytes(N, C), dtype=torch.uint8, device=dev)
+    y1, y2 = torch.empty_like(cat), torch.full_like(cat, float("nan"))
+    hip.check(L.lfm_groupnorm_f16(hip.ptr(cat), hip.ptr(y1), hip.ptr(gamma), hip.ptr(beta), hip.ptr(film), 2 * C if film_on else 0, hip.ptr(scr),
+                                  N, HW, C, 32, 1e-5, 1, hip.stream_ptr()), "gn")
+    hip.check(L.lfm_groupnorm2_f16(hip.ptr(xa), Ca, hip.ptr(xb), Cb, hip.ptr(y2), hip.ptr(gamma), hip.ptr(beta), hip.ptr(film),
+                                   2 * C if film_on else 0, hip.ptr(scr), N, HW, 32, 1e-5, 1, hip.stream_ptr()), "gn2")
+    assert torch.isfinite(y2).all() and torch.equal(y1, y2)
+    if Ca % 64 == 0 and C % 64 == 0:  # (the GEMM kernels take K in 32- / 64-deep tiles)
+        Nout = 256
+        w = (torch.randn(Nout, C, generator=g) / C ** 0.5).half().to(dev)
+        b = (torch.randn(Nout, generator=g) * 0.1).to(dev)
+        o1, o2 = torch.empty(N * HW, Nout, dtype=torch.float16, device=dev), torch.full((N * HW, Nout), float("nan"), dtype=torch.float16, device=dev)
+        hip.check(L.lfm_linear_f16(hip.ptr(cat), C, hip.ptr(w), C, hip.ptr(o1), Nout, N * HW, Nout, C, hip.ptr(b), None, hip.stream_ptr()), "linear")
+        hip.check(L.lfm_linear2_f16(hip.ptr(xa), Ca, hip.ptr(xb), Cb, hip.ptr(w), C, hip.ptr(o2), Nout, N * HW, Nout, hip.ptr(b), None,
+                                    hip.stream_ptr()), "linear2")
+        assert torch.equal(o1, o2)
+        ref = cat.float() @ w.float().t() + b
+        assert rel_l2(o2, ref) < 2e-3
