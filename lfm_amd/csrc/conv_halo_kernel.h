@@ -246,3 +246,121 @@ static inline int launch_conv3x3_halo(const half_t* in, const half_t* zeros, con
   LFM_CHECK_LAUNCH();
   return LFM_OK;
 }
+
+// ---- the same halo tiling for an OUTPUT convolution with at most four channels (the VAE decoder's conv_out, the UNets' out conv): fp16 NHWC in,
+// `epi.store(m, 0, f32x4 of channels 0..3, aux)` out.  As an implicit GEMM on the 128x128 kernel these layers compute 128 columns to keep 4 and
+// stage every input pixel nine times (1.2 ms per VAE decode of 64 images, 80 us per UNet evaluation); the work is one read of the input:
+//   tile     16 x 16 pixels per 4-wave workgroup, a wave owns 4 rows; ONE accumulator tile column (16 channels, 4 real) -- D[channel][pixel], so the lanes
+//            of k-group 0 end up with the four channels of one pixel each and store straight from registers;
+//   K order  32-channel quarters; per quarter the halo (21 KiB) AND all nine taps of the weights (9 x 16 rows x 64 B, rows 4..15 from the zero page)
+//            are staged, double-buffered over quarters: one barrier per quarter, 36 MFMAs per wave between barriers;
+//   LDS      2 x (21 KiB + 9 KiB) = 60 KiB: two workgroups per CU.  Bound: the HBM read of the input.
+// w4: fp16 [4][9 * Cin] (k = tap * Cin + ci), rows beyond the real channel count zero.  Cin % 32 == 0, H % 16 == W % 16 == 0.
+#define CHO_W_BYTES (9 * 16 * 64)                      // 9216
+#define CHO_BUF_BYTES (CH_HALO_BYTES + CHO_W_BYTES)    // 30720
+#define CHO_LDS_BYTES (2 * CHO_BUF_BYTES)              // 61440
+
+template <class Epi>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_out_kernel(const half_t* __restrict__ in, const half_t* __restrict__ zeros,
+                                                                   const half_t* __restrict__ w4, int H, int W, int Cin, int tiles_x, int tiles_per_img,
+                                                                   int total_tiles, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int t = blockIdx.x;
+  if ((total_tiles & 7) == 0) t = (t & 7) * (total_tiles >> 3) + (t >> 3);
+  const int img = t / tiles_per_img, rem = t - img * tiles_per_img, ty = rem / tiles_x, tx = rem - ty * tiles_x;
+  const int y0 = ty * 16, x0 = tx * 16;
+  const int nh = Cin >> 5;
+  const half_t* inimg = in + (size_t)img * H * W * Cin;
+  int hoff[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int slot = (k * 4 + wave) * 64 + lane, p = slot >> 2, ch = slot & 3;
+    const int hy = p / 18, hx = p - hy * 18, iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+    const bool ok = p < 324 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    hoff[k] = ok ? (iy * W + ix) * Cin + ((ch ^ ((p >> 1) & 2)) << 3) : -1;
+  }
+  // weights of a quarter: slot = widx * 64 + lane -> (tap, row) = slot >> 2, physical chunk slot & 3; 576 slots = 9 wave-wide DMAs
+  int woff[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int slot = (k * 4 + wave) * 64 + lane, tr = slot >> 2, ch = slot & 3, tap = tr >> 4, row = tr & 15;
+    woff[k] = (row < 4 && tap < 9) ? row * 9 * Cin + tap * Cin + ((ch ^ ((row >> 1) & 2)) << 3) : -1;
+  }
+  auto issue = [&](int h, int b) {
+    char* base = smem + b * CHO_BUF_BYTES;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int widx = k * 4 + wave;
+      if (widx < 21) {
+        int o = hoff[k];
+        asm volatile("" : "+v"(o));
+        glds16(o >= 0 ? inimg + o + h * 32 : zeros, base + widx * 1024);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int widx = k * 4 + wave;
+      if (widx < 9) {
+        int o = woff[k];
+        asm volatile("" : "+v"(o));
+        glds16(o >= 0 ? w4 + o + h * 32 : zeros, base + CH_HALO_BYTES + widx * 1024);
+      }
+    }
+  };
+  const int r = lane & 15, q = lane >> 4, pl = wave * 72 + r;  // wave w owns tile rows 4 w .. 4 w + 3: halo pixel (4 w + i + dy) * 18 + dx + r
+  const int wfrag = r * 64 + ((q ^ ((r >> 1) & 2)) << 4);
+  f32x4_t acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  issue(0, 0);
+  for (int h = 0; h < nh; ++h) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my share of quarter h has landed
+    G256_BARRIER();                                   // everyone's has; and every wave is done reading the other buffer (quarter h - 1)
+    if (h + 1 < nh) issue(h + 1, (h + 1) & 1);
+    const char* hb = smem + (h & 1) * CHO_BUF_BYTES;
+    const char* wb = hb + CH_HALO_BYTES;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const half8_t wf = *(const half8_t*)(wb + tap * 1024 + wfrag);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int p = pl + (i + tap / 3) * 18 + tap % 3;
+        const half8_t af = *(const half8_t*)(hb + p * 64 + ((q ^ ((p >> 1) & 2)) << 4));
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, af, acc[i], 0, 0, 0);
+      }
+    }
+  }
+  if (q == 0) {  // D[channel 4 q + e][pixel r]: k-group 0 holds channels 0..3
+    const typename Epi::Aux aux = epi.load(0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = (img * H + y0 + wave * 4 + i) * W + x0 + r;
+      epi.store(m, 0, (f32x4){acc[i].x, acc[i].y, acc[i].z, acc[i].w}, aux);
+    }
+  }
+}
+
+// returns 1 when the shape is not this kernel's (the caller takes the implicit GEMM)
+template <class Epi>
+static inline int launch_conv3x3_halo_out(const half_t* in, const half_t* zeros, const half_t* w4, int n, int H, int W, int Cin, const Epi& epi,
+                                          hipStream_t st) {
+  if (n <= 0 || (H & 15) || (W & 15) || (Cin & 31)) return 1;
+  if ((long)n * H * W >= (1L << 31) || (long)H * W * Cin >= (1L << 31)) return 1;
+  const int tiles_x = W / 16, tiles_per_img = tiles_x * (H / 16);
+  const long total = (long)n * tiles_per_img;
+  if ((total < 256 && !(lfm_gemm_debug_flags() & 16777216)) || total >= (1L << 31)) return 1;
+  if (((uintptr_t)in | (uintptr_t)w4 | (uintptr_t)zeros) & 15) return LFM_ERR_ALIGN;
+  static unsigned long long attr_set = 0;
+  int devid = 0;
+  (void)hipGetDevice(&devid);
+  if (!((attr_set >> (devid & 63)) & 1)) {
+    if (hipFuncSetAttribute((const void*)conv3x3_halo_out_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, CHO_LDS_BYTES) != hipSuccess)
+      return LFM_ERR_LAUNCH;
+    attr_set |= 1ull << (devid & 63);
+  }
+  hipLaunchKernelGGL((conv3x3_halo_out_kernel<Epi>), dim3((unsigned)total), dim3(256), CHO_LDS_BYTES, st, in, zeros, w4, H, W, Cin, tiles_x, tiles_per_img,
+                     (int)total, epi);
+  LFM_CHECK_LAUNCH();
+  return LFM_OK;
+}

@@ -182,8 +182,12 @@ extern "C" int lfm_conv3x3_out_f32(const void* in, const void* w4, const float* 
   const half_t* z = zero_page();
   if (!z) return LFM_ERR_LAUNCH;
   const int M = N * H * W;
-  return launch_gemm_tn(ASrcConv<0>{(const half_t*)in, z, H, W, Cin, M, 0, 0, 0, 0}, (const half_t*)w4, 9L * Cin, M, 4, 9 * Cin,
-                        EpiNCHWF32{out_nchw, bias4, H * W, nch}, (hipStream_t)stream);
+  const EpiNCHWF32 eo{out_nchw, bias4, H * W, nch};
+  if (lfm_gemm_selected() == 0 && !(lfm_gemm_debug_flags() & 8388608)) {  // flag 8388608: the implicit GEMM (A/B)
+    const int rc = launch_conv3x3_halo_out((const half_t*)in, z, (const half_t*)w4, N, H, W, Cin, eo, (hipStream_t)stream);
+    if (rc != 1) return rc;
+  }
+  return launch_gemm_tn(ASrcConv<0>{(const half_t*)in, z, H, W, Cin, M, 0, 0, 0, 0}, (const half_t*)w4, 9L * Cin, M, 4, 9 * Cin, eo, (hipStream_t)stream);
 }
 
 extern "C" int lfm_linear_f16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N, int K, const float* bias,

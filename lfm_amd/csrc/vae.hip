@@ -604,8 +604,13 @@ extern "C" int lfm_vae_decode(const lfm_vae_weights* w, void* workspace, size_t 
     }
     RC(gn(x, t1, ws.stats, ws.part, w->no_g, w->no_b, n, H * H, 128, true, st, xs));
     const int M = n * H * H;
-    RC(launch_gemm_tn(ASrcConv3x3<0>{t1, ws.zeros, H, H, 128, M, 0, 0}, (const half_t*)w->cout_w, 9L * 128, M, 4, 9 * 128,
-                      EpiConvOutNCHW{out + (long)n0 * 3 * H * H, w->cout_b, H * H}, st));
+    {
+      const EpiConvOutNCHW eo{out + (long)n0 * 3 * H * H, w->cout_b, H * H};
+      int rc = 1;  // flag 8388608: the implicit GEMM (A/B)
+      if (lfm_gemm_selected() == 0 && !(lfm_gemm_debug_flags() & 8388608)) rc = launch_conv3x3_halo_out(t1, ws.zeros, (const half_t*)w->cout_w, n, H, H, 128, eo, st);
+      if (rc == 1) rc = launch_gemm_tn(ASrcConv3x3<0>{t1, ws.zeros, H, H, 128, M, 0, 0}, (const half_t*)w->cout_w, 9L * 128, M, 4, 9 * 128, eo, st);
+      RC(rc);
+    }
   }
   return LFM_OK;
 }

@@ -321,3 +321,40 @@ def test_two_source_groupnorm_and_linear_equal_the_concatenated_path(N, HW, Ca, 
         assert torch.equal(o1, o2)
         ref = cat.float() @ w.float().t() + b
         assert rel_l2(o2, ref) < 2e-3
+
+
+@pytest.mark.parametrize("N,H,W,Cin,nch", [(2, 32, 48, 128, 3), (1, 64, 64, 256, 4), (3, 16, 16, 192, 1)])
+def test_halo_output_conv_vs_torch_and_the_implicit_gemm(N, H, W, Cin, nch):
+    """lfm_conv3x3_out_f32 (the UNets' / the VAE decoder's <= 4-channel output convolution, fp16 NHWC -> fp32 NCHW) on the halo-tiled kernel
+    (conv3x3_halo_out_kernel, forced at these small sizes with flag 16777216) against torch and against the implicit GEMM (flag 8388608):
+    border and interior tiles, 4 / 6 / 8 channel quarters, 1 / 3 / 4 real output channels."""
+    import torch.nn.functional as F
+
+    from lfm_amd import hip
+
+    dev = torch.device("cuda:0")
+    L = hip.lib()
+    g = torch.Generator().manual_seed(N + H + Cin + nch)
+    x = torch.randn(N, Cin, H, W, generator=g).half()
+    w = (torch.randn(nch, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).half()
+    b = torch.randn(nch, generator=g) * 0.1
+    w4 = torch.zeros(4, 9 * Cin, dtype=torch.float16)
+    w4[:nch] = w.permute(0, 2, 3, 1).reshape(nch, -1)
+    b4 = torch.zeros(4)
+    b4[:nch] = b
+    xin, w4d, b4d = x.permute(0, 2, 3, 1).contiguous().to(dev), w4.to(dev), b4.to(dev)
+    ref = F.conv2d(x.float(), w.float(), b, padding=1)
+
+    def run(flags):
+        out = torch.full((N, nch, H, W), float("nan"), device=dev)
+        hip.gemm_select(flags << 4)
+        try:
+            hip.check(L.lfm_conv3x3_out_f32(hip.ptr(xin), hip.ptr(w4d), hip.ptr(b4d), hip.ptr(out), N, H, W, Cin, nch, hip.stream_ptr()), "out conv")
+        finally:
+            hip.gemm_select(0)
+        return out.cpu()
+
+    halo = run(16777216)
+    assert torch.isfinite(halo).all()
+    assert rel_l2(halo, ref) < 1e-4  # fp32 accumulation and output: only the summation order differs from torch
+    assert rel_l2(run(8388608), halo) < 1e-5
