@@ -245,10 +245,110 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
   }
 }
 
+// The same on the matrix cores (Cout % 64 == 0): the scalar kernel above runs at 16 TFLOP/s and had become 1.5 % of a celeb512 UNet evaluation.
+// A workgroup walks chunks of 64 pixels: its 256 threads gather the im2col rows (k = c * 9 + tap, zero beyond the border and beyond Cin * 9) once into
+// the LDS, split hi / lo into two fp16 planes (x = hi + lo to 2^-22: three MFMAs -- w_hi x_hi + w_hi x_lo + w_lo x_hi -- are the fp32 dot product to
+// ~2^-21, the fp32 arithmetic of the scalar kernel and of the reference's conv at TF32-or-better); the fp32 weights are split the same way once per
+// workgroup.  Wave w owns output channels [w Cout / 4, (w + 1) Cout / 4): D[channel][pixel] on v_mfma_f32_16x16x16_f16 with the weights as the A
+// operand, so a lane ends up with four consecutive channels of one pixel: 8-byte NHWC stores.  Bound: the fp16 output write.
+#define CIM_PIX 64
+template <int NT>  // 16-channel tiles per wave = Cout / 64
+__global__ __launch_bounds__(256) void conv_in_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                           half_t* __restrict__ out, int N, int H, int W, int Cin, int Cout, int KS) {
+  extern __shared__ __attribute__((aligned(16))) char smraw[];
+  const int Kp = KS * 16, LD = Kp + 8, KK = Cin * 9;  // LDS row stride (halves): + 8 keeps 16 consecutive rows on distinct banks for the 8-byte reads
+  half_t* wh = (half_t*)smraw;                  // [Cout][LD]
+  half_t* wl = wh + (size_t)Cout * LD;
+  half_t* xh = wl + (size_t)Cout * LD;          // [CIM_PIX][LD]
+  half_t* xl = xh + CIM_PIX * LD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  for (int e = tid; e < Cout * Kp; e += 256) {
+    const int co = e / Kp, k = e - co * Kp;
+    const float v = k < KK ? w[(long)co * KK + k] : 0.f;
+    const half_t h = (half_t)v;
+    wh[co * LD + k] = h;
+    wl[co * LD + k] = (half_t)(v - (float)h);
+  }
+  const long total = (long)N * H * W;
+  const int c0 = wave * NT * 16;
+  f32x4 bias4[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bias4[nt] = *(const f32x4*)(b + c0 + nt * 16 + q * 4);
+  for (long p0 = (long)blockIdx.x * CIM_PIX; p0 < total; p0 += (long)gridDim.x * CIM_PIX) {
+    __syncthreads();  // the previous chunk's fragment reads are done (and, first time round, the weights are in place)
+    {
+      const long pix = p0 + (tid & 63);
+      const bool live = pix < total;
+      const int xx = live ? (int)(pix % W) : 0, yy = live ? (int)((pix / W) % H) : 0, n = live ? (int)(pix / ((long)H * W)) : 0;
+      for (int k = tid >> 6; k < Kp; k += 4) {
+        float v = 0.f;
+        if (live && k < KK) {
+          const int c = k / 9, t = k - c * 9, iy = yy + t / 3 - 1, ix = xx + t % 3 - 1;
+          if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = x[(((long)n * Cin + c) * H + iy) * W + ix];
+        }
+        const half_t h = (half_t)v;
+        xh[(tid & 63) * LD + k] = h;
+        xl[(tid & 63) * LD + k] = (half_t)(v - (float)h);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pt = 0; pt < CIM_PIX / 16; ++pt) {
+      f32x4 acc[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = bias4[nt];
+      for (int s = 0; s < KS; ++s) {
+        const half4_t bh = *(const half4_t*)(xh + (pt * 16 + r) * LD + s * 16 + q * 4), bl = *(const half4_t*)(xl + (pt * 16 + r) * LD + s * 16 + q * 4);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const half4_t ah = *(const half4_t*)(wh + (c0 + nt * 16 + r) * LD + s * 16 + q * 4), al = *(const half4_t*)(wl + (c0 + nt * 16 + r) * LD + s * 16 + q * 4);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bl, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bh, acc[nt], 0, 0, 0);
+        }
+      }
+      const long pix = p0 + pt * 16 + r;  // lane holds channels c0 + 16 nt + 4 q .. + 3 of this pixel
+      if (pix < total) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          *(half4_t*)(out + pix * Cout + c0 + nt * 16 + q * 4) = (half4_t){(half_t)acc[nt].x, (half_t)acc[nt].y, (half_t)acc[nt].z, (half_t)acc[nt].w};
+      }
+    }
+  }
+}
+
+template <int NT>
+static int launch_conv_in_mfma(const float* x, const float* w, const float* b, half_t* out, int N, int H, int W, int Cin, int Cout, hipStream_t st) {
+  const int KS = cdiv(Cin * 9, 16), LD = KS * 16 + 8;
+  const size_t lds = ((size_t)2 * Cout + 2 * CIM_PIX) * LD * 2;
+  if (lds > 160 * 1024) return 1;
+  static unsigned long long attr_set = 0;
+  int devid = 0;
+  (void)hipGetDevice(&devid);
+  if (!((attr_set >> (devid & 63)) & 1)) {
+    if (hipFuncSetAttribute((const void*)conv_in_mfma_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return LFM_ERR_LAUNCH;
+    attr_set |= 1ull << (devid & 63);
+  }
+  const long chunks = cdiv((long)N * H * W, CIM_PIX);
+  const int grid = (int)(chunks < 1024 ? chunks : 1024);  // a workgroup pays the weight split once and then walks its chunks
+  hipLaunchKernelGGL(conv_in_mfma_kernel<NT>, dim3(grid), dim3(256), lds, st, x, w, b, out, N, H, W, Cin, Cout, KS);
+  LFM_CHECK_LAUNCH();
+  return LFM_OK;
+}
+
 extern "C" int lfm_conv3x3_in_f32(const float* x_nchw, const float* w, const float* bias, void* out_nhwc, int N, int H, int W, int Cin,
                                   int Cout, lfm_stream_t stream) {
   if (!x_nchw || !w || !bias || !out_nhwc) return LFM_ERR_ARG;
   if (N <= 0 || Cin <= 0 || Cin > 16 || Cout % 8 || Cout / 8 > 256) return LFM_ERR_SHAPE;
+  if ((Cout == 64 || Cout == 128 || Cout == 192 || Cout == 256) && !((uintptr_t)out_nhwc & 7) && !((uintptr_t)bias & 15) &&
+      !(lfm_gemm_debug_flags() & 1)) {  // flag 1: the scalar kernel (A/B)
+    int rc;
+    if (Cout == 64) rc = launch_conv_in_mfma<1>(x_nchw, w, bias, (half_t*)out_nhwc, N, H, W, Cin, Cout, (hipStream_t)stream);
+    else if (Cout == 128) rc = launch_conv_in_mfma<2>(x_nchw, w, bias, (half_t*)out_nhwc, N, H, W, Cin, Cout, (hipStream_t)stream);
+    else if (Cout == 192) rc = launch_conv_in_mfma<3>(x_nchw, w, bias, (half_t*)out_nhwc, N, H, W, Cin, Cout, (hipStream_t)stream);
+    else rc = launch_conv_in_mfma<4>(x_nchw, w, bias, (half_t*)out_nhwc, N, H, W, Cin, Cout, (hipStream_t)stream);
+    if (rc != 1) return rc;
+  }
   const size_t lds = (size_t)Cin * 9 * Cout * 4;
   if (lds > 160 * 1024) return LFM_ERR_SHAPE;
   static bool set = false;

@@ -358,3 +358,38 @@ def test_halo_output_conv_vs_torch_and_the_implicit_gemm(N, H, W, Cin, nch):
     assert torch.isfinite(halo).all()
     assert rel_l2(halo, ref) < 1e-4  # fp32 accumulation and output: only the summation order differs from torch
     assert rel_l2(run(8388608), halo) < 1e-5
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 24, 40, 4, 256), (3, 16, 16, 9, 128), (1, 33, 17, 8, 192), (2, 8, 8, 16, 64)])
+def test_input_conv_mfma_vs_torch_and_the_scalar_kernel(N, H, W, Cin, Cout):
+    """lfm_conv3x3_in_f32 (fp32 NCHW latent -> fp16 NHWC, unet.py:416-420; 4 / 8 / 9 / 16 input channels = plain, semantic, inpainting, widest) on
+    the MFMA kernel with hi / lo-split operands against torch fp32 and against the scalar fp32 kernel (flag 1): the fp32 results agree to ~2^-20, so
+    after the fp16 rounding of the output the two kernels differ by at most one ulp, and only rarely."""
+    import torch.nn.functional as F
+
+    from lfm_amd import hip
+
+    dev = torch.device("cuda:0")
+    L = hip.lib()
+    g = torch.Generator().manual_seed(N + H + Cin + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g) * 1.5
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    ref = F.conv2d(x, w, b, padding=1)
+    xd, wd, bd = x.to(dev), w.reshape(Cout, -1).contiguous().to(dev), b.to(dev)
+
+    def run(flags):
+        out = torch.full((N * H * W, Cout), float("nan"), dtype=torch.float16, device=dev)
+        hip.gemm_select(flags << 4)
+        try:
+            hip.check(L.lfm_conv3x3_in_f32(hip.ptr(xd), hip.ptr(wd), hip.ptr(bd), hip.ptr(out), N, H, W, Cin, Cout, hip.stream_ptr()), "conv in")
+        finally:
+            hip.gemm_select(0)
+        return out.reshape(N, H, W, Cout).permute(0, 3, 1, 2).float().cpu()
+
+    got, scalar = run(0), run(1)
+    assert torch.isfinite(got).all()
+    assert rel_l2(got, ref) < 5e-4 and rel_l2(scalar, ref) < 5e-4
+    diff = (got - scalar).abs()
+    assert float(diff.max()) <= 2.0 ** -10 * float(ref.abs().max())
+    assert float((diff > 0).float().mean()) < 0.01
