@@ -331,3 +331,20 @@ def test_library_options_are_host_state_only():
         hip.set_option(99, 1)
     hip.set_option(hip.OPT_FOLD_LN, 0)
     hip.set_option(hip.OPT_FOLD_LN, 1)
+
+
+def test_conv_split_k_plan_for_the_small_maps():
+    """lfm_conv3x3_workspace_bytes is host-only arithmetic = the split-K plan of the UNets' low-resolution 3x3 convolutions (csrc/ops.hip): up to 256
+    tiles of 128x128 split (the 16x16 maps of the celeb512 UNet at batch 32 would otherwise run one four-wave workgroup per CU), to at most 512
+    workgroups, slices at least 128 deep and a multiple of 64; chip-filling problems need no workspace."""
+    from lfm_amd import hip
+
+    L = hip.lib()
+    ws = lambda n, h, cin, cout: L.lfm_conv3x3_workspace_bytes(n, h, h, cin, cout)
+    assert ws(32, 64, 256, 256) == 0 and ws(32, 32, 512, 512) == 0          # 2048 / 1024 tiles: no split
+    assert ws(32, 16, 512, 512) == 2 * 8192 * 512 * 4                        # 256 tiles -> two slices
+    assert ws(32, 16, 1024, 512) == 2 * 8192 * 512 * 4
+    assert ws(32, 8, 512, 512) == 8 * 2048 * 512 * 4                         # 64 tiles -> eight slices of K / 8 = 576
+    assert ws(32, 4, 1024, 1024) == 16 * 512 * 1024 * 4                      # 32 tiles -> sixteen slices of 576
+    assert ws(2, 8, 64, 128) == 0                                            # K = 576: a half (288) is not a multiple of the 64-deep K-tile
+    assert ws(0, 8, 64, 128) == 0
