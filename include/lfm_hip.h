@@ -116,8 +116,9 @@ int lfm_gemm_qkv_f16(const void* A, long lda, const void* W, long ldw, void* Q, 
 
 /* Kernel selection for the GEMMs: 0 = automatic (the 256x256 quadrant-phased kernel on 16x16x32 MFMAs for chip-filling shapes with K % 64 == 0,
  * the 256x128 two-workgroups-per-CU kernel for chip-filling shapes that are only 128 columns wide, the 128x128 kernel otherwise), 1 = force
- * 128x128, 4 = force 256x128, 5 = force 256x256 (other values are refused); | flags << 4 = ablation / A-B switches.  For measurement and parity
- * tests. */
+ * 128x128, 4 = force 256x128, 5 = force 256x256 with eight waves, 6 = force 256x256 with one wave per SIMD (128x128 wave tiles; row-major A
+ * operands, K % 64 == 0 -- other cases take kernel 5) (other values are refused); | flags << 4 = ablation / A-B switches.  For measurement and
+ * parity tests. */
 int lfm_gemm_select(int which);
 
 /* Measurement only: when enabled, every eager lfm_dit_forward records a HIP event pair around each block's fc1 GEMM (the
@@ -129,6 +130,12 @@ int lfm_profile_fc1(int enable);
  * (residual width a multiple of 256, whole 256-row tiles of one image or one shared conditioning row, chip-filling batch); 0 = always the separate
  * lfm_ln_modulate launches (the path every other shape takes).  Same result up to fp16 rounding of the operand (tests/test_gpu_dit.py). */
 #define LFM_OPT_FOLD_LN 1
+/* key 2 (LFM_OPT_GEMM_V6), value 0 / 1: the chip-filling row-major GEMMs (the four linears of a DiT block) on the one-wave-per-SIMD 256x256 kernel
+ * (csrc/gemm256w_kernel.h) instead of the eight-wave one.  Same accumulation order per output element: bit-identical results. */
+#define LFM_OPT_GEMM_V6 2
+/* key 3 (LFM_OPT_EPI_PREFETCH), value 0 / 1: the gated-residual epilogues of the eight-wave kernel on the folded path request the residual rows of
+ * the next 32-row pass before they issue the stores of the current one (the four-wave kernel always does).  Bit-identical results. */
+#define LFM_OPT_EPI_PREFETCH 3
 int lfm_set_option(int key, int value);
 
 /* Measurement only: s_memtime stamps written by the quadrant-phased GEMM (select flag 2) after every barrier of block 0,

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 typedef _Float16 half_t;
 typedef half_t half2_t __attribute__((ext_vector_type(2)));

@@ -18,17 +18,34 @@ int lfm_gemm_prefers_v4(int M, int N, int K) {
   return 0;
 }
 static int g_opt_fold_ln = 1;
+static int g_opt_v6 = 0;
+int lfm_gemm_v6_default() { return g_opt_v6; }
+static int g_opt_xpf = 0;  // producer epilogues of the eight-wave kernel request the next pass's residual rows ahead of the current pass's stores
+static inline EpiGateResidModP as_xpf(const EpiGateResidMod& e) {
+  static_assert(sizeof(EpiGateResidModP) == sizeof(EpiGateResidMod), "same members");
+  EpiGateResidModP p;
+  memcpy((void*)&p, (const void*)&e, sizeof p);
+  return p;
+}
 
 extern "C" int lfm_set_option(int key, int value) {  // key 1 (LFM_OPT_FOLD_LN): adaLN LayerNorm-modulate folded into the GEMM epilogues (default 1)
   if (key == 1) {
     g_opt_fold_ln = value != 0;
     return LFM_OK;
   }
+  if (key == 3) {  // LFM_OPT_EPI_PREFETCH
+    g_opt_xpf = value != 0;
+    return LFM_OK;
+  }
+  if (key == 2) {  // LFM_OPT_GEMM_V6: the one-wave-per-SIMD 256x256 kernel for the chip-filling row-major GEMMs
+    g_opt_v6 = value != 0;
+    return LFM_OK;
+  }
   return LFM_ERR_ARG;
 }
-extern "C" int lfm_gemm_select(int which) {  // low 4 bits: kernel choice (0 auto, 1, 4, 5); bits 4+: ablation flags (measurement only)
+extern "C" int lfm_gemm_select(int which) {  // low 4 bits: kernel choice (0 auto, 1, 4, 5, 6); bits 4+: ablation flags (measurement only)
   const int k = which & 15;
-  if (which < 0 || !(k == 0 || k == 1 || k == 4 || k == 5)) return LFM_ERR_ARG;
+  if (which < 0 || !(k == 0 || k == 1 || k == 4 || k == 5 || k == 6)) return LFM_ERR_ARG;
   g_gemm_sel = which & 15;
   g_gemm_dbg = which >> 4;
   return LFM_OK;
@@ -942,7 +959,7 @@ extern "C" int lfm_gemm_f16(const void* A, long lda, const void* W, long ldw, vo
 #ifdef LFM_MEASURE
       if (g_gemm_sel == 5 && (g_gemm_dbg & 2) && K % G256Q_BK == 0)  // measurement: the epilogue-stamped build of the 16x16x32 kernel
         return launch_gemm256h_tn<ASrcRowMajor, EpiBiasGeluF16, true>(a, (const half_t*)W, ldw, M, N, K, EpiBiasGeluF16{(half_t*)C, ldc, bias}, st);
-      if (g_gemm_sel == 5 && ((g_gemm_dbg >> 21) & 7) && K % G256Q_BK == 0) {  // measurement: main-loop ablations (flags 1..4 << 21)
+      if (g_gemm_sel == 5 && ((g_gemm_dbg >> 21) & 7) && K % G256Q_BK == 0) {  // measurement: main-loop ablations (flags 1..7 << 21)
         const EpiBiasGeluF16 e{(half_t*)C, ldc, bias};
         switch ((g_gemm_dbg >> 21) & 7) {
           case 1: return launch_gemm256h_tn<ASrcRowMajor, EpiBiasGeluF16, false, 1>(a, (const half_t*)W, ldw, M, N, K, e, st);
@@ -953,6 +970,17 @@ extern "C" int lfm_gemm_f16(const void* A, long lda, const void* W, long ldw, vo
           case 6: return launch_gemm256h_tn<ASrcRowMajor, EpiBiasGeluF16, false, 6>(a, (const half_t*)W, ldw, M, N, K, e, st);
           default: return (g_gemm_dbg & (1 << 24)) ? launch_gemm256h_tn<ASrcRowMajor, EpiBiasGeluF16, false, 8>(a, (const half_t*)W, ldw, M, N, K, e, st)
                                                    : launch_gemm256h_tn<ASrcRowMajor, EpiBiasGeluF16, false, 7>(a, (const half_t*)W, ldw, M, N, K, e, st);
+        }
+      }
+      if (g_gemm_sel == 6 && ((g_gemm_dbg >> 21) & 15) && K % G256Q_BK == 0) {  // measurement: v6 main-loop ablations (1..3 << 21) and DMA placement (8 << 21)
+        const EpiBiasGeluF16 e{(half_t*)C, ldc, bias};
+        switch ((g_gemm_dbg >> 21) & 15) {
+          case 1: return launch_gemm256w_tn<ASrcRowMajor, EpiBiasGeluF16, 1>(a, (const half_t*)W, ldw, M, N, K, e, st);
+          case 2: return launch_gemm256w_tn<ASrcRowMajor, EpiBiasGeluF16, 2>(a, (const half_t*)W, ldw, M, N, K, e, st);
+          case 3: return launch_gemm256w_tn<ASrcRowMajor, EpiBiasGeluF16, 3>(a, (const half_t*)W, ldw, M, N, K, e, st);
+          case 4: return launch_gemm256w_tn<ASrcRowMajor, EpiBiasGeluF16, 4>(a, (const half_t*)W, ldw, M, N, K, e, st);
+          case 8: return launch_gemm256w_tn<ASrcRowMajor, EpiBiasGeluF16, 0, 1>(a, (const half_t*)W, ldw, M, N, K, e, st);
+          default: return LFM_ERR_ARG;
         }
       }
 #endif
@@ -1070,7 +1098,8 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
   // folded LayerNorm-modulate: decided here because the */2 patch embedding can already play the first producer (see below)
   const int tiles_p = D / 256;
   const bool fold = g_opt_fold_ln && (D % 256 == 0) && (M % 256 == 0) && (rows == 1 || T % 256 == 0) && (long)(M / 256) * tiles_p >= 192 &&
-                    g_gemm_sel == 0 && (H % 64 == 0) && s->depth >= 1;
+                    (g_gemm_sel == 0 || g_gemm_sel == 6) && (H % 64 == 0) && s->depth >= 1;
+  const bool w6 = g_gemm_sel == 6 || (g_gemm_sel == 0 && g_opt_v6);  // the block GEMMs of the folded path on the one-wave-per-SIMD kernel
   const bool pe_mfma = s->patch == 2 && s->in_ch == 4 && (D % 256 == 0) && D <= 1280 && (s->res % 2 == 0) && !(g_gemm_dbg & 2097152);  // flag: round-1 kernel
   if (pe_mfma) {
     const int tpb = 2;
@@ -1130,32 +1159,37 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
     cen_cur ^= 1;
     return r;
   };
+  auto launch_fold = [&](const ASrcRowMajor& a, const half_t* Wp, long ldw_, int M_, int N_, int K_, const auto& e) {
+    return w6 ? launch_gemm256w_tn(a, Wp, ldw_, M_, N_, K_, e, st) : launch_gemm256h_tn(a, Wp, ldw_, M_, N_, K_, e, st);
+  };
   if (fold) {
     for (int i = 0; i < s->depth; ++i) {
       const float* mod = ws.mod + (long)i * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
       const float* uq = ws.uvq + (long)i * 2 * rows * 3 * D;
       const float* uf = ws.uvf + (long)i * 2 * rows * H;
       const EpiQKVMod e_qkv{Qb, Kb, Vb, uq, uq + (long)rows * 3 * D, uvs_q, D, D / s->heads, T, EpiQKV::log2_or_neg(T), rowstat_src(), nullptr, 0};
-      rc = launch_gemm256h_tn(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->qkv_w + (size_t)i * 3 * D * D, D, M, 3 * D, D, e_qkv, st);
+      rc = launch_fold(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->qkv_w + (size_t)i * 3 * D * D, D, M, 3 * D, D, e_qkv);
       if (rc) return rc;
       rc = attention_launch(Qb, Kb, Vb, ws.A, B, s->heads, D / s->heads, T, st);
       if (rc) return rc;
       // proj: X += gate_msa * (.), A' for fc1 with scale_mlp, partials; c = the row means the qkv GEMM just published
       const EpiGateResidMod e_proj{ws.X, D, w->proj_b + (size_t)i * D, mod + 2 * D, mstride, T, ws.A, mod + 4 * D, mstride, ws.cen[cen_cur], ws.ln_part, tiles_p};
-      rc = launch_gemm256h_tn(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D, e_proj, st);
+      rc = g_opt_xpf ? launch_fold(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D, as_xpf(e_proj))
+                     : launch_fold(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D, e_proj);
       if (rc) return rc;
       const bool prof = g_prof_on && g_prof_count < LFM_PROF_MAX;
       if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_count], st);
       const EpiModGeluF16 e_fc1{ws.QKVH, H, uf, uf + (long)rows * H, uvs_f, T, rowstat_src(), nullptr, 0};
-      rc = launch_gemm256h_tn(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->fc1_w + (size_t)i * H * D, D, M, H, D, e_fc1, st);
+      rc = launch_fold(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->fc1_w + (size_t)i * H * D, D, M, H, D, e_fc1);
       if (rc) return rc;
       if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_count++ + 1], st);
       if (i + 1 < s->depth) {  // fc2 writes the NEXT block's A' (its scale_msa)
         const EpiGateResidMod e_fc2{ws.X, D, w->fc2_b + (size_t)i * D, mod + 5 * D, mstride, T, ws.A, mod + 7 * D, mstride, ws.cen[cen_cur], ws.ln_part, tiles_p};
-        rc = launch_gemm256h_tn(ASrcRowMajor{ws.QKVH, H, M, 0}, (const half_t*)w->fc2_w + (size_t)i * D * H, H, M, D, H, e_fc2, st);
+        rc = g_opt_xpf ? launch_fold(ASrcRowMajor{ws.QKVH, H, M, 0}, (const half_t*)w->fc2_w + (size_t)i * D * H, H, M, D, H, as_xpf(e_fc2))
+                       : launch_fold(ASrcRowMajor{ws.QKVH, H, M, 0}, (const half_t*)w->fc2_w + (size_t)i * D * H, H, M, D, H, e_fc2);
       } else {
         const EpiGateResidF32 e_fc2{ws.X, D, w->fc2_b + (size_t)i * D, mod + 5 * D, mstride, T};
-        rc = launch_gemm256h_tn(ASrcRowMajor{ws.QKVH, H, M, 0}, (const half_t*)w->fc2_w + (size_t)i * D * H, H, M, D, H, e_fc2, st);
+        rc = launch_fold(ASrcRowMajor{ws.QKVH, H, M, 0}, (const half_t*)w->fc2_w + (size_t)i * D * H, H, M, D, H, e_fc2);
       }
       if (rc) return rc;
     }

@@ -197,6 +197,12 @@ __device__ __forceinline__ void g256h_epilogue_mod(f32x4_t (&acc)[8][4], char* s
   const f32x4 bias = *(const f32x4*)(epi.bias + n);
   const f32x4 gate = *(const f32x4*)(epi.gate + (long)img * epi.gate_stride + n);
   const f32x4 sc1 = *(const f32x4*)(epi.scale + (long)img * epi.mod_stride + n) + 1.0f;
+  f32x4 xo[2][8];  // [pass parity][row]: with Epi::xpf the next pass's rows are in flight while this pass's stores are issued
+  auto load_x = [&](int buf, int i) {
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) xo[buf][ps] = *(const f32x4*)(epi.X + (long)(m0 + g * 128 + i * 32 + rrow + ps * 4) * epi.ldx + n);
+  };
+  if constexpr (Epi::xpf) load_x(0, 0);
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -206,14 +212,16 @@ __device__ __forceinline__ void g256h_epilogue_mod(f32x4_t (&acc)[8][4], char* s
       for (int j = 0; j < 4; ++j) *(f32x4_t*)(scr + (h2 * 16 + l15) * 272 + (j * 16 + l4 * 4) * 4) = acc[2 * i + h2][j];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const int rl = g * 128 + i * 32 + rrow;  // + 4 ps: row inside the tile
-    f32x4 xo[8];
-#pragma unroll
-    for (int ps = 0; ps < 8; ++ps) xo[ps] = *(const f32x4*)(epi.X + (long)(m0 + rl + ps * 4) * epi.ldx + n);
+    if constexpr (Epi::xpf) {
+      if (i + 1 < 4) load_x((i + 1) & 1, i + 1);
+    } else {
+      load_x(i & 1, i);
+    }
 #pragma unroll
     for (int ps = 0; ps < 8; ++ps) {
       const f32x4 v = *(const f32x4*)(scr + (ps * 4 + rrow) * 272 + rcol * 16);
       const float c = cen_s[rl + ps * 4];
-      const f32x4 xn = xo[ps] + gate * (v + bias);
+      const f32x4 xn = xo[i & 1][ps] + gate * (v + bias);
       *(f32x4*)(epi.X + (long)(m0 + rl + ps * 4) * epi.ldx + n) = xn;
       const f32x4 d = xn - c;
       const f32x4 ap = d * sc1;
@@ -287,17 +295,11 @@ __device__ __forceinline__ void g256h_rowstat_finish(Epi& epi, const G256hRowSta
   epi.m0 = m0;
 }
 
+// One 128 x 64 accumulator block (rows g * 128 .., columns wn * 64 .. of the tile at m0, n0) through the epilogue `epi`; the wave's private scratch is
+// slot `wave`.  Shared by the 8-wave kernel below (one block per wave) and the 4-wave kernel of gemm256w_kernel.h (two blocks per wave).
 template <int BN, bool TRACE = false, class Epi>
-__device__ __forceinline__ void g256h_epilogue(f32x4_t (&acc)[8][4], char* smem, Epi& epi, int m0, int n0, int M, int N, int g, int wn, int lane,
-                                               int wave, int bz, long bsC, int dbg, bool swapped) {
-  const bool tr = TRACE && m0 == 0 && n0 == ((dbg >> 21) & 15) * BN && bz == 0;  // the stamped tile: row 0, column (flags >> 21) & 15
-  epi_batch(epi, bz, bsC, 0);
-  g256h_stamp<TRACE>(tr, g, wn, lane, 0);
-  if (dbg & 4) return;  // ablation: no epilogue
-  if constexpr (epi_is_producer_mod<Epi>::value) {
-    g256h_epilogue_mod(acc, smem, epi, m0, n0, n0 / BN, N, g, wn, lane, wave);
-    return;
-  }
+__device__ __forceinline__ void g256h_epilogue_body(f32x4_t (&acc)[8][4], char* smem, Epi& epi, int m0, int n0, int M, int N, int g, int wn, int lane,
+                                                    int wave, int dbg, bool swapped, bool tr) {
   const int l15 = lane & 15, l4 = lane >> 4;
   if constexpr (epi_has_transposed<Epi>::value) {
     // The K loop ran this tile with the MFMA operands swapped: acc[i][j][r] = C[m = 16 i + 4 l4 + r][n = 16 j + l15], FOUR CONSECUTIVE m per
@@ -403,6 +405,20 @@ __device__ __forceinline__ void g256h_epilogue(f32x4_t (&acc)[8][4], char* smem,
   g256h_epilogue_rows<BN, TRACE>(acc, smem, epi, m0, n0, M, N, g, wn, lane, wave, (dbg & 1024) != 0, tr);
   if constexpr (epi_has_finish_tile<Epi>::value) epi.finish_tile(m0, n0, g, wn, lane);
   g256h_stamp<TRACE>(tr, g, wn, lane, 17);
+}
+
+template <int BN, bool TRACE = false, class Epi>
+__device__ __forceinline__ void g256h_epilogue(f32x4_t (&acc)[8][4], char* smem, Epi& epi, int m0, int n0, int M, int N, int g, int wn, int lane,
+                                               int wave, int bz, long bsC, int dbg, bool swapped) {
+  const bool tr = TRACE && m0 == 0 && n0 == ((dbg >> 21) & 15) * BN && bz == 0;  // the stamped tile: row 0, column (flags >> 21) & 15
+  epi_batch(epi, bz, bsC, 0);
+  g256h_stamp<TRACE>(tr, g, wn, lane, 0);
+  if (dbg & 4) return;  // ablation: no epilogue
+  if constexpr (epi_is_producer_mod<Epi>::value) {
+    g256h_epilogue_mod(acc, smem, epi, m0, n0, n0 / BN, N, g, wn, lane, wave);
+    return;
+  }
+  g256h_epilogue_body<BN, TRACE>(acc, smem, epi, m0, n0, M, N, g, wn, lane, wave, dbg, swapped, tr);
 }
 
 // Round 3, where the main loop goes (tools/mainloop_ablation.py on an LFM_MEASURE build, profiles/r03_mainloop_ablation.txt; epilogue off, fc2 shape

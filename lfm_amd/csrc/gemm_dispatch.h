@@ -1,6 +1,14 @@
 // Kernel selection for every GEMM of the library (all generations share the operand / A-source / epilogue interfaces).
 #pragma once
-#include "gemm256h_kernel.h"
+#include <type_traits>
+#include "gemm256w_kernel.h"
+
+// v6 (gemm256w_kernel.h, one wave per SIMD) serves row-major A operands and epilogues without per-lane tile accumulators
+template <class ASrc, class Epi>
+struct gemm_v6_ok {
+  static constexpr bool value = std::is_same<ASrc, ASrcRowMajor>::value && !epi_has_finish_tile<Epi>::value;
+};
+int lfm_gemm_v6_default();  // 1: chip-filling row-major GEMMs with K % 64 == 0 take v6 instead of v5 (lfm_set_option key 2)
 
 // Dispatcher: the 256x256 kernel (16x16x32 MFMAs, gemm256h_kernel.h) when the problem fills the chip with such tiles and K % 64 == 0, the 256x128
 // two-per-CU kernel (gemm256n_kernel.h) for chip-filling problems that are only 128 columns wide (or where it measured faster, see
@@ -16,6 +24,7 @@ static inline int gemm_auto_choice(int M, int N, int K, int batch = 1) {
     const bool narrow = N > 64 && N < 256 && tiles128 >= 256;
     if (sel == 4 || (sel == 0 && (narrow || (big && lfm_gemm_prefers_v4(M, N, K))))) return 4;
   }
+  if (sel == 6 && (K % G256Q_BK) == 0) return 6;
   if ((sel == 5 || (sel == 0 && big)) && (K % G256Q_BK) == 0) return 5;
   return 1;
 }
@@ -32,6 +41,10 @@ static inline int launch_gemm_auto(const ASrc& asrc, const half_t* W, long ldw, 
     if (sel == 4 || (sel == 0 && (narrow || (big && lfm_gemm_prefers_v4(M, N, K)))))
       return launch_gemm256n_tn(asrc, W, ldw, M, N, K, epi, stream, batch, bsA, bsW, bsC);
   }
-  if ((sel == 5 || (sel == 0 && big)) && (K % G256Q_BK) == 0) return launch_gemm256h_tn(asrc, W, ldw, M, N, K, epi, stream, batch, bsA, bsW, bsC);
+  if constexpr (gemm_v6_ok<ASrc, Epi>::value) {
+    if ((sel == 6 || (sel == 0 && big && lfm_gemm_v6_default())) && (K % G256Q_BK) == 0 && (long)N * ldw < (1L << 31))
+      return launch_gemm256w_tn(asrc, W, ldw, M, N, K, epi, stream, batch, bsA, bsW, bsC);
+  }
+  if ((sel == 5 || sel == 6 || (sel == 0 && big)) && (K % G256Q_BK) == 0) return launch_gemm256h_tn(asrc, W, ldw, M, N, K, epi, stream, batch, bsA, bsW, bsC);
   return launch_gemm_tn(asrc, W, ldw, M, N, K, epi, stream, batch, bsA, bsW, bsC);
 }

@@ -187,7 +187,10 @@ struct RowStatSrc {
 };
 
 // X[m][n] += gate * (acc + bias)  AND  A'[m][n] = fp16((X[m][n] - c[m]) (1 + scale[n])),  part[m][tile_n] = (sum X, sum (X - c)^2)
-struct EpiGateResidMod {
+// XPF (round 4): the eight-wave kernel's epilogue requests the X rows of the NEXT 32-row pass before it issues the stores of the current one.
+template <bool XPF>
+struct EpiGateResidModT {
+  static constexpr bool xpf = XPF;
   float* X;
   long ldx;
   const float* bias;
@@ -215,6 +218,8 @@ struct EpiGateResidMod {
     *(f32x4*)(X + (long)m * ldx + n) = a.x + a.g * (v + a.b);
   }
 };
+typedef EpiGateResidModT<false> EpiGateResidMod;
+typedef EpiGateResidModT<true> EpiGateResidModP;
 template <class Epi, class = void>
 struct epi_is_producer_mod {
   static constexpr bool value = false;

@@ -177,7 +177,7 @@ def require_gpu(t, what):
 
 # ----------------------------------------------------------------------------- thin op wrappers (used by tests)
 def gemm_select(which):
-    """Force a GEMM kernel (0 auto, 1 128x128, 4 256x128, 5 256x256) | ablation flags << 4; A/B measurements
+    """Force a GEMM kernel (0 auto, 1 128x128, 4 256x128, 5 256x256 eight waves, 6 256x256 four waves) | ablation flags << 4; A/B measurements
     and parity tests only.  Raises on a value the library rejects (a silently ignored selection invalidates an A/B)."""
     check(lib().lfm_gemm_select(int(which)), "lfm_gemm_select")
 
@@ -215,6 +215,8 @@ def ln_modulate(X, shift, scale, tokens, mod_stride):
 
 
 OPT_FOLD_LN = 1  # adaLN LayerNorm-modulate folded into the GEMM epilogues, default on (include/lfm_hip.h)
+OPT_EPI_PREFETCH = 3  # producer epilogues of the eight-wave GEMM prefetch the next pass's residual rows (A/B; include/lfm_hip.h)
+OPT_GEMM_V6 = 2  # chip-filling row-major GEMMs on the one-wave-per-SIMD 256x256 kernel (csrc/gemm256w_kernel.h) instead of the 8-wave one
 
 
 def set_option(key, value):

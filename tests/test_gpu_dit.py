@@ -79,15 +79,16 @@ def _gemm_case(M, N, K, epi):
                                    (512, 256, 192), (256, 512, 320), (768, 512, 576), (512, 128, 96), (384, 132, 160), (256, 128, 32),
                                    (65536, 128, 1152)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
-@pytest.mark.parametrize("kernel", [4, 4 | (1024 << 4), 5, 5 | (1024 << 4)])
+@pytest.mark.parametrize("kernel", [4, 4 | (1024 << 4), 5, 5 | (1024 << 4), 6, 6 | (1024 << 4)])
 def test_gemm256_kernels(dev, M, N, K, epi, kernel):
     """Same checks with a 256-row kernel forced (lfm_gemm_select: 4 = the 256x128 two-workgroups-per-CU kernel, 4 | 1024<<4 = with the 8-byte-store
-    epilogue, 5 = the quadrant-phased 256x256 kernel on 16x16x32 MFMAs, the default for chip-filling shapes); K covers 1, 2, 3, 5, odd and even
+    epilogue, 5 = the quadrant-phased 256x256 kernel on 16x16x32 MFMAs, the default for chip-filling shapes, 6 = the one-wave-per-SIMD 256x256
+    kernel with 128x128 wave tiles, gemm256w_kernel.h); K covers 1, 2, 3, 5, odd and even
     numbers of 64-deep (and, for the 256x128 kernel, 32-deep) K-tiles, i.e. every prologue / tail path; N = 128 / 132 the narrow shapes; repeated
     launches screen for races."""
     if (kernel & 15) != 4 and M > 8192 and N == 128:
         pytest.skip("the narrow-N convolution shape is the 256x128 kernel's")
-    if (kernel & 15) == 5 and K % 64:
+    if (kernel & 15) in (5, 6) and K % 64:
         pytest.skip("64-deep K-tiles: every K on the reference path is a multiple of 64 (32-deep tails are the 256x128 kernel's)")
     from lfm_amd import hip
 
@@ -109,7 +110,7 @@ def test_gemm256_kernels(dev, M, N, K, epi, kernel):
         assert torch.equal(o, outs[0])  # deterministic across launches (no data race on the LDS stages)
 
 
-@pytest.mark.parametrize("kernel", [4, 5])
+@pytest.mark.parametrize("kernel", [4, 5, 6])
 def test_gemm256_detects_transpose(dev, kernel):
     from lfm_amd import hip
 
@@ -133,7 +134,7 @@ def _qkv_case(batch, tokens, D):
     return A, W, bias, A.float() @ W.float().t() + bias
 
 
-@pytest.mark.parametrize("kernel", [1, 4, 5, 5 | (1024 << 4)])
+@pytest.mark.parametrize("kernel", [1, 4, 5, 5 | (1024 << 4), 6, 6 | (1024 << 4)])
 @pytest.mark.parametrize("batch,tokens,D,hd", [(3, 256, 384, 64), (8, 64, 512, 64), (2, 256, 1024, 64), (2, 256, 1152, 72), (3, 64, 576, 72)])
 def test_gemm_qkv_split(dev, batch, tokens, D, hd, kernel):
     """Fused QKV projection: Q, K row-major, V transposed per head (timm Attention's qkv + reshape + permute, DiT.py:120), with
@@ -351,7 +352,7 @@ def _every_kernel_case(name, batch):
     return m, x, y, t, dit_ref.dit_forward(sd, cfg, t, x, y)
 
 
-@pytest.mark.parametrize("kernel", [1, 4, 5])
+@pytest.mark.parametrize("kernel", [1, 4, 5, 6])
 @pytest.mark.parametrize("name,batch", [("DiT-S/2", 5), ("DiT-B/2", 3), ("DiT-XL/2", 2)])
 def test_dit_with_every_gemm_kernel(dev, name, batch, kernel):
     """The same forward with each GEMM kernel forced (auto picks by size, so small test batches would never reach the 256x256
@@ -401,12 +402,14 @@ def test_forward_refuses_cpu():
         m(torch.tensor(0.5), torch.zeros(1, 4, 32, 32))
 
 
+@pytest.mark.parametrize("kernel", [0, 6])
 @pytest.mark.parametrize("name,batch,labels", [("DiT-L/2", 48, False), ("DiT-B/2", 64, True)])
-def test_folded_ln_epilogues_match_separate_launches_and_the_oracle(dev, name, batch, labels):
+def test_folded_ln_epilogues_match_separate_launches_and_the_oracle(dev, name, batch, labels, kernel):
     """lfm_set_option(LFM_OPT_FOLD_LN) (default on): LayerNorm-modulate folded into the proj / fc2 / qkv / fc1 epilogues must give the forward of the
     separate ln_modulate launches up to the fp16 rounding of the GEMM operand, be bit-repeatable (no atomics, no inter-workgroup waits), and stay
     inside the per-forward budget against the CPU oracle on its own.  The smallest batches that meet its preconditions: DiT-L/2 (4 column tiles,
-    one shared conditioning row) at 48, class-conditional DiT-B/2 (3 column tiles, one conditioning row PER IMAGE) at 64."""
+    one shared conditioning row) at 48, class-conditional DiT-B/2 (3 column tiles, one conditioning row PER IMAGE) at 64.  Both with the default
+    kernels and with the one-wave-per-SIMD kernel forced."""
     from lfm_amd import hip
     from lfm_amd.models import DiT_models
 
@@ -421,14 +424,18 @@ def test_folded_ln_epilogues_match_separate_launches_and_the_oracle(dev, name, b
     y = torch.randint(0, 1001, (batch,), generator=g) if labels else None
     t = torch.linspace(0.05, 0.95, batch) if labels else torch.tensor(0.6)
     xd, td, yd = x.to(dev), t.to(dev), (y.to(dev) if labels else None)
-    hip.set_option(hip.OPT_FOLD_LN, 0)
+    hip.gemm_select(kernel)  # 0: the default kernels; 6: producer / consumer epilogues of the one-wave-per-SIMD kernel (gemm256w_kernel.h)
     try:
-        base = m(td, xd, yd).clone()
+        hip.set_option(hip.OPT_FOLD_LN, 0)
+        try:
+            base = m(td, xd, yd).clone()
+        finally:
+            hip.set_option(hip.OPT_FOLD_LN, 1)
+        a = m(td, xd, yd).clone()
+        b = m(td, xd, yd).clone()
+        torch.cuda.synchronize()
     finally:
-        hip.set_option(hip.OPT_FOLD_LN, 1)
-    a = m(td, xd, yd).clone()
-    b = m(td, xd, yd).clone()
-    torch.cuda.synchronize()
+        hip.gemm_select(0)
     assert torch.equal(a, b)
     assert not torch.equal(a, base), "the folded path did not run (preconditions?)"
     assert rel_l2(a, base) < 1e-3
