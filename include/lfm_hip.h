@@ -88,6 +88,11 @@ typedef struct lfm_dit_call {
   float* out;             /* [batch, C, R, R]                                                         */
   const float* axpy_base; /* NULL: out = v.   else out = axpy_base + (*axpy_dt) * v  (may alias out)  */
   const float* axpy_dt;   /* device scalar (read at kernel run time => one captured graph per solver) */
+  /* ABI 3: per-grid conditioning table (lfm_dit_cond_table_build), or NULL.  Only for evaluations with ONE shared conditioning row (t_len == 1, y == NULL):
+   * everything the forward derives from t alone is then copied from table row *cond_step + cond_offset instead of being recomputed; t is not read. */
+  const void* cond_table;
+  const int* cond_step;   /* device int (a fixed-grid solver's interval counter) */
+  int cond_offset;
 } lfm_dit_call;
 
 /* Bytes of caller-owned scratch for batches up to max_batch: residual stream, LN / attention buffers, Q|K|Vt (reused for the fc1
@@ -99,6 +104,16 @@ size_t lfm_dit_workspace_bytes(const lfm_dit_shape* shape, int max_batch);
  * `denoiser` (test_flow_latent.py:55-59) and sampler/karras_sample.py:42-46. */
 int lfm_dit_forward(const lfm_dit_shape* shape, const lfm_dit_weights* w, void* workspace, size_t workspace_bytes,
                     const lfm_dit_call* call, lfm_stream_t stream);
+
+/* Per-grid conditioning tables for the unconditional models (test_args/{celeb256,ffhq,bed,church}_dit.txt: num_classes 1, no labels, scalar t -- the
+ * closure `denoiser` of test_flow_latent.py:55-59 calls model(t, x) with the solver's grid time): c = t_embedder(t), the adaLN modulation of every block and
+ * of the final layer (models/DiT.py:128, 170, 259-262) and the u / v rows of the folded LayerNorm path are pure functions of t, so a fixed-grid solver
+ * computes them ONCE per grid time.  Rows are written by the same launches an evaluation would make: results are bit-identical.
+ * t_values: device [n_times]; table: device, lfm_dit_cond_table_bytes(shape, n_times) bytes, 16-byte aligned; workspace / batch: as for lfm_dit_forward
+ * (scratch).  The table depends on the weights and on the grid, not on x. */
+size_t lfm_dit_cond_table_bytes(const lfm_dit_shape* shape, int n_times);
+int lfm_dit_cond_table_build(const lfm_dit_shape* shape, const lfm_dit_weights* w, void* workspace, size_t workspace_bytes, int batch, const float* t_values,
+                             int n_times, void* table, size_t table_bytes, lfm_stream_t stream);
 
 /* ------------------------------------------------------------------ building blocks (exported for parity tests)
  * C[M,N] (+)= A[M,K] * W[N,K]^T on MFMA, fp16 operands, fp32 accumulate.  epilogue:

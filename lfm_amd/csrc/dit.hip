@@ -896,7 +896,7 @@ extern "C" const char* lfm_strerror(int code) {
   }
   return "unknown";
 }
-extern "C" int lfm_abi_version(void) { return 2; }  // 2: lfm_time_embed takes label_rows
+extern "C" int lfm_abi_version(void) { return 3; }  // 2: lfm_time_embed takes label_rows; 3: lfm_dit_call carries the per-grid conditioning table
 
 extern "C" size_t lfm_dit_workspace_bytes(const lfm_dit_shape* shape, int max_batch) {
   if (check_shape(shape) != LFM_OK || max_batch <= 0) return 0;
@@ -971,6 +971,14 @@ extern "C" int lfm_gemm_f16(const void* A, long lda, const void* W, long ldw, vo
           default: return (g_gemm_dbg & (1 << 24)) ? launch_gemm256h_tn<ASrcRowMajor, EpiBiasGeluF16, false, 8>(a, (const half_t*)W, ldw, M, N, K, e, st)
                                                    : launch_gemm256h_tn<ASrcRowMajor, EpiBiasGeluF16, false, 7>(a, (const half_t*)W, ldw, M, N, K, e, st);
         }
+      }
+      if ((g_gemm_sel == 5 || g_gemm_sel == 6) && ((g_gemm_dbg >> 25) & 3) && K % G256Q_BK == 0) {  // measurement: OPT variants (1..3 << 25)
+        const EpiBiasGeluF16 e{(half_t*)C, ldc, bias};
+        const int o = (g_gemm_dbg >> 25) & 3;
+        if (g_gemm_sel == 6) return launch_gemm256w_tn<ASrcRowMajor, EpiBiasGeluF16, 0, 0, 1>(a, (const half_t*)W, ldw, M, N, K, e, st);
+        if (o == 1) return launch_gemm256h_tn<ASrcRowMajor, EpiBiasGeluF16, false, 0, 1>(a, (const half_t*)W, ldw, M, N, K, e, st);
+        if (o == 2) return launch_gemm256h_tn<ASrcRowMajor, EpiBiasGeluF16, false, 0, 2>(a, (const half_t*)W, ldw, M, N, K, e, st);
+        return launch_gemm256h_tn<ASrcRowMajor, EpiBiasGeluF16, false, 0, 3>(a, (const half_t*)W, ldw, M, N, K, e, st);
       }
       if (g_gemm_sel == 6 && ((g_gemm_dbg >> 21) & 15) && K % G256Q_BK == 0) {  // measurement: v6 main-loop ablations (1..3 << 21) and DMA placement (8 << 21)
         const EpiBiasGeluF16 e{(half_t*)C, ldc, bias};
@@ -1064,6 +1072,102 @@ extern "C" int lfm_attention_wg_trace_read(unsigned long long* host_out, int n_w
   return LFM_OK;
 }
 
+// ------------------------------------------------------------------ conditioning (everything the forward derives from t and y alone)
+// c = t_emb(t) (+ y_emb), the adaLN modulation rows of every block and of the final layer (DiT.py:252-262, 128, 170) and -- for the folded
+// LayerNorm path -- the u / v rows of the qkv and fc1 projections (gemm_kernel.h).  One function, so that the per-grid tables below are written by
+// exactly the launches a forward would make.
+static int dit_conditioning(const lfm_dit_shape* s, const lfm_dit_weights* w, const DitWs& ws, const float* t, int t_len, const int64_t* y, int rows,
+                            bool want_uv, hipStream_t st) {
+  const int D = s->hidden, H = s->mlp_hidden;
+  const long J = (long)s->depth * 6 * D + 2 * D;
+  const long mstride = rows == 1 ? 0 : J;
+  hipLaunchKernelGGL(temb1_kernel, dim3(cdiv(D, 4), t_len), dim3(256), 0, st, t, w->t_w0, w->t_b0, ws.temb_h, D);
+  LFM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(temb2_kernel, dim3(cdiv(D, 4), t_len), dim3(256), 0, st, ws.temb_h, w->t_w2, w->t_b2, ws.temb, D);
+  LFM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(cond_kernel, dim3(cdiv((long)rows * D, 256)), dim3(256), 0, st, ws.temb, t_len, w->y_table, y, s->label_rows, ws.c_half, D, rows);
+  LFM_CHECK_LAUNCH();
+  int rc = launch_gemm_tn(ASrcRowMajor{ws.c_half, D, rows, 0}, (const half_t*)w->ada_w, D, rows, (int)J, D, EpiBiasF32{ws.mod, J, w->ada_b}, st);
+  if (rc || !want_uv) return rc;
+  if (rows == 1 && D <= 8 * 64 * LN_MAXP) {  // one shared conditioning row: weight-streaming GEMVs (u, v of every block)
+    hipLaunchKernelGGL(uv_gemv_kernel, dim3(cdiv(3 * D, 4 * UV_ROWS), s->depth), dim3(256), 0, st, (const half_t*)w->qkv_w, w->qkv_b, ws.mod, 3 * D, D, D, 0,
+                       ws.uvq);
+    LFM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(uv_gemv_kernel, dim3(cdiv(H, 4 * UV_ROWS), s->depth), dim3(256), 0, st, (const half_t*)w->fc1_w, w->fc1_b, ws.mod, H, D, 4 * D, 3 * D,
+                       ws.uvf);
+    LFM_CHECK_LAUNCH();
+    return LFM_OK;
+  }
+  const long nmod = (long)s->depth * 4 * rows * (D / 4);
+  hipLaunchKernelGGL(mod_rows_f16_kernel, dim3(cdiv(nmod, 256)), dim3(256), 0, st, ws.mod, mstride, s->depth, rows, D, ws.amod);
+  LFM_CHECK_LAUNCH();
+  // u, v of every block in two batched GEMMs (batch = depth): [2 rows x D] x [D x 3D] and [2 rows x D] x [D x H]
+  rc = launch_gemm_auto(ASrcRowMajor{ws.amod, D, 2 * rows, 0}, (const half_t*)w->qkv_w, D, 2 * rows, 3 * D, D, EpiUV{ws.uvq, 3L * D, w->qkv_b, rows, 3L * D}, st,
+                        s->depth, 4L * rows * D, 3L * D * D, 2L * rows * 3 * D);
+  if (rc) return rc;
+  return launch_gemm_auto(ASrcRowMajor{ws.amod + 2L * rows * D, D, 2 * rows, 0}, (const half_t*)w->fc1_w, D, 2 * rows, H, D,
+                          EpiUV{ws.uvf, (long)H, w->fc1_b, rows, (long)H}, st, s->depth, 4L * rows * D, (long)H * D, 2L * rows * H);
+}
+
+// Per-grid conditioning tables (round 4).  For the unconditional models (one shared conditioning row: scalar t, no labels -- celeb256 / ffhq / bed /
+// church_dit.txt) the conditioning is a pure function of the grid time, yet every evaluation re-streamed the adaLN table (304 MB of weights for
+// DiT-L/2) and both u / v GEMVs: ~168 us = 1.6 % of an evaluation (profiles/r03_final_bench_kernel_stats.csv).  A table row holds, for one time,
+// [mod: J floats | uvq: depth * 2 * 3D | uvf: depth * 2 * H]; rows are written by dit_conditioning itself (bit-identical to the per-evaluation path)
+// and an evaluation copies its row into the workspace (one ~2 MB copy launch) -- the row index is read on the device, so one captured graph serves
+// every interval of the grid.
+static inline bool cond_uv_shape(const lfm_dit_shape* s) { return (s->hidden % 256) == 0 && (s->mlp_hidden % 64) == 0; }
+static inline long cond_row_floats(const lfm_dit_shape* s) {
+  const long D = s->hidden, H = s->mlp_hidden, J = (long)s->depth * 6 * D + 2 * D;
+  return J + (cond_uv_shape(s) ? (long)s->depth * 2 * (3 * D + H) : 0);
+}
+__global__ __launch_bounds__(256) void cond_row_copy_kernel(const float* __restrict__ table, long row_floats, const int* __restrict__ step, int offset,
+                                                            int fixed_row, float* __restrict__ mod, long nmod, float* __restrict__ uvq, long nq,
+                                                            float* __restrict__ uvf, long nf, int to_table) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= nmod + nq + nf) return;
+  const long row = step ? (long)(*step + offset) : (long)fixed_row;
+  float* ws = i < nmod ? mod + i : (i < nmod + nq ? uvq + (i - nmod) : uvf + (i - nmod - nq));  // nmod, nq, nf are multiples of 4
+  float* tb = (float*)table + row * row_floats + i;
+  if (to_table) *(f32x4*)tb = *(const f32x4*)ws;
+  else *(f32x4*)ws = *(const f32x4*)tb;
+}
+static int dit_cond_copy(const lfm_dit_shape* s, const DitWs& ws, const float* table, const int* step, int offset, int fixed_row, int to_table,
+                         hipStream_t st) {
+  const long D = s->hidden, H = s->mlp_hidden, J = (long)s->depth * 6 * D + 2 * D;
+  const long nq = cond_uv_shape(s) ? (long)s->depth * 2 * 3 * D : 0, nf = cond_uv_shape(s) ? (long)s->depth * 2 * H : 0;
+  hipLaunchKernelGGL(cond_row_copy_kernel, dim3(cdiv((J + nq + nf) / 4, 256)), dim3(256), 0, st, table, cond_row_floats(s), step, offset, fixed_row, ws.mod, J,
+                     ws.uvq, nq, ws.uvf, nf, to_table);
+  LFM_CHECK_LAUNCH();
+  return LFM_OK;
+}
+static int dit_cond_select(const lfm_dit_shape* s, const DitWs& ws, const float* table, const int* step, int offset, hipStream_t st) {
+  return dit_cond_copy(s, ws, table, step, offset, 0, 0, st);
+}
+
+extern "C" size_t lfm_dit_cond_table_bytes(const lfm_dit_shape* shape, int n_times) {
+  if (check_shape(shape) != LFM_OK || n_times <= 0) return 0;
+  return (size_t)cond_row_floats(shape) * 4 * (size_t)n_times;
+}
+
+extern "C" int lfm_dit_cond_table_build(const lfm_dit_shape* s, const lfm_dit_weights* w, void* workspace, size_t workspace_bytes, int batch,
+                                        const float* t_values, int n_times, void* table, size_t table_bytes, lfm_stream_t stream) {
+  int rc = check_shape(s);
+  if (rc) return rc;
+  if (!w || !workspace || !t_values || !table || n_times <= 0 || batch <= 0) return LFM_ERR_ARG;
+  if (table_bytes < lfm_dit_cond_table_bytes(s, n_times)) return LFM_ERR_WORKSPACE;
+  const DitWs ws = carve(s, batch, workspace);  // the buffers an evaluation at this batch would use (the conditioning part does not depend on it)
+  if (ws.total > workspace_bytes) return LFM_ERR_WORKSPACE;
+  if (((uintptr_t)workspace & 255) || ((uintptr_t)table & 15)) return LFM_ERR_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  for (int i = 0; i < n_times; ++i) {
+    rc = dit_conditioning(s, w, ws, t_values + i, 1, nullptr, 1, cond_uv_shape(s), st);
+    if (rc) return rc;
+    rc = dit_cond_copy(s, ws, (const float*)table, nullptr, 0, i, 1, st);
+    if (rc) return rc;
+  }
+  return LFM_OK;
+}
+
 extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w, void* workspace, size_t workspace_bytes,
                                const lfm_dit_call* c, lfm_stream_t stream) {
   int rc = check_shape(s);
@@ -1084,15 +1188,8 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
   // conditioning rows: one shared row when time is scalar and there are no labels
   const int rows = (c->t_len == 1 && !c->y) ? 1 : B;
   const long mstride = rows == 1 ? 0 : J;
-  hipLaunchKernelGGL(temb1_kernel, dim3(cdiv(D, 4), c->t_len), dim3(256), 0, st, c->t, w->t_w0, w->t_b0, ws.temb_h, D);
-  LFM_CHECK_LAUNCH();
-  hipLaunchKernelGGL(temb2_kernel, dim3(cdiv(D, 4), c->t_len), dim3(256), 0, st, ws.temb_h, w->t_w2, w->t_b2, ws.temb, D);
-  LFM_CHECK_LAUNCH();
-  hipLaunchKernelGGL(cond_kernel, dim3(cdiv((long)rows * D, 256)), dim3(256), 0, st, ws.temb, c->t_len, w->y_table, c->y, s->label_rows,
-                     ws.c_half, D, rows);
-  LFM_CHECK_LAUNCH();
-  rc = launch_gemm_tn(ASrcRowMajor{ws.c_half, D, rows, 0}, (const half_t*)w->ada_w, D, rows, (int)J, D, EpiBiasF32{ws.mod, J, w->ada_b}, st);
-  if (rc) return rc;
+  const bool tab = c->cond_table != nullptr;  // everything derived from t alone comes from a per-grid table (lfm_dit_cond_table_build)
+  if (tab && (rows != 1 || !c->cond_step)) return LFM_ERR_ARG;
 
   const int KK = s->in_ch * s->patch * s->patch;
   // folded LayerNorm-modulate: decided here because the */2 patch embedding can already play the first producer (see below)
@@ -1101,6 +1198,12 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
                     (g_gemm_sel == 0 || g_gemm_sel == 6) && (H % 64 == 0) && s->depth >= 1;
   const bool w6 = g_gemm_sel == 6 || (g_gemm_sel == 0 && g_opt_v6);  // the block GEMMs of the folded path on the one-wave-per-SIMD kernel
   const bool pe_mfma = s->patch == 2 && s->in_ch == 4 && (D % 256 == 0) && D <= 1280 && (s->res % 2 == 0) && !(g_gemm_dbg & 2097152);  // flag: round-1 kernel
+  if (tab) {
+    rc = dit_cond_select(s, ws, (const float*)c->cond_table, c->cond_step, c->cond_offset, st);
+  } else {
+    rc = dit_conditioning(s, w, ws, c->t, c->t_len, c->y, rows, fold, st);
+  }
+  if (rc) return rc;
   if (pe_mfma) {
     const int tpb = 2;
     hipLaunchKernelGGL(patch_embed_ln_kernel, dim3(cdiv(M, 16 * tpb)), dim3(64 * (D / 256)), 0, st, c->x, w->patch_w, w->patch_b, w->pos_embed, ws.X,
@@ -1129,25 +1232,6 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
   const long uvs_q = rows == 1 ? 0 : 3 * D, uvs_f = rows == 1 ? 0 : H;
   int cen_cur = 0;
   if (fold) {
-    if (rows == 1 && D <= 8 * 64 * LN_MAXP) {  // one shared conditioning row: weight-streaming GEMVs (u, v of every block)
-      hipLaunchKernelGGL(uv_gemv_kernel, dim3(cdiv(3 * D, 4 * UV_ROWS), s->depth), dim3(256), 0, st, (const half_t*)w->qkv_w, w->qkv_b, ws.mod, 3 * D, D,
-                         D, 0, ws.uvq);
-      LFM_CHECK_LAUNCH();
-      hipLaunchKernelGGL(uv_gemv_kernel, dim3(cdiv(H, 4 * UV_ROWS), s->depth), dim3(256), 0, st, (const half_t*)w->fc1_w, w->fc1_b, ws.mod, H, D, 4 * D,
-                         3 * D, ws.uvf);
-      LFM_CHECK_LAUNCH();
-    } else {
-      const long nmod = (long)s->depth * 4 * rows * (D / 4);
-      hipLaunchKernelGGL(mod_rows_f16_kernel, dim3(cdiv(nmod, 256)), dim3(256), 0, st, ws.mod, mstride, s->depth, rows, D, ws.amod);
-      LFM_CHECK_LAUNCH();
-      // u, v of every block in two batched GEMMs (batch = depth): [2 rows x D] x [D x 3D] and [2 rows x D] x [D x H]
-      rc = launch_gemm_auto(ASrcRowMajor{ws.amod, D, 2 * rows, 0}, (const half_t*)w->qkv_w, D, 2 * rows, 3 * D, D,
-                            EpiUV{ws.uvq, 3L * D, w->qkv_b, rows, 3L * D}, st, s->depth, 4L * rows * D, 3L * D * D, 2L * rows * 3 * D);
-      if (rc) return rc;
-      rc = launch_gemm_auto(ASrcRowMajor{ws.amod + 2L * rows * D, D, 2 * rows, 0}, (const half_t*)w->fc1_w, D, 2 * rows, H, D,
-                            EpiUV{ws.uvf, (long)H, w->fc1_b, rows, (long)H}, st, s->depth, 4L * rows * D, (long)H * D, 2L * rows * H);
-      if (rc) return rc;
-    }
     if (!pe_mfma) {  // (the MFMA patch embedding has already written A', the partials and the row means)
       hipLaunchKernelGGL(ln_center_mod_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, ws.X, ws.A, M, D, T, ws.mod + D, mstride, ws.ln_part, tiles_p,
                          ws.cen[0]);

@@ -440,7 +440,16 @@ __device__ __forceinline__ void g256h_epilogue(f32x4_t (&acc)[8][4], char* smem,
 // 3 = neither (the bare MFMA stream + barriers), 4 = static priority (s_setprio 1 for the second wave group, no per-phase flips),
 // 5 = 3 without the per-phase barriers (the bare MFMA stream), 6 = 3 with one barrier per K-tile instead of per phase,
 // 7 = 5 with the accumulators pinned (inline-asm MFMA, D = C), 8 = the full kernel with pinned accumulators
-template <class ASrc, class Epi, bool TRACE = false, int ABL = 0>
+// OPT (round 4): bit 0 = LDS-DMAs through buffer resources (ASrc::buffer_form sources; byte offsets < 2^31, checked at launch), bit 1 = a LOAD part
+// issues its first LDS-DMA BEFORE its fragment reads and the second one after them (a wave's VMEM instructions serialise at ~110 cycles each --
+// tools/ubench/ldsdma_rate.hip, one wave: 105-116 cycles per 1-KiB instruction in every addressing form -- so the second of two back-to-back issues
+// waits for the first; the reads in between cover that wait).
+// Measured (tools/dma_opt_probe.py, profiles/r04_dma_opt_probe.txt; bit-identical results): bit 0 -0.6 .. -2.1 us on the main loops of both 256x256 kernels
+// (252 -> 218 VGPRs in this one) = the default; bit 1 +1.5 .. +3 us = rejected.
+#ifndef G256H_DEFAULT_OPT
+#define G256H_DEFAULT_OPT 1
+#endif
+template <class ASrc, class Epi, bool TRACE = false, int ABL = 0, int OPT = G256H_DEFAULT_OPT>
 __global__ __launch_bounds__(512) void gemm256h_tn_kernel(ASrc asrc, const half_t* __restrict__ W, long ldw, int M, int N, int K, int tiles_n,
                                                            Epi epi, long bsA, long bsW, long bsC, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -471,15 +480,41 @@ __global__ __launch_bounds__(512) void gemm256h_tn_kernel(ASrc asrc, const half_
   const int nk = K / G256Q_BK;
   const int dma_off = wave * 1024;
   bool dma_on = true;  // (ABL 1 / 3 turn it off after the prologue)
-  auto issue_a = [&](int s, char* slot) {
+  constexpr bool BUFDMA = (OPT & 1) != 0 && asrc_has_buffer<ASrc>::value;
+  __amdgpu_buffer_rsrc_t rsa, rsw;
+  unsigned avoff[2][2], wvoff[2][2];
+  if constexpr (BUFDMA) {
+    rsa = asrc.rsrc();
+    rsw = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        avoff[s][p] = asrc.voff(arow[s][p], cswz);
+        const int n = n0 + (p * 2 + (tid >> 8)) * 64 + s * 32 + ((tid >> 3) & 31);
+        wvoff[s][p] = (unsigned)(((n < N ? n : N - 1) * (int)ldw + cswz) * 2);
+      }
+  }
+  // the two LDS-DMAs of a piece: P = 0 / 1 / 2 = both / the first / the second
+  auto issue_a = [&](int s, char* slot, int P = 0) {
     if ((ABL == 1 || ABL == 3 || (ABL >= 5 && ABL <= 7)) && !dma_on) return;
-    glds16(asrc.ptr(arow[s][0], cswz), slot + dma_off);
-    glds16(asrc.ptr(arow[s][1], cswz), slot + 8192 + dma_off);
+    if constexpr (BUFDMA) {
+      if (P != 2) glds16_buf(rsa, avoff[s][0], asrc.soff(), slot + dma_off);
+      if (P != 1) glds16_buf(rsa, avoff[s][1], asrc.soff(), slot + 8192 + dma_off);
+    } else {
+      if (P != 2) glds16(asrc.ptr(arow[s][0], cswz), slot + dma_off);
+      if (P != 1) glds16(asrc.ptr(arow[s][1], cswz), slot + 8192 + dma_off);
+    }
   };
-  auto issue_b = [&](int s, int kt, char* slot) {
+  auto issue_b = [&](int s, int kt, char* slot, int P = 0) {
     if ((ABL == 1 || ABL == 3 || (ABL >= 5 && ABL <= 7)) && !dma_on) return;
-    glds16(wrow[s][0] + kt * G256Q_BK, slot + dma_off);
-    glds16(wrow[s][1] + kt * G256Q_BK, slot + 8192 + dma_off);
+    if constexpr (BUFDMA) {
+      if (P != 2) glds16_buf(rsw, wvoff[s][0], (unsigned)kt * (G256Q_BK * 2), slot + dma_off);
+      if (P != 1) glds16_buf(rsw, wvoff[s][1], (unsigned)kt * (G256Q_BK * 2), slot + 8192 + dma_off);
+    } else {
+      if (P != 2) glds16(wrow[s][0] + kt * G256Q_BK, slot + dma_off);
+      if (P != 1) glds16(wrow[s][1] + kt * G256Q_BK, slot + 8192 + dma_off);
+    }
   };
 
   f32x4_t acc[8][4];
@@ -511,6 +546,24 @@ __global__ __launch_bounds__(512) void gemm256h_tn_kernel(ASrc asrc, const half_
     constexpr int PH = decltype(PHC)::value, BUF = decltype(BUFC)::value, HI = BUF * G256Q_BUF_BYTES;
     char* cur = smem + BUF * G256Q_BUF_BYTES;
     char* oth = smem + (BUF ^ 1) * G256Q_BUF_BYTES;
+    auto stage = [&](int P) {  // this phase's piece (P: which of its two LDS-DMAs)
+      if constexpr (PH == 0) {
+        if (s1) issue_b(1, t + 1, oth + G256Q_SLOT_B1, P);
+      } else if constexpr (PH == 1) {
+        if (s1) issue_a(1, oth + G256Q_SLOT_A1, P);
+      } else if constexpr (PH == 2) {
+        if (s2) {
+          if (P != 2) asrc.begin_tile(t + 2, G256Q_BK);
+          issue_a(0, cur + G256Q_SLOT_A0, P);
+        }
+      } else {
+        if (s2) issue_b(0, t + 2, cur + G256Q_SLOT_B0, P);
+      }
+    };
+    if constexpr ((OPT & 2) != 0) {
+      stage(1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     if constexpr (PH == 0) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -537,18 +590,7 @@ __global__ __launch_bounds__(512) void gemm256h_tn_kernel(ASrc asrc, const half_
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (PH == 0) {
-      if (s1) issue_b(1, t + 1, oth + G256Q_SLOT_B1);
-    } else if constexpr (PH == 1) {
-      if (s1) issue_a(1, oth + G256Q_SLOT_A1);
-    } else if constexpr (PH == 2) {
-      if (s2) {
-        asrc.begin_tile(t + 2, G256Q_BK);
-        issue_a(0, cur + G256Q_SLOT_A0);
-      }
-    } else {
-      if (s2) issue_b(0, t + 2, cur + G256Q_SLOT_B0);
-    }
+    stage((OPT & 2) != 0 ? 2 : 0);
     if constexpr (ABL == 1 || ABL == 3 || (ABL >= 5 && ABL <= 7)) {
       G256H_VMCNT(0);
     } else if (s2) G256H_VMCNT(6);  // pieces allowed in flight: 3 3 3 3 | 3 3 2 1 | 0 0 0 0
@@ -703,10 +745,13 @@ __global__ __launch_bounds__(512) void gemm256h_tn_kernel(ASrc asrc, const half_
   g256h_epilogue<G256_BN, TRACE>(acc, smem, epi, m0, n0, M, N, g, wn, lane, wave, bz, bsC, dbg, swapped);
 }
 
-template <class ASrc, class Epi, bool TRACE = false, int ABL = 0>
+template <class ASrc, class Epi, bool TRACE = false, int ABL = 0, int OPT = G256H_DEFAULT_OPT>
 static inline int launch_gemm256h_tn(const ASrc& asrc, const half_t* W, long ldw, int M, int N, int K, const Epi& epi, hipStream_t stream,
                                      int batch = 1, long bsA = 0, long bsW = 0, long bsC = 0) {
   if (!asrc_fits(asrc, 0)) return LFM_ERR_SHAPE;
+  if constexpr ((OPT & 1) != 0 && asrc_has_buffer<ASrc>::value) {  // byte offsets of the buffer-addressed LDS-DMAs (batched operands: per batch element)
+    if (!asrc_fits_buffer(asrc, 0) || (long)N * ldw >= (1L << 30)) return LFM_ERR_SHAPE;
+  }
   if (M <= 0 || N <= 0 || K <= 0 || (K % G256Q_BK) != 0 || (N % 4) != 0) return LFM_ERR_SHAPE;
   if ((ldw % 8) != 0 || ((uintptr_t)W & 15)) return LFM_ERR_ALIGN;
   const int tm = cdiv(M, G256_BM), tn = cdiv(N, G256_BN);
@@ -715,11 +760,11 @@ static inline int launch_gemm256h_tn(const ASrc& asrc, const half_t* W, long ldw
   int devid = 0;
   (void)hipGetDevice(&devid);
   if (!((attr_set >> (devid & 63)) & 1)) {
-    if (hipFuncSetAttribute((const void*)gemm256h_tn_kernel<ASrc, Epi, TRACE, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemm256h_tn_kernel<ASrc, Epi, TRACE, ABL, OPT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return LFM_ERR_LAUNCH;
     attr_set |= 1ull << (devid & 63);
   }
-  hipLaunchKernelGGL((gemm256h_tn_kernel<ASrc, Epi, TRACE, ABL>), dim3(tm * tn, batch), dim3(512), LDS, stream, asrc, W, ldw, M, N, K, tn, epi, bsA,
+  hipLaunchKernelGGL((gemm256h_tn_kernel<ASrc, Epi, TRACE, ABL, OPT>), dim3(tm * tn, batch), dim3(512), LDS, stream, asrc, W, ldw, M, N, K, tn, epi, bsA,
                      bsW, bsC, lfm_gemm_debug_flags());
   LFM_CHECK_LAUNCH();
   return LFM_OK;

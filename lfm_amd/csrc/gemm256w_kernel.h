@@ -120,7 +120,8 @@ __device__ __forceinline__ void g256w_epilogue_mod(f32x4_t (&acc)[2][8][4], char
 // 4 = 3 without the barrier and the waits in the middle of a K-tile (the bare MFMA stream).
 // VAR: where the sixteen LDS-DMAs of a K-tile go in its second step: 0 = one per group of four MFMAs, 1 = two per group in the first eight groups,
 //      2 = one per group, the position inside the group rotated by the wave id (the four SIMDs' issues do not coincide)
-template <class ASrc, class Epi, int ABL = 0, int VAR = 0>
+// OPT bit 0: LDS-DMAs through buffer resources (see gemm256h_kernel.h)
+template <class ASrc, class Epi, int ABL = 0, int VAR = 0, int OPT = G256H_DEFAULT_OPT>
 __global__ __launch_bounds__(256) void gemm256w_tn_kernel(ASrc asrc, const half_t* __restrict__ W, long ldw, int M, int N, int K, int tiles_n,
                                                            Epi epi, long bsA, long bsW, long bsC, int dbg) {
   static_assert(!epi_has_finish_tile<Epi>::value, "per-lane tile accumulators (GroupNorm statistics) assume one 128 x 64 block per wave");
@@ -150,10 +151,24 @@ __global__ __launch_bounds__(256) void gemm256w_tn_kernel(ASrc asrc, const half_
   }
   const int nk = K / G256Q_BK;
   const int dma_off = wave * 1024;
+  constexpr bool BUFDMA = (OPT & 1) != 0 && asrc_has_buffer<ASrc>::value;
+  __amdgpu_buffer_rsrc_t rsa, rsw;
+  unsigned avoff[8];
+  if constexpr (BUFDMA) {
+    rsa = asrc.rsrc();
+    rsw = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) avoff[p] = asrc.voff(arow[p], cswz);
+  }
   auto issue_dma = [&](auto DC, auto BUFC, int kt) {  // DMA d of 16 of K-tile kt into buffer BUF (begin_tile(kt) has been called)
     constexpr int D = decltype(DC)::value, BUF = decltype(BUFC)::value;
-    if constexpr (D < 8) glds16(asrc.ptr(arow[D], cswz), smem + BUF * G256W_BUF_BYTES + D * 4096 + dma_off);
-    else glds16((W + kt * G256Q_BK) + woff[D - 8], smem + BUF * G256W_BUF_BYTES + G256W_W_OFF + (D - 8) * 4096 + dma_off);
+    if constexpr (BUFDMA) {
+      if constexpr (D < 8) glds16_buf(rsa, avoff[D], asrc.soff(), smem + BUF * G256W_BUF_BYTES + D * 4096 + dma_off);
+      else glds16_buf(rsw, woff[D - 8] * 2u, (unsigned)kt * (G256Q_BK * 2), smem + BUF * G256W_BUF_BYTES + G256W_W_OFF + (D - 8) * 4096 + dma_off);
+    } else {
+      if constexpr (D < 8) glds16(asrc.ptr(arow[D], cswz), smem + BUF * G256W_BUF_BYTES + D * 4096 + dma_off);
+      else glds16((W + kt * G256Q_BK) + woff[D - 8], smem + BUF * G256W_BUF_BYTES + G256W_W_OFF + (D - 8) * 4096 + dma_off);
+    }
   };
 
   f32x4_t acc[2][8][4];  // [column half][16-row tile][16-column tile of the half]
@@ -315,12 +330,15 @@ __global__ __launch_bounds__(256) void gemm256w_tn_kernel(ASrc asrc, const half_
   }
 }
 
-template <class ASrc, class Epi, int ABL = 0, int VAR = 0>
+template <class ASrc, class Epi, int ABL = 0, int VAR = 0, int OPT = G256H_DEFAULT_OPT>
 static inline int launch_gemm256w_tn(const ASrc& asrc, const half_t* W, long ldw, int M, int N, int K, const Epi& epi, hipStream_t stream,
                                      int batch = 1, long bsA = 0, long bsW = 0, long bsC = 0) {
   if (!asrc_fits(asrc, 0)) return LFM_ERR_SHAPE;
   if (M <= 0 || N <= 0 || K <= 0 || (K % G256Q_BK) != 0 || (N % 4) != 0) return LFM_ERR_SHAPE;
-  if ((long)N * ldw >= (1L << 31)) return LFM_ERR_SHAPE;  // W rows are 32-bit element offsets
+  if ((long)N * ldw >= (1L << 30)) return LFM_ERR_SHAPE;  // W rows are 32-bit element offsets (byte offsets with OPT bit 0)
+  if constexpr ((OPT & 1) != 0 && asrc_has_buffer<ASrc>::value) {
+    if (!asrc_fits_buffer(asrc, 0)) return LFM_ERR_SHAPE;
+  }
   if ((ldw % 8) != 0 || ((uintptr_t)W & 15)) return LFM_ERR_ALIGN;
   const int tm = cdiv(M, G256_BM), tn = cdiv(N, G256_BN);
   constexpr int LDS = G256W_LDS_BYTES + (epi_has_rowstat<Epi>::value ? 2048 : 0);  // + rs[256][2] of the folded LayerNorm consumers
@@ -328,11 +346,11 @@ static inline int launch_gemm256w_tn(const ASrc& asrc, const half_t* W, long ldw
   int devid = 0;
   (void)hipGetDevice(&devid);
   if (!((attr_set >> (devid & 63)) & 1)) {
-    if (hipFuncSetAttribute((const void*)gemm256w_tn_kernel<ASrc, Epi, ABL, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemm256w_tn_kernel<ASrc, Epi, ABL, VAR, OPT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return LFM_ERR_LAUNCH;
     attr_set |= 1ull << (devid & 63);
   }
-  hipLaunchKernelGGL((gemm256w_tn_kernel<ASrc, Epi, ABL, VAR>), dim3(tm * tn, batch), dim3(256), LDS, stream, asrc, W, ldw, M, N, K, tn, epi, bsA,
+  hipLaunchKernelGGL((gemm256w_tn_kernel<ASrc, Epi, ABL, VAR, OPT>), dim3(tm * tn, batch), dim3(256), LDS, stream, asrc, W, ldw, M, N, K, tn, epi, bsA,
                      bsW, bsC, lfm_gemm_debug_flags());
   LFM_CHECK_LAUNCH();
   return LFM_OK;

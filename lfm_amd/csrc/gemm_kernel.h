@@ -48,7 +48,35 @@ struct ASrcRowMajor {
   __device__ __forceinline__ void begin_tile(int kt, int bk) { k0 = kt * bk; }
   __device__ __forceinline__ const half_t* ptr(const Row& r, int koff) const { return (A + k0) + (r.off + (unsigned)koff); }
   bool fits() const { return (long)M * lda < (1L << 31); }
+  // buffer-addressed LDS-DMA (round 4; tools/ubench/ldsdma_rate.hip: buffer_load_dwordx4 .. offen lds with an SGPR resource, a 32-bit VGPR byte
+  // offset and the K offset in an SGPR sustains 47.9 B/clk/CU from eight waves where global_load_lds with 64-bit VGPR addresses sustains 42.2, and
+  // needs no 64-bit VALU add per issue): resource over A, per-row byte offset, per-K-tile scalar offset.  Byte offsets < 2^31.
+  static constexpr bool buffer_form = true;
+  __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc() const { return __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7fffffff, 0x00020000); }
+  __device__ __forceinline__ unsigned voff(const Row& r, int koff) const { return (r.off + (unsigned)koff) * 2u; }
+  __device__ __forceinline__ unsigned soff() const { return (unsigned)k0 * 2u; }
+  bool fits_buffer() const { return (long)M * lda < (1L << 30); }
 };
+template <class ASrc, class = void>
+struct asrc_has_buffer {
+  static constexpr bool value = false;
+};
+template <class ASrc>
+struct asrc_has_buffer<ASrc, decltype((void)ASrc::buffer_form)> {
+  static constexpr bool value = ASrc::buffer_form;
+};
+template <class ASrc>
+static inline auto asrc_fits_buffer(const ASrc& a, int) -> decltype(a.fits_buffer()) {
+  return a.fits_buffer();
+}
+template <class ASrc>
+static inline bool asrc_fits_buffer(const ASrc&, long) {
+  return false;
+}
+// 16-byte LDS-DMA through a buffer resource: address = resource base + voff (VGPR, bytes) + soff (SGPR, bytes)
+__device__ __forceinline__ void glds16_buf(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, void* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_PTR(lds_wave_base), 16, (int)voff, (int)soff, 0, 0);
+}
 // A = [A1 | A2]: the K range [0, Ca) from A1 [M, Ca], [Ca, Ca + Cb) from A2 [M, Cb] (dense rows); Ca is a multiple of every kernel's K-tile depth,
 // so a K-tile lies in one of the two.  Not batched.
 struct ASrcRowMajor2 {

@@ -27,7 +27,8 @@ class DitWeights(C.Structure):
 
 class DitCall(C.Structure):
     _fields_ = [("batch", C.c_int), ("x", C.c_void_p), ("t", C.c_void_p), ("t_len", C.c_int), ("y", C.c_void_p),
-                ("cfg", C.c_int), ("cfg_scale", C.c_float), ("out", C.c_void_p), ("axpy_base", C.c_void_p), ("axpy_dt", C.c_void_p)]
+                ("cfg", C.c_int), ("cfg_scale", C.c_float), ("out", C.c_void_p), ("axpy_base", C.c_void_p), ("axpy_dt", C.c_void_p),
+                ("cond_table", C.c_void_p), ("cond_step", C.c_void_p), ("cond_offset", C.c_int)]
 
 
 def lib():
@@ -59,6 +60,10 @@ def lib():
     L.lfm_gemm_f16.restype = C.c_int
     L.lfm_gemm_f16.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int,
                                C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.c_int, C.c_void_p]
+    L.lfm_dit_cond_table_bytes.restype = C.c_size_t
+    L.lfm_dit_cond_table_bytes.argtypes = [C.c_void_p, C.c_int]
+    L.lfm_dit_cond_table_build.restype = C.c_int
+    L.lfm_dit_cond_table_build.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
     L.lfm_gemm_select.restype = C.c_int
     L.lfm_gemm_select.argtypes = [C.c_int]
     L.lfm_gemm_qkv_f16.restype = C.c_int

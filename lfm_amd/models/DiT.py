@@ -212,7 +212,25 @@ class DiT(nn.Module):
 
     # ---- the single entry to the device code
     @torch.no_grad()
-    def _run(self, t, x, y, cfg, cfg_scale, out=None, axpy_base=None, axpy_dt=None):
+    def cond_table(self, ts, batch):
+        """Per-grid conditioning table (include/lfm_hip.h: lfm_dit_cond_table_build) for the grid times `ts` (device fp32 [n]): what every evaluation of
+        an UNCONDITIONAL model at scalar time derives from t alone, one row per time.  Returns a device byte tensor to pass to _run(cond=...)."""
+        hip.require_gpu(ts, "DiT.cond_table")
+        w, _, shape = self._packed or self._pack()
+        ts = ts.detach().to(torch.float32).contiguous()
+        n = ts.numel()
+        nbytes = hip.lib().lfm_dit_cond_table_bytes(C.byref(shape), n)
+        if nbytes == 0:
+            raise hip.LfmHipError("lfm_dit_cond_table_bytes refused the shape")
+        table = torch.empty(nbytes, dtype=torch.uint8, device=ts.device)
+        ws = self._workspace(batch, ts.device)
+        rc = hip.lib().lfm_dit_cond_table_build(C.byref(shape), C.byref(w), hip.ptr(ws), ws.numel(), batch, hip.ptr(ts), n, hip.ptr(table), nbytes,
+                                                hip.stream_ptr(ts.device))
+        hip.check(rc, "lfm_dit_cond_table_build")
+        return table
+
+    @torch.no_grad()
+    def _run(self, t, x, y, cfg, cfg_scale, out=None, axpy_base=None, axpy_dt=None, cond=None):
         hip.require_gpu(x, "DiT.forward")
         if self.training:
             raise hip.LfmHipError("the HIP DiT is inference-only: call .eval() (label dropout / autograd are training features)")
@@ -225,6 +243,8 @@ class DiT(nn.Module):
         t = torch.as_tensor(t, device=x.device).float().reshape(-1).contiguous()
         if t.numel() not in (1, N):
             raise ValueError(f"t must have 1 or {N} elements, got {t.numel()}")
+        if cond is not None and (y is not None or t.numel() != 1):
+            raise ValueError("a per-grid conditioning table serves evaluations with ONE shared conditioning row (scalar t, no labels)")
         if y is not None:
             y = y.to(device=x.device, dtype=torch.long).contiguous()
             if y.numel() != N:
@@ -235,7 +255,9 @@ class DiT(nn.Module):
         ws = self._workspace(N, x.device)
         call = hip.DitCall(N, x.data_ptr(), t.data_ptr(), t.numel(), y.data_ptr() if y is not None else None, 1 if cfg else 0,
                            float(cfg_scale), out.data_ptr(), axpy_base.data_ptr() if axpy_base is not None else None,
-                           axpy_dt.data_ptr() if axpy_dt is not None else None)
+                           axpy_dt.data_ptr() if axpy_dt is not None else None,
+                           cond[0].data_ptr() if cond is not None else None, cond[1].data_ptr() if cond is not None else None,
+                           int(cond[2]) if cond is not None else 0)  # cond = (table, device step counter, row offset): see cond_table()
         rc = hip.lib().lfm_dit_forward(C.byref(shape), C.byref(w), hip.ptr(ws), ws.numel(), C.byref(call), hip.stream_ptr(x.device))
         hip.check(rc, "lfm_dit_forward")
         return out

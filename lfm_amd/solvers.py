@@ -11,6 +11,8 @@ hipGraph and replayed per interval; the time grid lives in device memory so the 
 """
 import math
 
+import os
+
 import torch
 
 from . import hip
@@ -404,6 +406,12 @@ class GraphedFixedGrid:
         self.use_graph = graph
         self.graphs = {}
         self._graph_gen = -1  # model buffer generation the graphs were captured against
+        # per-grid conditioning table (DiT.cond_table): unconditional DiT at scalar time only.  The captured graphs hold its address, so it lives in a
+        # persistent buffer that is only re-FILLED when the grid or the weights change (re-allocated, and the graphs dropped, when a longer grid arrives)
+        self.use_cond_table = self.is_dit and self.y is None and not self.use_cfg and os.environ.get("LFM_COND_TABLE", "1") != "0"
+        self.cond_buf = None
+        self._cond_key = None
+        self._grid_host = ()
 
     def set_grid(self, ts, dts):
         """Copy a time grid (n+1 times, n signed steps) INTO the persistent device buffers the captured graphs point at."""
@@ -413,14 +421,36 @@ class GraphedFixedGrid:
         self.ts[: n + 1].copy_(ts.to(torch.float32))
         self.dts[:n].copy_(dts.to(torch.float32))
         self.n_intervals = n
+        self._grid_host = tuple(float(v) for v in ts.detach().cpu().tolist())
+        self._refresh_cond()
+
+    def _refresh_cond(self):
+        """(Re)fill the conditioning table when the grid or the model's weights changed since it was written (run() asks too: a load_state_dict between
+        two solves on the same grid must not leave stale rows behind)."""
+        if not self.use_cond_table or self.n_intervals < 1:
+            return
+        n = self.n_intervals
+        if self._cond_key == (self._grid_host, getattr(self.model, "_gen", 0)):
+            return
+        table = self.model.cond_table(self.ts[: n + 1], self.batch)  # may (re)pack weights / size the workspace: read the generation after it
+        if self.cond_buf is None or self.cond_buf.numel() < table.numel():
+            self.cond_buf = table
+            self.graphs.clear()  # they point at the old buffer
+        else:
+            self.cond_buf[: table.numel()].copy_(table)
+        self._cond_key = (self._grid_host, getattr(self.model, "_gen", 0))
+
+    def _cond(self, offset):
+        """(table, interval counter, row offset) of an evaluation at grid time ts[step + offset]; _advance has already incremented the counter."""
+        return (self.cond_buf, self.step, offset) if self.use_cond_table and self.cond_buf is not None else None
 
     def _advance(self):
         hip.check(hip.lib().lfm_grid_advance(hip.ptr(self.ts), hip.ptr(self.dts), hip.ptr(self.step), hip.ptr(self.tcur), hip.ptr(self.tnext),
                                              hip.ptr(self.dt), hip.stream_ptr(self.dev)), "lfm_grid_advance")
 
-    def _velocity(self, t, x, out=None):
+    def _velocity(self, t, x, out=None, grid_offset=None):
         if self.is_dit:
-            return self.model._run(t, x, self.y, self.use_cfg, self.cfg_scale, out=out)
+            return self.model._run(t, x, self.y, self.use_cfg, self.cfg_scale, out=out, cond=None if grid_offset is None else self._cond(grid_offset))
         v = self.model(t, x, self.y)  # host-sequenced UNet: its launches are captured like any others
         if out is not None:
             out.copy_(v)
@@ -430,15 +460,15 @@ class GraphedFixedGrid:
     def _euler(self):
         self._advance()
         if self.is_dit:  # x <- x + dt*v fused into the model's last kernel
-            self.model._run(self.tcur, self.x, self.y, self.use_cfg, self.cfg_scale, out=self.x, axpy_base=self.x, axpy_dt=self.dt)
+            self.model._run(self.tcur, self.x, self.y, self.use_cfg, self.cfg_scale, out=self.x, axpy_base=self.x, axpy_dt=self.dt, cond=self._cond(-1))
         else:
             hip.lincomb(self.x, self.x, [self._velocity(self.tcur, self.x)], self.c1, self.dt)
 
     def _heun(self):
         self._advance()
-        d1 = self._velocity(self.tcur, self.x, out=self.d1)
+        d1 = self._velocity(self.tcur, self.x, out=self.d1, grid_offset=-1)  # at ts[k] (the counter already reads k + 1)
         hip.lincomb(self.xp, self.x, [d1], self.c1, self.dt)
-        d2 = self._velocity(self.tnext, self.xp, out=self.d2)
+        d2 = self._velocity(self.tnext, self.xp, out=self.d2, grid_offset=0)  # at ts[k + 1]
         hip.lincomb(self.x, self.x, [d1, d2], self.c2, self.dt)
 
     def _get(self, kind):
@@ -474,6 +504,7 @@ class GraphedFixedGrid:
         applied on interval i iff i < heun_limit - 1;  heun_limit = 0 means plain Euler."""
         assert self.n_intervals > 0, "set_grid first"
         n = self.n_intervals
+        self._refresh_cond()
         self.x.copy_(x0)
         self.step.zero_()
         n_heun = max(0, min(n, heun_limit - 1)) if heun_limit else 0

@@ -124,3 +124,34 @@ def test_fused_sampler_survives_repeated_calls_and_grid_changes():
         eager = sample_from_model(m, x0, {}, args)[-1]
         assert rel_l2(fused, eager) < 1e-5, h
         del junk
+
+
+@pytest.mark.parametrize("name,batch", [("DiT-S/2", 3), ("DiT-L/2", 48)])
+def test_cond_table_solve_is_bit_identical(name, batch):
+    """Per-grid conditioning tables (lfm_dit_cond_table_build: c, the adaLN modulation and the folded-LayerNorm u / v rows computed once per grid time for the
+    unconditional models) against the per-evaluation conditioning: same launches, so the Euler and the Heun solves must agree bit for bit -- for a model
+    on the separate-LayerNorm path (small batch) and for DiT-L/2 at a batch that takes the folded path (u / v rows from the table).  Then a grid change and a
+    weight reload: the table must follow both."""
+    from lfm_amd.solvers import GraphedFixedGrid, torchdiffeq_euler_grid
+
+    dev = torch.device("cuda:0")
+    cfg, sd, m = _mk(name, dev, num_classes=1, label_dropout=0.0)
+    x0 = torch.randn(batch, 4, 32, 32, generator=torch.Generator().manual_seed(5)).to(dev)
+    with_t, without = GraphedFixedGrid(m, batch), GraphedFixedGrid(m, batch)
+    assert with_t.use_cond_table
+    without.use_cond_table = False
+    for h in (0.25, 0.2):
+        ts, dts = torchdiffeq_euler_grid(h)
+        for s in (with_t, without):
+            s.set_grid(ts, dts)
+        assert with_t.cond_buf is not None and without.cond_buf is None
+        for heun_limit in (0, dts.numel()):
+            a = with_t.run(x0, heun_limit=heun_limit).clone()
+            b = without.run(x0, heun_limit=heun_limit).clone()
+            assert torch.equal(a, b), (name, h, heun_limit)
+    if name == "DiT-S/2":
+        m.load_state_dict(dit_ref.make_dit_state(cfg, seed=31), strict=True)
+        ts, dts = torchdiffeq_euler_grid(0.25)
+        for s in (with_t, without):
+            s.set_grid(ts, dts)
+        assert torch.equal(with_t.run(x0).clone(), without.run(x0).clone())
