@@ -5,13 +5,15 @@ the torchdiffeq grid (step_size 0.02, the path the reference actually runs) + f8
 Synthetic data: seeded random-init weights of the real architectures (de-zeroed), seeded Gaussian latents; one "step" = one full batch
 through the hot path, INCLUDING the host-to-device copy of its latents (64 x 16 KiB from pinned memory) -- everything else is resident.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5|6]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 --config selects another BASELINE.json configuration (same JSON contract, its own `roofline`):
   3  DiT-L/2 class-conditional, dopri5 rtol = atol = 1e-5, CFG 1.5, 64 live + 64 null rows, + decode
   4  DiT-B/2 imnet class-conditional, CFG 1.5, batch 256 (+256 null), 50-point Karras grid Heun with the reference's steps=40 quirk (88 NFE), + decode
   5  origin-ADM celeb512 (352 M parameters), batch 32, 64x64 latents, 50-step Euler + VAE decode at 512x512
+  6  EDM-style ADM UNet (models/EDM.py DhariwalUNet) at the test_args/{ffhq,bed}_adm.txt size (406 M parameters), batch 64, 50-step Euler + VAE decode (round 4;
+     not a BASELINE.json configuration: 3 of the reference's 11 arg files run this backbone)
 
 Ranks shard batches (weak scaling, no data-path collective during the solve); with N > 1 every batch ends with one RCCL
 all_gather_into_tensor of the uint8 images, issued on a side stream so that it overlaps the next batch's solve.
@@ -30,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense fp16/bf16 (MI355X_MICROARCH.md)
+EDM_FFHQ_FLOP_PER_IMAGE = 73.053765632e9  # one DhariwalUNet evaluation at the ffhq_adm size: hook-counted on the reference module (tests/golden/edm_full.pt, oracle/make_golden.py::golden_edm_full)
 CONFIG3_FIELD_GAIN = 100.0  # output-layer scale of config 3's synthetic field (see --field-gain)
 
 # L2-miss traffic of the dominant GEMM of config 2 (fc1: M 16384 x N 4096 x K 1024, folded-LayerNorm + GELU epilogue) per launch, from separate
@@ -44,7 +47,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=3)
     p.add_argument("--warmup", type=int, default=1)
-    p.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5])
+    p.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5, 6])
     p.add_argument("--batch", type=int, default=0, help="images per GPU per step (0 = the configuration's own)")
     p.add_argument("--model", type=str, default="", help="override the DiT of configs 2-4")
     p.add_argument("--nfe", type=int, default=50)
@@ -219,6 +222,24 @@ def build_workload(a, dev, rank):
                   "(88 NFE) + f8 VAE decode + uint8")
         extra["per_eval_flop"] = per_eval
         x_shape, res = (B, 4, 32, 32), 32
+    elif a.config == 6:
+        # EDM-style ADM UNet (models/EDM.py DhariwalUNet) at the size of test_args/{ffhq,bed}_adm.txt (USE_ORIGIN_ADM=false): 3 of the reference's 11 arg files run
+        # this backbone.  The arg files use dopri5; the bench line keeps the 50-step Euler grid of the headline so the numbers compare across backbones.
+        from argparse import Namespace
+
+        B = a.batch or 64
+        cfg = Namespace(use_origin_adm=False, layout=False, model_type="adm", image_size=256, f=8, num_in_channels=4, num_out_channels=4, nf=256,
+                        num_res_blocks=2, attn_resolutions=(16, 8, 4), dropout=0.0, ch_mult=(1, 2, 3, 4), label_dim=0, label_dropout=0.0, num_classes=1)
+        torch.manual_seed(0)
+        model = dezero_(create_network(cfg)).to(dev).eval()
+        ts, dts = torchdiffeq_euler_grid(1.0 / a.nfe)
+        solver = GraphedFixedGrid(model, B, resolution=32)
+        solver.set_grid(ts, dts)
+        solve = lambda x: solver.run(x)  # noqa: E731
+        f_model = a.nfe * EDM_FFHQ_FLOP_PER_IMAGE
+        wl = (f"EDM-style ADM UNet ffhq_adm (DhariwalUNet, 406 M params), 4x32x32 latents, batch {B}/GPU, {a.nfe}-step Euler (torchdiffeq grid) + f8 VAE decode to "
+              "256x256 + uint8 NHWC")
+        x_shape, res, extra = (B, 4, 32, 32), 32, {"nfe": a.nfe}
     else:
         from argparse import Namespace
 
@@ -237,7 +258,7 @@ def build_workload(a, dev, rank):
         x_shape, res, extra = (B, 4, 64, 64), 64, {"nfe": a.nfe}
     x_host = torch.randn(*x_shape, generator=g).pin_memory()
     return dict(model=model, vae=vae, solve=solve, B=B, res=res, x_host=x_host, workload=wl, f_model=f_model, f_vae=vae_decode_flops(res),
-                extra=extra, name=(a.model or {2: "DiT-L/2", 3: "DiT-L/2", 4: "DiT-B/2", 5: "ADM-celeb512"}[a.config]))
+                extra=extra, name=(a.model or {2: "DiT-L/2", 3: "DiT-L/2", 4: "DiT-B/2", 5: "ADM-celeb512", 6: "EDM-ADM-ffhq"}[a.config]))
 
 
 def roofline_dit(model, lat, rows, dev):
@@ -279,13 +300,13 @@ def roofline_dit(model, lat, rows, dev):
     return r
 
 
-def roofline_adm(B, dev):
+def roofline_adm(B, dev, side=64, ch=256):
     """Dominant kernel of config 5: the 3x3 implicit-GEMM convolution of the 64x64, 256-channel ResBlocks (M = B*4096 pixels, N = 256, K = 2304;
     8 of them per evaluation plus the 512-input ones of the up path).  Timed live with HIP events on the launching stream, standalone on
     random NHWC activations of the real shape."""
     from lfm_amd import hip
 
-    N, H, W, Cin, Cout = B, 64, 64, 256, 256
+    N, H, W, Cin, Cout = B, side, side, ch, ch
     x = (torch.randn(N * H * W, Cin, device=dev) * 0.5).half()
     w = (torch.randn(Cout, 9 * Cin, device=dev) * 0.02).half()
     b = torch.zeros(Cout, device=dev)
@@ -309,7 +330,7 @@ def roofline_adm(B, dev):
     ach = 2.0 * M * Cout * K / dur / 1e12
     return {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
             "algorithmic_bytes": 2.0 * (M * Cin + Cout * K + M * Cout), "algorithmic_flop": 2.0 * M * Cout * K,
-            "kernel": "conv3x3_halo_kernel<EpiResidF16,0> (3x3 conv 256->256 at 64x64, halo-tiled direct kernel)", "shape": {"M": M, "N": Cout, "K": K},
+            "kernel": f"conv3x3_halo_kernel<EpiResidF16,0> (3x3 conv {ch}->{ch} at {side}x{side}, halo-tiled direct kernel)", "shape": {"M": M, "N": Cout, "K": K},
             "avg_launch_us": dur * 1e6, "launches_timed": 10}
 
 
@@ -465,6 +486,8 @@ def main():
     if rank == 0 and not a.no_roofline:
         if a.config == 5:
             res["roofline"] = roofline_adm(B, dev)
+        elif a.config == 6:  # the 32x32 level (256 channels: 10 of the evaluation's 3x3 convolutions run at this shape or its 512-input variant)
+            res["roofline"] = roofline_adm(B, dev, side=32, ch=256)
         else:
             res["roofline"] = roofline_dit(w["model"], lat, B if a.config == 2 else 2 * B, dev)
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.config == 2:

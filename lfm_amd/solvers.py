@@ -364,10 +364,11 @@ def torchdiffeq_euler_grid(step_size, device=None):
 # ============================================================================ fused, graph-captured fixed grid
 def fused_fixed_grid_available(model, x):
     from .models.DiT import DiT
+    from .models.EDM import DhariwalUNet
     from .models.unet import UNetModel
 
     inner = getattr(model, "model", None) if type(model).__name__ == "WrapperCondFlow" else model  # downstream-task conditioning wrapper
-    return isinstance(inner, (DiT, UNetModel)) and x.is_cuda and not inner.training
+    return isinstance(inner, (DiT, UNetModel, DhariwalUNet)) and x.is_cuda and not inner.training
 
 
 class GraphedFixedGrid:
