@@ -153,6 +153,7 @@ class Dopri5:
         # time is kept twice, as device tensors for the kernels and as host doubles for the control flow (same IEEE arithmetic, no read-back)
         self._dev = bool(y0.is_cuda and y0.dtype == torch.float32 and y0.is_contiguous() and y0.numel() % 4 == 0 and len(self.E) <= 8
                          and float(rtol) == rtol and float(atol) == atol)
+        self._y_like = y0
         if self._dev:
             dv = y0.device
             self._cB = [torch.tensor(b, dtype=torch.float32, device=dv) for b in self.B]
@@ -160,7 +161,7 @@ class Dopri5:
             self._cSOL = None if self.SOL is None else torch.tensor(self.SOL, dtype=torch.float32, device=dv)
             self._scratch = torch.empty(1024, dtype=torch.float32, device=dv)
             self._ratio = torch.empty(1, dtype=torch.float32, device=dv)
-        f0 = f(t0, y0)
+        f0 = self._stage(f(t0, y0))
         self.y0, self.f0 = y0, f0
         self.t0 = self.t1 = t0
         self._t0_h = self._t1_h = float(t0)
@@ -188,6 +189,21 @@ class Dopri5:
             h1 = (0.01 / torch.max(d1, d2)) ** (1.0 / (order + 1))
         return torch.min(100 * h0, h1).to(t0.dtype)
 
+    def _stage(self, k):
+        """A stage derivative as the device kernels need it.  odeint() is a generic torchdiffeq-style API: `func` may return an expanded / permuted view,
+        another dtype (the reverse-time wrapper preserves strides) or a tensor on another device.  lfm_lincomb / lfm_rk_error_norm take raw pointers to dense
+        fp32 arrays of y0's length, so anything else is coerced here (one copy), and a result that cannot be coerced turns the device path off."""
+        if not self._dev:
+            return k
+        y0 = self.y0 if hasattr(self, "y0") else None
+        ref = y0 if y0 is not None else self._y_like
+        if torch.is_tensor(k) and k.shape == ref.shape and k.device == ref.device:
+            if k.dtype != ref.dtype or not k.is_contiguous():
+                k = k.to(ref.dtype).contiguous()
+            return k
+        self._dev = False  # a broadcastable / off-device result: the eager combinations below handle it as torch would
+        return k
+
     def _lin(self, base, ks, coef_dev, coef_host, dty):
         """base + dty * sum coef_j k_j: one lincomb launch on the device path, eager torch otherwise."""
         if self._dev and len(ks) <= 8:
@@ -204,7 +220,7 @@ class Dopri5:
         yi = y0
         for i, (a, b) in enumerate(zip(self.A, self.B)):
             yi = self._lin(y0, k, self._cB[i] if self._dev else None, b, dty)
-            k.append(self.f(t1y if a == 1.0 else t0y + a * dty, yi))
+            k.append(self._stage(self.f(t1y if a == 1.0 else t0y + a * dty, yi)))
         # FSAL pairs: the last stage IS the solution; otherwise (adaptive_heun) the solution is its own combination and -- as in
         # torchdiffeq's _runge_kutta_step -- the last stage's derivative still serves as f1 of the next step
         y1 = yi if self.SOL is None else self._lin(y0, k, self._cSOL if self._dev else None, self.SOL, dty)

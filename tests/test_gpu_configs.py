@@ -208,6 +208,59 @@ def test_adm_celeb512_vs_oracle(dev):
         assert rel_l2(out, ref) < 3e-3, sel
 
 
+def test_adm_celeb512_full_batch_vs_oracle(dev):
+    """BASELINE config 5 at its REAL batch (N = 32: M = 131072 pixels at 64x64): the automatic dispatch now picks the chip-filling kernels -- halo
+    convolutions with the XCD remap, split-K plans of the small maps, the MFMA attention, the two-source ops -- that the N = 2 case above never
+    reaches.  Images are independent, so the CPU oracle checks the first three; two runs must agree bit for bit (deterministic GroupNorm statistics and
+    split-K reductions)."""
+    from lfm_amd.models import create_network
+
+    sd = unet_ref.make_unet_state(CELEB512_CFG, seed=3)
+    m = create_network(Namespace(**CELEB512_ARGS))
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).eval()
+    N, k = 32, 3
+    x0 = torch.randn(N, 4, 64, 64, generator=torch.Generator().manual_seed(6))
+    t = torch.linspace(0.95, 0.05, N)
+    a = m(t.to(dev), x0.to(dev)).clone()
+    b = m(t.to(dev), x0.to(dev)).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    ref = unet_ref.unet_forward(sd, CELEB512_CFG, t[:k], x0[:k])
+    assert rel_l2(a[:k], ref) < 3e-3
+    # the same images at N = 3 (other kernels by automatic dispatch) stay within the budget of each other
+    small = m(t[:k].to(dev), x0[:k].to(dev))
+    assert rel_l2(a[:k], small) < 3e-3
+
+
+def test_dit_b2_config4_full_rows_vs_oracle(dev):
+    """BASELINE config 4 at its REAL row count: DiT-B/2 imnet, 256 images + 256 null rows under CFG 1.5 with PER-IMAGE labels and times (M = 131072
+    token rows, one conditioning row per image: the per-image modulation / u-v paths of the folded LayerNorm at full size).  The oracle checks the
+    first three (cond, uncond) pairs; both output halves carry the guided field; two runs agree bit for bit."""
+    from lfm_amd.models import DiT_models
+
+    kw = dict(num_classes=1000, label_dropout=0.1)
+    cfg = dit_ref.DiTCfg.named("DiT-B/2", **kw)
+    sd = dit_ref.make_dit_state(cfg, seed=4)
+    m = DiT_models["DiT-B/2"](img_resolution=32, in_channels=4, **kw)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).eval()
+    B, k = 256, 3
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(B, 4, 32, 32, generator=g)
+    xx = torch.cat([x, x], 0)
+    y = torch.cat([torch.randint(0, 1000, (B,), generator=g), torch.full((B,), 1000)])
+    t = torch.cat([torch.linspace(0.98, 0.02, B)] * 2)
+    a = m.forward_with_cfg(t.to(dev), xx.to(dev), y.to(dev), cfg_scale=1.5).clone()
+    b = m.forward_with_cfg(t.to(dev), xx.to(dev), y.to(dev), cfg_scale=1.5).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    assert torch.equal(a[:B], a[B:])
+    idx = torch.cat([torch.arange(k), B + torch.arange(k)])
+    ref = dit_ref.dit_forward_with_cfg(sd, cfg, t[idx], xx[idx], y[idx], 1.5)
+    assert rel_l2(a[idx], ref) < 2e-3
+
+
 def test_vae_decode_512_vs_oracle(dev):
     """R = 64 (512x512 images): T = 4096 mid-attention tokens, 134 M-pixel activations."""
     from lfm_amd.autoencoder import AutoencoderKL

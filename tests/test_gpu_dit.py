@@ -447,8 +447,8 @@ def test_folded_ln_epilogues_match_separate_launches_and_the_oracle(dev, name, b
 @pytest.mark.parametrize("fold", [1, 0])
 def test_trained_like_dynamic_range(dev, fold):
     """Every other parity test runs on xavier / N(0, 0.02) weights.  A trained DiT has a few 'massive' residual channels, large adaLN scales and a wide
-    fc1: this case puts four residual channels at +-300 (through the patch-embedding bias, so they ride the residual stream through every block),
-    multiplies the adaLN scale rows by 8 and the fc1 weights by 4, and checks the forward against the fp32 oracle inside the usual per-forward budget
+    fc1: this case puts four residual channels at +-3000 (through the patch-embedding bias, so they ride the residual stream through every block),
+    multiplies the adaLN scale rows by 8 and the fc1 weights by 32 (fp16 fc1 activations beyond 64), and checks the forward against the fp32 oracle inside the usual per-forward budget
     -- with the LayerNorm folded into the GEMM epilogues (centred fp16 operand, one-pass shifted variance: the case this test was written for) and
     with the separate launches.  Finite output implies finite Q / K / V^T / H everywhere upstream (nothing masks an inf or NaN on this path); the last
     block's fp16 fc1 activation, still in the workspace, is checked directly."""
@@ -460,13 +460,13 @@ def test_trained_like_dynamic_range(dev, fold):
     cfg = dit_ref.DiTCfg.named(name, **kw)
     sd = dit_ref.make_dit_state(cfg, seed=11)
     D = cfg.hidden
-    sd["x_embedder.proj.bias"][[5, 100, 333, 700]] += torch.tensor([300.0, 300.0, -300.0, 300.0])
+    sd["x_embedder.proj.bias"][[5, 100, 333, 700]] += torch.tensor([3000.0, 3000.0, -3000.0, 3000.0])
     for i in range(cfg.depth):
         b = f"blocks.{i}."
         for lo in (D, 4 * D):  # scale_msa, scale_mlp rows of the adaLN table
             sd[b + "adaLN_modulation.1.weight"][lo:lo + D] *= 8.0
             sd[b + "adaLN_modulation.1.bias"][lo:lo + D] *= 8.0
-        sd[b + "mlp.fc1.weight"] *= 4.0
+        sd[b + "mlp.fc1.weight"] *= 32.0
     m = DiT_models[name](img_resolution=32, in_channels=4, **kw)
     m.load_state_dict(sd, strict=True)
     m = m.to(dev).eval()
@@ -488,4 +488,7 @@ def test_trained_like_dynamic_range(dev, fold):
     ws = m._ws[1]
     off = M * D * 4 + M * D * 2
     hb = ws[off:off + M * H * 2].view(torch.float16)
-    assert bool(torch.isfinite(hb).all()) and float(hb.abs().max()) > 4.0  # wider than on N(0, 0.02) weights, far from the fp16 range
+    print(f"dynamic range (fold={fold}): fc1 activation peak {float(hb.abs().max()):.1f}, residual peak {float(ws[:M * D * 4].view(torch.float32).abs().max()):.0f}, "
+          f"rel-L2 vs oracle {err:.2e}")
+    assert bool(torch.isfinite(hb).all()) and float(hb.abs().max()) >= 64.0  # round 4: two orders wider than on N(0, 0.02) weights, still far from 65504
+    assert float(ws[:M * D * 4].view(torch.float32).abs().max()) >= 2900.0  # the residual stream really carries the massive channels to the last block

@@ -155,3 +155,30 @@ def test_cond_table_solve_is_bit_identical(name, batch):
         for s in (with_t, without):
             s.set_grid(ts, dts)
         assert torch.equal(with_t.run(x0).clone(), without.run(x0).clone())
+
+
+@pytest.mark.parametrize("kind", ["transposed_view", "expanded", "float64"])
+def test_dopri5_device_path_accepts_generic_stage_tensors(kind):
+    """odeint() is a torchdiffeq-style API: the derivative may come back as a non-contiguous view, a broadcast (expanded) tensor or another dtype.  The device
+    fast path hands raw pointers to lfm_lincomb / lfm_rk_error_norm, so such results must be coerced (or the eager path taken) -- never read as dense fp32."""
+    from lfm_amd.solvers import odeint
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(12)
+    A = (torch.randn(16, 16, generator=g) * 0.4)
+    y0 = torch.randn(8, 16, 16, generator=g)
+    c = torch.randn(1, 1, 16, generator=g)
+
+    def field(t, y, A_, c_):
+        if kind == "transposed_view":
+            return (-(y.transpose(-1, -2).contiguous() @ A_)).transpose(-1, -2)  # same shape, permuted strides
+        if kind == "expanded":
+            return (c_ * (1.0 + t)).expand(y.shape) - 0.0 * y[..., :1]  # broadcast view (stride 0) of the right shape
+        return (-(y.double() @ A_.double()) * (1.0 + t.double()))  # fp64 result for an fp32 state
+
+    t = torch.tensor([0.0, 1.0])
+    ref = ode_ref.odeint(lambda tt, yy: field(tt, yy, A, c).to(yy.dtype) if kind == "float64" else field(tt, yy, A, c), y0, t, method="dopri5",
+                         rtol=1e-6, atol=1e-6)
+    Ad, cd = A.to(dev), c.to(dev)
+    got = odeint(lambda tt, yy: field(tt, yy, Ad, cd), y0.to(dev), t.to(dev), method="dopri5", rtol=1e-6, atol=1e-6)
+    assert rel_l2(got[-1], ref[-1]) < 1e-5, kind
