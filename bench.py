@@ -376,8 +376,11 @@ def main_stub(a, world, rank):
         dist.all_gather(allt, tt)
         el = max(float(t) for t in allt)
         assert len(got) == a.steps and all(b.shape[0] == B * world for b in got)
+        per_rank = [{"rank": r, "clock_mhz_under_mfma_load": None, "images_per_sec": B * a.steps / float(t)} for r, t in enumerate(allt)]
+    else:
+        per_rank = [{"rank": 0, "clock_mhz_under_mfma_load": None, "images_per_sec": B * a.steps / el}]
     if rank == 0:
-        print(json.dumps({"metric": "images/sec", "value": world * B * a.steps / el, "unit": "images/sec", "n_gpus": world, "steps": a.steps,
+        print(json.dumps({"per_rank": per_rank, "metric": "images/sec", "value": world * B * a.steps / el, "unit": "images/sec", "n_gpus": world, "steps": a.steps,
                           "warmup": a.warmup, "ms_per_step": 1e3 * el / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": "u8", "data": "stub", "config": {"workload": "STUB (launcher rehearsal, not a measurement)", "sharding": f"dp{world}"},
                           "rccl_world": dist.get_world_size() if world > 1 else 1}), flush=True)
@@ -482,6 +485,19 @@ def main():
     ev[2].record()
     torch.cuda.synchronize()
     res["split_ms"] = {"solver": ev[0].elapsed_time(ev[1]), "vae_decode_u8": ev[1].elapsed_time(ev[2])}
+    # what every rank ran at: the clock its GPU sustains under matrix load (boxes / GPUs differ by several percent under the power cap) and its own
+    # solve / decode times -- so that a multi-GPU line explains its own spread
+    from lfm_amd import hip as _hip
+
+    mine = torch.tensor([_hip.effective_clock_mhz(dev), res["split_ms"]["solver"], res["split_ms"]["vae_decode_u8"], B * a.steps / el_local], device=dev,
+                        dtype=torch.float64)
+    per = [mine]
+    if world > 1:
+        per = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(per, mine)
+    res["per_rank"] = [{"rank": r, "clock_mhz_under_mfma_load": round(float(v[0]), 1), "solver_ms": round(float(v[1]), 3), "vae_decode_u8_ms": round(float(v[2]), 3),
+                        "images_per_sec": round(float(v[3]), 3)} for r, v in enumerate(per)]
+    res["clock_mhz_under_mfma_load"] = res["per_rank"][0]["clock_mhz_under_mfma_load"]
 
     if rank == 0 and not a.no_roofline:
         if a.config == 5:

@@ -153,6 +153,11 @@ int lfm_profile_fc1(int enable);
 #define LFM_OPT_EPI_PREFETCH 3
 int lfm_set_option(int key, int value);
 
+/* Measurement aid (bench.py): the clock the chip sustains under matrix load.  `blocks` workgroups of 512 threads each stream iters x 64 MFMAs per wave on
+ * pseudo-random fp16 operands between two s_memtime reads; ticks_out[blocks] (device) receives the tick count of every workgroup (one tick = one shader
+ * cycle).  Sustained clock = ticks / the launch's wall time (HIP events around the call). */
+int lfm_clock_probe(int blocks, int iters, unsigned long long* ticks_out, lfm_stream_t stream);
+
 /* Measurement only: s_memtime stamps written by the quadrant-phased GEMM (select flag 2) after every barrier of block 0,
  * wave groups 0 and 1; host_out receives 2 x n_per_group values. */
 int lfm_gemm_trace_read(unsigned long long* host_out, int n_per_group);

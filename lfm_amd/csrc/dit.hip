@@ -1345,6 +1345,49 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
   return LFM_OK;
 }
 
+// ------------------------------------------------------------------ effective clock under matrix load (measurement aid for bench.py)
+// The GEMMs of this path run under the board power cap: boxes of the pool differ by 6-7 % in the clock they sustain, and a
+// roofline fraction means little without it.  One workgroup per CU streams v_mfma_f32_16x16x32_f16 on pseudo-random fp16 operands (the load the GEMMs
+// put on the chip) for `iters` x 64 instructions per wave and brackets the stream with s_memtime (one tick = one shader cycle, MI355X_MICROARCH.md):
+// ticks / wall time = the sustained clock.  out[0 .. blocks) = ticks per workgroup.
+__global__ __launch_bounds__(512) void clock_probe_kernel(unsigned long long* __restrict__ out, int iters, unsigned seed) {
+  half8_t a[4], b[4];
+  unsigned h = seed ^ (threadIdx.x * 2654435761u) ^ (blockIdx.x * 40503u);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      h = h * 1664525u + 1013904223u;
+      a[i][e] = (half_t)(((int)(h >> 16) & 1023) * (1.0f / 512.0f) - 1.0f);
+      h = h * 1664525u + 1013904223u;
+      b[i][e] = (half_t)(((int)(h >> 16) & 1023) * (1.0f / 512.0f) - 1.0f);
+    }
+  f32x4 c[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) c[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  unsigned long long t0, t1;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j & 3], b[(j >> 2) & 3], c[j], 0, 0, 0);
+  }
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) s += c[j][0] + c[j][3];
+  if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
+  if (s == 123.456f) out[blockIdx.x] = 0;  // keeps the accumulators live
+}
+
+extern "C" int lfm_clock_probe(int blocks, int iters, unsigned long long* ticks_out, lfm_stream_t stream) {
+  if (!ticks_out || blocks <= 0 || iters <= 0) return LFM_ERR_ARG;
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(512), 0, (hipStream_t)stream, ticks_out, iters, 12345u);
+  LFM_CHECK_LAUNCH();
+  return LFM_OK;
+}
+
 extern "C" int lfm_grid_advance(const float* ts, const float* dts, int* step, float* t_cur, float* t_next, float* dt_cur, lfm_stream_t stream) {
   if (!ts || !dts || !step || !t_cur || !t_next || !dt_cur) return LFM_ERR_ARG;
   hipLaunchKernelGGL(grid_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, ts, dts, step, t_cur, t_next, dt_cur);

@@ -64,6 +64,8 @@ def lib():
     L.lfm_dit_cond_table_bytes.argtypes = [C.c_void_p, C.c_int]
     L.lfm_dit_cond_table_build.restype = C.c_int
     L.lfm_dit_cond_table_build.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.lfm_clock_probe.restype = C.c_int
+    L.lfm_clock_probe.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.lfm_gemm_select.restype = C.c_int
     L.lfm_gemm_select.argtypes = [C.c_int]
     L.lfm_gemm_qkv_f16.restype = C.c_int
@@ -222,6 +224,22 @@ def ln_modulate(X, shift, scale, tokens, mod_stride):
 OPT_FOLD_LN = 1  # adaLN LayerNorm-modulate folded into the GEMM epilogues, default on (include/lfm_hip.h)
 OPT_EPI_PREFETCH = 3  # producer epilogues of the eight-wave GEMM prefetch the next pass's residual rows (A/B; include/lfm_hip.h)
 OPT_GEMM_V6 = 2  # chip-filling row-major GEMMs on the one-wave-per-SIMD 256x256 kernel (csrc/gemm256w_kernel.h) instead of the 8-wave one
+
+
+def effective_clock_mhz(device=None, iters=20000):
+    """The clock this GPU sustains under matrix load (lfm_clock_probe: one workgroup per CU streaming MFMAs on random operands for ~50 ms): s_memtime
+    ticks of the slowest workgroup over the launch's wall time.  Boxes differ by several percent under the board power cap."""
+    dev = torch.device(device or "cuda:0")
+    n = torch.cuda.get_device_properties(dev).multi_processor_count
+    ticks = torch.zeros(n, dtype=torch.int64, device=dev)
+    for it in (200, iters):  # a short warm-up launch, then the measured one
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(dev))
+        check(lib().lfm_clock_probe(n, it, ptr(ticks), stream_ptr(dev)), "lfm_clock_probe")
+        e1.record(torch.cuda.current_stream(dev))
+        torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1)
+    return float(ticks.max()) / (ms * 1e3)
 
 
 def set_option(key, value):

@@ -198,6 +198,7 @@ def test_bench_self_launches_two_gloo_ranks():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["rccl_world"] == 2 and j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "weak"
     assert j["value"] > 0 and abs(j["value"] - 2 * 4 * 3 / (j["ms_per_step"] * 3e-3)) < 1e-6 * j["value"]
+    assert [p["rank"] for p in j["per_rank"]] == [0, 1] and all(p["images_per_sec"] > 0 for p in j["per_rank"])  # every rank reports itself in the one line
 
 
 def test_bench_refuses_a_mismatched_world():
@@ -225,3 +226,73 @@ def test_bench_flop_closed_forms_match_the_oracle():
     for name in ("DiT-S/2", "DiT-B/2", "DiT-L/2", "DiT-XL/2", "DiT-B/4", "DiT-L/8"):
         c = dit_ref.DiTCfg.named(name, num_classes=1, label_dropout=0.0)
         assert bench.dit_flops_per_image(c.tokens, c.hidden, c.depth, c.patch * c.patch * c.in_ch) == dit_ref.dit_flops_per_image(c)
+
+
+# ----------------------------------------------------------------------------- world 8: the shape of the round-end scaling run
+def test_shard_plan_50000_images_world8_batch64():
+    """The reference's FID run (test_flow_latent_ddp.py:116-126,138; n_sample 50000) on one 8-GPU node at batch 64: 50000 is not a multiple of the global
+    batch 512, so 98 iterations sample 50176 images; every global file index 0 .. 50175 is produced exactly once, by the rank / iteration / local image
+    the reference's `index = j * world + rank + total` names."""
+    from lfm_amd.test_flow_latent_ddp import global_indices, shard_plan
+
+    world, B = 8, 64
+    total, per_rank, iters = shard_plan(50000, B, world)
+    assert (total, per_rank, iters) == (50176, 6272, 98)
+    seen = torch.zeros(total, dtype=torch.int32)
+    for it in range(iters):
+        for r in range(world):
+            idx = torch.tensor(global_indices(B, world, r, it))
+            assert idx[0] == it * B * world + r and idx[1] - idx[0] == world
+            seen[idx] += 1
+    assert bool((seen == 1).all())
+
+
+def _ddp_worker8(rank, world, port, q, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from lfm_amd import test_flow_latent_ddp as ddp
+
+    saved, calls = [], [0]
+
+    def build(a, d):
+        torch.manual_seed(a.seed)
+        return _StubModel().eval(), _StubVae()
+
+    def tag(img):  # instead of pixels: every image carries (rank, iteration, local index) so that rank 0 can check where the gather put it
+        it = calls[0]
+        calls[0] += 1
+        n = img.shape[0]
+        t = torch.zeros(n, 2, 2, 3, dtype=torch.uint8)
+        t[..., 0], t[..., 1], t[..., 2] = rank, it, torch.arange(n, dtype=torch.uint8).reshape(n, 1, 1)
+        return t
+
+    hooks = dict(backend="gloo", device="cpu", build_models=build, to_uint8=tag, save=lambda block, start: saved.append((start, block[:, 0, 0].clone())))
+    argv = ["--model_type", "DiT-S/2", "--image_size", "32", "--num_in_channels", "4", "--n_sample", "1000", "--batch_size", "64", "--method", "euler",
+            "--step_size", "0.5", "--generator", "determ", "--seed", "3", "--compute_fid", "--save_dir", outdir]
+    res = ddp.main(argv, hooks=hooks)
+    q.put((rank, res["total"], res["iters"], res["written"], [(s, b.tolist()) for s, b in saved]))
+
+
+def test_world8_ddp_main_gather_order(tmp_path):
+    """Eight gloo ranks through main(): n_sample 1000 at batch 64 -> 1024 images in 2 iterations (non-divisible tail).  Only rank 0 writes; block i starts at
+    file index i * 512 and position p of a block holds local image p // 8 of rank p % 8 of that iteration (the reference's j * world + rank)."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker8, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, total, iters, written, saved in res:
+        assert (total, iters) == (1024, 2)
+        if rank != 0:
+            assert saved == [] and written == []
+            continue
+        assert written == [(0, 512), (512, 512)]
+        assert [s for s, _ in saved] == [0, 512]
+        for i, (_, tags) in enumerate(saved):
+            for p, (r, it, j) in enumerate(tags):
+                assert (r, it, j) == (p % world, i, p // world), (i, p, r, it, j)
