@@ -158,6 +158,8 @@ int lfm_set_option(int key, int value);
  * cycle).  Sustained clock = ticks / the launch's wall time (HIP events around the call). */
 int lfm_clock_probe(int blocks, int iters, unsigned long long* ticks_out, lfm_stream_t stream);
 
+/* ---- measurement-only entry points: exported by LFM_MEASURE builds of the library only (LFM_MEASURE=1 python -m lfm_amd._build; tools/README.md) */
+#ifdef LFM_MEASURE
 /* Measurement only: s_memtime stamps written by the quadrant-phased GEMM (select flag 2) after every barrier of block 0,
  * wave groups 0 and 1; host_out receives 2 x n_per_group values. */
 int lfm_gemm_trace_read(unsigned long long* host_out, int n_per_group);
@@ -166,6 +168,7 @@ int lfm_attention_trace_read(unsigned long long* host_out, int n);
 /* Measurement only (LFM_MEASURE builds, same trace build): per attention workgroup {HW_ID | XCC_ID << 32, start, loads landed, end} -- which CU it ran on
  * and when; host_out receives 4 x n_wg values (n_wg <= 2048). */
 int lfm_attention_wg_trace_read(unsigned long long* host_out, int n_wg);
+#endif /* LFM_MEASURE */
 int lfm_profile_fc1_read(float* host_ms_out, int max_n);
 
 /* A fp16 [M,D] = LayerNorm(X fp32 [M,D], eps 1e-6, no affine) * (1 + scale[img]) + shift[img]

@@ -15,6 +15,8 @@ STAMP = os.path.join(LIBDIR, "liblfm_hip.stamp")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only",
          "-Wno-macro-redefined"]
+if os.environ.get("LFM_NO_FAST_MATH") == "1":  # A/B of -ffast-math (round 4): parity deltas and time, tools/fastmath_ab.sh
+    FLAGS.remove("-ffast-math")
 if os.environ.get("LFM_MEASURE") == "1":  # measurement builds: the s_memtime-stamped GEMM epilogues and the attention phase / trace variants (tools/)
     FLAGS.append("-DLFM_MEASURE")
 
@@ -45,7 +47,13 @@ def build(force=False, verbose=False):
     dig = _digest()
     if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read() == dig:
         return LIB
-    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+    try:
+        lock = open(os.path.join(LIBDIR, ".build.lock"), "w")
+    except PermissionError:  # a read-only install: nothing can be (re)built here anyway
+        if os.path.exists(LIB):
+            return LIB
+        raise
+    with lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
             if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read() == dig:

@@ -144,6 +144,13 @@ class _Encoder(nn.Module):
 class AutoencoderKL(nn.Module):
     """AutoencoderKL of the sd-vae-ft-mse architecture (encoder optional: the sampling path only decodes)."""
 
+    @staticmethod
+    def _max_chunk(R):
+        """Images per launch such that every row-major GEMM operand of the full-resolution level (chunk * (8R)^2 pixels x up to 256 channels) stays below the
+        2^31-element addressing limit of the GEMM kernels' 32-bit row offsets (csrc/gemm_kernel.h: ASrcRowMajor::fits): a user-set
+        decode_chunk beyond it would otherwise be refused by the library (LFM_ERR_SHAPE) instead of being split."""
+        return max(1, ((1 << 31) - 1) // (64 * R * R * 256))
+
     def __init__(self, decode_chunk=None, with_encoder=False):
         super().__init__()
         if with_encoder:
@@ -334,7 +341,7 @@ class AutoencoderKL(nn.Module):
         w, _ = self._packed_enc or self._pack_enc()
         x = x.contiguous().float()
         N, R = x.shape[0], x.shape[2] // 8
-        chunk = min(self.decode_chunk or max(1, (64 * 32 * 32) // (R * R)), N)
+        chunk = min(self.decode_chunk or max(1, (64 * 32 * 32) // (R * R)), N, self._max_chunk(R))
         L = hip.lib()
         need = L.lfm_vae_workspace_bytes(R, chunk)
         if self._ws is None or self._ws.numel() < need or self._ws.device != x.device:
@@ -357,7 +364,7 @@ class AutoencoderKL(nn.Module):
         # images per pass: bigger is faster (57.9 ms vs 65.9 ms per 64 images for 64 vs 16 at 256x256) and bounded by the
         # 4 ping-pong activation buffers: auto = 64 images at 256x256 (8.6 GB), scaled by resolution (16 at 512x512)
         chunk = self.decode_chunk or max(1, (64 * 32 * 32) // (R * R))
-        chunk = min(chunk, N)
+        chunk = min(chunk, N, self._max_chunk(R))
         L = hip.lib()
         need = L.lfm_vae_workspace_bytes(R, chunk)
         if self._ws is None or self._ws.numel() < need or self._ws.device != z.device:

@@ -855,9 +855,11 @@ static DitWs carve(const lfm_dit_shape* s, int B, void* ws, bool sizing = false)
   w.ln_part = (float*)take(M * ((D + 255) / 256) * 8);
   w.cen[0] = (float*)take(M * 4);
   w.cen[1] = (float*)take(M * 4);
-  w.amod = (half_t*)take((size_t)s->depth * 4 * B * D * 2);
-  w.uvq = (float*)take((size_t)s->depth * 2 * B * 3 * D * 4);
-  w.uvf = (float*)take((size_t)s->depth * 2 * B * H * 4);
+  // only shapes that can ever take the folded LayerNorm path (residual width a multiple of 256, H % 64 == 0: lfm_dit_forward's `fold`) pay for its operands
+  const bool uv = (D % 256 == 0) && (H % 64 == 0);
+  w.amod = (half_t*)take(uv ? (size_t)s->depth * 4 * B * D * 2 : 0);
+  w.uvq = (float*)take(uv ? (size_t)s->depth * 2 * B * 3 * D * 4 : 0);
+  w.uvf = (float*)take(uv ? (size_t)s->depth * 2 * B * H * 4 : 0);
   // latency mode: room for up to 4 K slices of the widest GEMM output (fc1), when the token count is small
   // (when SIZING for a maximum batch, reserve the slabs of the largest small batch too, so that the requirement is monotone in the
   // batch and a workspace sized for max_batch serves every smaller batch)
@@ -1048,6 +1050,7 @@ extern "C" int lfm_gemm_qkv_f16(const void* A, long lda, const void* W, long ldw
                           EpiQKV::make((half_t*)Q, (half_t*)Kout, (half_t*)Vt, bias, D, head_dim, tokens), (hipStream_t)stream);
 }
 
+#ifdef LFM_MEASURE  // s_memtime trace readers: measurement builds only (include/lfm_hip.h)
 extern "C" int lfm_gemm_trace_read(unsigned long long* host_out, int n_per_group) {  // 2 x n stamps (group 0, group 1)
   if (!host_out || n_per_group <= 0 || n_per_group > G256Q_TRACE_MAX) return LFM_ERR_ARG;
   if (hipDeviceSynchronize() != hipSuccess) return LFM_ERR_LAUNCH;
@@ -1071,6 +1074,7 @@ extern "C" int lfm_attention_wg_trace_read(unsigned long long* host_out, int n_w
   if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(att_wg_trace), sizeof(unsigned long long) * 4 * n_wg, 0, hipMemcpyDeviceToHost) != hipSuccess) return LFM_ERR_LAUNCH;
   return LFM_OK;
 }
+#endif  // LFM_MEASURE
 
 // ------------------------------------------------------------------ conditioning (everything the forward derives from t and y alone)
 // c = t_emb(t) (+ y_emb), the adaLN modulation rows of every block and of the final layer (DiT.py:252-262, 128, 170) and -- for the folded

@@ -485,14 +485,14 @@ __global__ __launch_bounds__(512) void gemm256h_tn_kernel(ASrc asrc, const half_
   unsigned avoff[2][2], wvoff[2][2];
   if constexpr (BUFDMA) {
     rsa = asrc.rsrc();
-    rsw = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, 0x7fffffff, 0x00020000);
+    rsw = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, -1, 0x00020000);
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
         avoff[s][p] = asrc.voff(arow[s][p], cswz);
         const int n = n0 + (p * 2 + (tid >> 8)) * 64 + s * 32 + ((tid >> 3) & 31);
-        wvoff[s][p] = (unsigned)(((n < N ? n : N - 1) * (int)ldw + cswz) * 2);
+        wvoff[s][p] = ((unsigned)(n < N ? n : N - 1) * (unsigned)ldw + (unsigned)cswz) * 2u;
       }
   }
   // the two LDS-DMAs of a piece: P = 0 / 1 / 2 = both / the first / the second
@@ -750,7 +750,7 @@ static inline int launch_gemm256h_tn(const ASrc& asrc, const half_t* W, long ldw
                                      int batch = 1, long bsA = 0, long bsW = 0, long bsC = 0) {
   if (!asrc_fits(asrc, 0)) return LFM_ERR_SHAPE;
   if constexpr ((OPT & 1) != 0 && asrc_has_buffer<ASrc>::value) {  // byte offsets of the buffer-addressed LDS-DMAs (batched operands: per batch element)
-    if (!asrc_fits_buffer(asrc, 0) || (long)N * ldw >= (1L << 30)) return LFM_ERR_SHAPE;
+    if (!asrc_fits_buffer(asrc, 0) || (long)N * ldw >= (1L << 31)) return LFM_ERR_SHAPE;
   }
   if (M <= 0 || N <= 0 || K <= 0 || (K % G256Q_BK) != 0 || (N % 4) != 0) return LFM_ERR_SHAPE;
   if ((ldw % 8) != 0 || ((uintptr_t)W & 15)) return LFM_ERR_ALIGN;

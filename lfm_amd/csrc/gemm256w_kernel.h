@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void gemm256w_tn_kernel(ASrc asrc, const half_
   unsigned avoff[8];
   if constexpr (BUFDMA) {
     rsa = asrc.rsrc();
-    rsw = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, 0x7fffffff, 0x00020000);
+    rsw = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, -1, 0x00020000);
 #pragma unroll
     for (int p = 0; p < 8; ++p) avoff[p] = asrc.voff(arow[p], cswz);
   }
@@ -335,7 +335,7 @@ static inline int launch_gemm256w_tn(const ASrc& asrc, const half_t* W, long ldw
                                      int batch = 1, long bsA = 0, long bsW = 0, long bsC = 0) {
   if (!asrc_fits(asrc, 0)) return LFM_ERR_SHAPE;
   if (M <= 0 || N <= 0 || K <= 0 || (K % G256Q_BK) != 0 || (N % 4) != 0) return LFM_ERR_SHAPE;
-  if ((long)N * ldw >= (1L << 30)) return LFM_ERR_SHAPE;  // W rows are 32-bit element offsets (byte offsets with OPT bit 0)
+  if ((long)N * ldw >= (1L << 31)) return LFM_ERR_SHAPE;  // W rows are 32-bit element offsets (byte offsets with OPT bit 0)
   if constexpr ((OPT & 1) != 0 && asrc_has_buffer<ASrc>::value) {
     if (!asrc_fits_buffer(asrc, 0)) return LFM_ERR_SHAPE;
   }

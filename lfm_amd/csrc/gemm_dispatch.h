@@ -41,8 +41,8 @@ static inline int launch_gemm_auto(const ASrc& asrc, const half_t* W, long ldw, 
     if (sel == 4 || (sel == 0 && (narrow || (big && lfm_gemm_prefers_v4(M, N, K)))))
       return launch_gemm256n_tn(asrc, W, ldw, M, N, K, epi, stream, batch, bsA, bsW, bsC);
   }
-  // the 256x256 kernels address row-major operands through buffer resources (byte offsets < 2^31): larger operands take the 128x128 kernel
-  bool fits256 = (long)N * ldw < (1L << 30);
+  // the 256x256 kernels address row-major operands through buffer resources (unsigned 32-bit byte offsets: operands below 2^31 elements, like the 32-bit row offsets of every kernel)
+  bool fits256 = (long)N * ldw < (1L << 31);
   if constexpr (asrc_has_buffer<ASrc>::value) fits256 = fits256 && asrc_fits_buffer(asrc, 0);
   if constexpr (gemm_v6_ok<ASrc, Epi>::value) {
     if ((sel == 6 || (sel == 0 && big && lfm_gemm_v6_default())) && (K % G256Q_BK) == 0 && fits256)

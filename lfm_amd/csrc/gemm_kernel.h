@@ -50,12 +50,13 @@ struct ASrcRowMajor {
   bool fits() const { return (long)M * lda < (1L << 31); }
   // buffer-addressed LDS-DMA (round 4; tools/ubench/ldsdma_rate.hip: buffer_load_dwordx4 .. offen lds with an SGPR resource, a 32-bit VGPR byte
   // offset and the K offset in an SGPR sustains 47.9 B/clk/CU from eight waves where global_load_lds with 64-bit VGPR addresses sustains 42.2, and
-  // needs no 64-bit VALU add per issue): resource over A, per-row byte offset, per-K-tile scalar offset.  Byte offsets < 2^31.
+  // needs no 64-bit VALU add per issue): resource over A (num_records = 2^32 - 1: the range check never fires), per-row byte offset, per-K-tile
+  // scalar offset.  Byte offsets are UNSIGNED 32-bit: operands up to 2^31 elements (tests/test_gpu_dit.py::test_gemm_operands_beyond_2gb).
   static constexpr bool buffer_form = true;
-  __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc() const { return __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7fffffff, 0x00020000); }
+  __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc() const { return __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, -1, 0x00020000); }
   __device__ __forceinline__ unsigned voff(const Row& r, int koff) const { return (r.off + (unsigned)koff) * 2u; }
   __device__ __forceinline__ unsigned soff() const { return (unsigned)k0 * 2u; }
-  bool fits_buffer() const { return (long)M * lda < (1L << 30); }
+  bool fits_buffer() const { return (long)M * lda < (1L << 31); }
 };
 template <class ASrc, class = void>
 struct asrc_has_buffer {

@@ -71,8 +71,11 @@ def lib():
     L.lfm_gemm_qkv_f16.restype = C.c_int
     L.lfm_gemm_qkv_f16.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p, C.c_int, C.c_int, C.c_void_p]
-    L.lfm_gemm_trace_read.restype = C.c_int
-    L.lfm_gemm_trace_read.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+    if hasattr(L, "lfm_gemm_trace_read"):  # LFM_MEASURE builds only
+        L.lfm_gemm_trace_read.restype = C.c_int
+        L.lfm_gemm_trace_read.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+        L.lfm_attention_trace_read.restype = C.c_int
+        L.lfm_attention_trace_read.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
     L.lfm_profile_fc1.restype = C.c_int
     L.lfm_profile_fc1.argtypes = [C.c_int]
     L.lfm_profile_fc1_read.restype = C.c_int
@@ -81,8 +84,6 @@ def lib():
     L.lfm_ln_modulate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
     L.lfm_dit_attention.restype = C.c_int
     L.lfm_dit_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
-    L.lfm_attention_trace_read.restype = C.c_int
-    L.lfm_attention_trace_read.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
     L.lfm_set_option.restype = C.c_int
     L.lfm_set_option.argtypes = [C.c_int, C.c_int]
     L.lfm_dit_attention_hd.restype = C.c_int

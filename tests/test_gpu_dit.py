@@ -492,3 +492,31 @@ def test_trained_like_dynamic_range(dev, fold):
           f"rel-L2 vs oracle {err:.2e}")
     assert bool(torch.isfinite(hb).all()) and float(hb.abs().max()) >= 64.0  # round 4: two orders wider than on N(0, 0.02) weights, still far from 65504
     assert float(ws[:M * D * 4].view(torch.float32).abs().max()) >= 2900.0  # the residual stream really carries the massive channels to the last block
+
+
+def test_gemm_operands_beyond_2gb(dev):
+    """The 256x256 kernels address row-major operands through buffer resources with UNSIGNED 32-bit byte offsets: an A operand of 2^30 .. 2^31 elements
+    (2.1 .. 4.3 GB; e.g. the VAE's full-resolution 1x1 shortcut at decode_chunk 64: 64 x 256 x 256 pixels x 256 channels = 2^30) must give the result
+    of the 128x128 kernel (plain pointer arithmetic) in its LAST rows too, where the byte offsets exceed 2^31."""
+    from lfm_amd import hip
+
+    M, N, K = (1 << 22) + 4096, 256, 256  # M * K = 2^30 + 2^20 elements
+    g = torch.Generator(device=dev).manual_seed(5)
+    A = (torch.randn(M, K, device=dev, generator=g) * 0.5).half()
+    W = (torch.randn(N, K, device=dev, generator=g) / K ** 0.5).half()
+    b = torch.randn(N, device=dev, generator=g) * 0.1
+    outs = {}
+    for k in (1, 5, 6):
+        hip.gemm_select(k)
+        try:
+            outs[k] = hip.gemm_f16(A, W, b, epilogue=0)
+        finally:
+            hip.gemm_select(0)
+    torch.cuda.synchronize()
+    tail = slice(M - 2048, M)
+    ref = A[tail].float() @ W.float().t() + b
+    for k in (1, 5, 6):
+        assert rel_l2(outs[k][tail], ref) < 2e-3, k
+    for k in (5, 6):  # whole outputs, compared on the device (1 G elements)
+        d = float((outs[k].float() - outs[1].float()).norm() / outs[1].float().norm())
+        assert d < 1e-3, (k, d)

@@ -217,10 +217,15 @@ def test_c_abi_exports_every_declared_symbol():
     lib = ctypes.CDLL(lib_path)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     hdr = open(os.path.join(root, "include", "lfm_hip.h")).read()
-    names = sorted(set(re.findall(r"\b(lfm_[a-z0-9_]+)\s*\(", hdr)))
-    assert len(names) >= 12
+    measure = re.findall(r"#ifdef LFM_MEASURE(.*?)#endif", hdr, flags=re.S)
+    measure_names = set(re.findall(r"\b(lfm_[a-z0-9_]+)\s*\(", "".join(measure)))
+    names = sorted(set(re.findall(r"\b(lfm_[a-z0-9_]+)\s*\(", hdr)) - measure_names)
+    assert len(names) >= 12 and len(measure_names) == 3
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/lfm_hip.h but not exported"
+    if os.environ.get("LFM_MEASURE") != "1":  # the shipped library carries no measurement-only entry point
+        for n in measure_names:
+            assert not hasattr(lib, n), f"{n} is measurement-only but exported by the shipped build"
     lib.lfm_strerror.restype = ctypes.c_char_p
     assert lib.lfm_strerror(0) == b"ok" and lib.lfm_abi_version() >= 1
 
