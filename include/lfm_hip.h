@@ -125,7 +125,9 @@ int lfm_gemm_f16(const void* A, long lda, const void* W, long ldw, void* C, long
 
 /* The attention input projection with its fused split (timm Attention.qkv + reshape/permute, models/DiT.py:120):
  * [Q | K | V] = A[M,K] * W[3D,K]^T + bias;  Q, K fp16 [M, D] row-major;  V is written TRANSPOSED per head as
- * Vt[M / tokens][D / head_dim][head_dim][tokens] (what lfm_dit_attention reads).  head_dim % 8 == 0, tokens % 4 == 0. */
+ * Vt[M / tokens][D / head_dim][head_dim][tokens] (what lfm_dit_attention reads), with the tokens of every group of 16 stored in the order
+ * 0 1 2 3 8 9 10 11 4 5 6 7 12 13 14 15 (position p of a row holds token p with bits 2 and 3 exchanged: the operand order of the attention kernel's
+ * P V MFMA, csrc/gemm_kernel.h: vt_pos; ABI 3).  head_dim % 8 == 0, tokens % 16 == 0. */
 int lfm_gemm_qkv_f16(const void* A, long lda, const void* W, long ldw, void* Q, void* K_out, void* Vt, int M, int D, int K,
                      const float* bias, int head_dim, int tokens, lfm_stream_t stream);
 
@@ -177,7 +179,7 @@ int lfm_ln_modulate(const float* X, void* A, int M, int D, int tokens, const flo
                     lfm_stream_t stream);
 
 /* softmax(q k^T / sqrt(hd)) v for hd = 64, T in {64,128,256} (timm Attention as called at models/DiT.py:120).
- * Q,K: fp16 [batch*T, D] token-major; Vt: fp16 [batch, heads, hd, T]; O: fp16 [batch*T, D]. */
+ * Q,K: fp16 [batch*T, D] token-major; Vt: fp16 [batch, heads, hd, T] in the token order lfm_gemm_qkv_f16 writes (16-groups permuted); O: fp16 [batch*T, D]. */
 int lfm_dit_attention(const void* Q, const void* K, const void* Vt, void* O, int batch, int heads, int T, lfm_stream_t stream);
 /* The same with the head size as an argument: head_dim 64 (DiT-S / B / L) or 72 (DiT-XL/{2,4,8}: 1152 / 16, models/DiT.py:354-363);
  * D = heads * head_dim. */

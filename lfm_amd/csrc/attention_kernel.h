@@ -12,10 +12,11 @@
 // MFMA k-slot is the same permutation on both operands, so no shuffle is needed).
 // hd 72 = 4.5 k-slots of 16: the fifth slot's upper half (dims 72..79) is fed zeros on BOTH operands (LDS past a row end is
 // another row or stale bytes, possibly NaN patterns); O^T has 2.25 blocks of 32 rows: the third block computes 8 live rows.
+// V^T rows hold the tokens of every 16-group in the order 0-3, 8-11, 4-7, 12-15 (gemm_kernel.h: vt_pos), which makes a lane's P V operand one 16-byte read.
 // Keys are consumed in 32-key blocks with an online softmax (running max m, running sum l), which keeps
 // the live state at S 32 + P 16 + O 64 + Q 32 registers for hd 64, JQ 2 (2 waves / SIMD).
 #pragma once
-#include "common.h"
+#include "gemm_kernel.h"
 
 int lfm_gemm_debug_flags();
 
@@ -235,11 +236,9 @@ __global__ __launch_bounds__((T / (32 * JQ)) * 64, HD == 64 ? (T / (32 * JQ)) / 
         // rows past HD (third block of hd 72) re-read row HD-1: finite values into accumulator rows nobody stores
         const int d = (db * 32 + 32 <= HD) ? db * 32 + l31 : (db * 32 + l31 < HD ? db * 32 + l31 : HD - 1);
         const int vkey = d & VKEY;
-        const int c0 = kb * 4 + 2 * s;
-        const char* rowp = Vs + d * (2 * T) + hsel * 8;
-        const half4_t lo = *(const half4_t*)(rowp + ((c0 ^ vkey) << 4));
-        const half4_t hi = *(const half4_t*)(rowp + (((c0 + 1) ^ vkey) << 4));
-        const half8_t vf = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        // keys {4 h + r} and {8 + 4 h + r} of the 16-key k-slot are ONE 16-byte chunk of the permuted V^T row (gemm_kernel.h: vt_pos): chunk 2 (2 kb + s) + h
+        const int c0 = kb * 4 + 2 * s + hsel;
+        const half8_t vf = *(const half8_t*)(Vs + d * (2 * T) + ((c0 ^ vkey) << 4));
 #pragma unroll
         for (int jq = 0; jq < JQ; ++jq) Oa[jq][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, P[jq][s], Oa[jq][db], 0, 0, 0);
       }
@@ -334,7 +333,7 @@ __global__ __launch_bounds__(64) void dit_attention_t16_kernel(const half_t* __r
       const half8_t v1 = *(const half8_t*)(vp + (c * 8 + e) * T + 8);
       float acc = 0.f;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) acc += (float)ph[k] * (float)v0[k] + (float)ph[k + 8] * (float)v1[k];
+      for (int k = 0; k < 8; ++k) acc += (float)ph[vt_pos(k)] * (float)v0[k] + (float)ph[vt_pos(k + 8)] * (float)v1[k];  // memory position -> token (vt_pos)
       o8[e] = (half_t)(acc * inv);
     }
     *(half8_t*)(op + c * 8) = o8;

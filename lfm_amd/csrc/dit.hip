@@ -815,6 +815,8 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 struct DitWs {
   float* X;       // [M, D] fp32 residual stream
   half_t* A;      // [M, D] LN output / attention output
+  half_t* A2;     // [M, D] folded path: the proj GEMM's A' output (fc1's operand).  NOT ws.A: proj's operand IS ws.A (the attention output), and a tile of
+                  // a row panel may still be streaming columns that a sibling tile's epilogue would overwrite (round 4: found by the full-size parity test)
   half_t* QKVH;   // max(3*M*D, M*H): Q | K | Vt, later the fc1 activation
   float* temb;    // [B, D]
   float* temb_h;  // [B, D] hidden layer of the t-MLP
@@ -860,6 +862,7 @@ static DitWs carve(const lfm_dit_shape* s, int B, void* ws, bool sizing = false)
   w.amod = (half_t*)take(uv ? (size_t)s->depth * 4 * B * D * 2 : 0);
   w.uvq = (float*)take(uv ? (size_t)s->depth * 2 * B * 3 * D * 4 : 0);
   w.uvf = (float*)take(uv ? (size_t)s->depth * 2 * B * H * 4 : 0);
+  w.A2 = (half_t*)take(uv ? M * D * 2 : 0);
   // latency mode: room for up to 4 K slices of the widest GEMM output (fc1), when the token count is small
   // (when SIZING for a maximum batch, reserve the slabs of the largest small batch too, so that the requirement is monotone in the
   // batch and a workspace sized for max_batch serves every smaller batch)
@@ -1039,7 +1042,7 @@ extern "C" int lfm_gemm_qkv_f16(const void* A, long lda, const void* W, long ldw
                                 const float* bias, int head_dim, int tokens, lfm_stream_t stream) {
   if (!A || !W || !Q || !Kout || !Vt || !bias) return LFM_ERR_ARG;
   if ((lda % 8) || ((uintptr_t)A & 15)) return LFM_ERR_ALIGN;
-  if (head_dim <= 0 || tokens <= 0 || (D % head_dim) || (head_dim % 8) || (tokens % 4) || (M % tokens)) return LFM_ERR_SHAPE;
+  if (head_dim <= 0 || tokens <= 0 || (D % head_dim) || (head_dim % 8) || (tokens % 16) || (M % tokens)) return LFM_ERR_SHAPE;  // 16: the V^T token groups (vt_pos)
 #ifdef LFM_MEASURE
   if (g_gemm_sel == 5 && (g_gemm_dbg & 2) && K % G256Q_BK == 0)
     return launch_gemm256h_tn<ASrcRowMajor, EpiQKV, true>(ASrcRowMajor{(const half_t*)A, lda, M, 0}, (const half_t*)W, ldw, M, 3 * D, K,
@@ -1261,14 +1264,14 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
       rc = attention_launch(Qb, Kb, Vb, ws.A, B, s->heads, D / s->heads, T, st);
       if (rc) return rc;
       // proj: X += gate_msa * (.), A' for fc1 with scale_mlp, partials; c = the row means the qkv GEMM just published
-      const EpiGateResidMod e_proj{ws.X, D, w->proj_b + (size_t)i * D, mod + 2 * D, mstride, T, ws.A, mod + 4 * D, mstride, ws.cen[cen_cur], ws.ln_part, tiles_p};
+      const EpiGateResidMod e_proj{ws.X, D, w->proj_b + (size_t)i * D, mod + 2 * D, mstride, T, ws.A2, mod + 4 * D, mstride, ws.cen[cen_cur], ws.ln_part, tiles_p};
       rc = g_opt_xpf ? launch_fold(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D, as_xpf(e_proj))
                      : launch_fold(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D, e_proj);
       if (rc) return rc;
       const bool prof = g_prof_on && g_prof_count < LFM_PROF_MAX;
       if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_count], st);
       const EpiModGeluF16 e_fc1{ws.QKVH, H, uf, uf + (long)rows * H, uvs_f, T, rowstat_src(), nullptr, 0};
-      rc = launch_fold(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->fc1_w + (size_t)i * H * D, D, M, H, D, e_fc1);
+      rc = launch_fold(ASrcRowMajor{ws.A2, D, M, 0}, (const half_t*)w->fc1_w + (size_t)i * H * D, D, M, H, D, e_fc1);
       if (rc) return rc;
       if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_count++ + 1], st);
       if (i + 1 < s->depth) {  // fc2 writes the NEXT block's A' (its scale_msa)

@@ -162,7 +162,8 @@ __device__ __forceinline__ void g256_epilogue(f32x16 (&acc)[4][2], char* smem, E
     // back row-major, 16 lanes cover 64 consecutive m of one n -> epi.store_t(n, m, C[m..m+3][n]).
     if (swapped && !(dbg & 1024) && epi.wide_t_ok()) {  // 16-byte stores: lane = (column n = lane>>3 of 8 per pass, 8 consecutive rows m)
       char* scr = smem + wave * (32 * 272);
-      const int rrow = lane >> 3, rcol = lane & 7;
+      const int rrow = lane >> 3;
+      const int ml = 16 * ((lane & 7) >> 1) + 4 * (lane & 1);  // tokens ml .. ml + 3 and ml + 8 .. ml + 11: one 16-byte chunk of the permuted V^T row (vt_pos)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int nb = n0 + wn * 64 + j * 32 + rrow;
@@ -182,15 +183,18 @@ __device__ __forceinline__ void g256_epilogue(f32x16 (&acc)[4][2], char* smem, E
           f32x4 lo[4], hi[4];
 #pragma unroll
           for (int ps = 0; ps < 4; ++ps) {
-            lo[ps] = *(const f32x4*)(scr + (ps * 8 + rrow) * 272 + rcol * 32);
-            hi[ps] = *(const f32x4*)(scr + (ps * 8 + rrow) * 272 + rcol * 32 + 16);
+            lo[ps] = *(const f32x4*)(scr + (ps * 8 + rrow) * 272 + ml * 4);
+            hi[ps] = *(const f32x4*)(scr + (ps * 8 + rrow) * 272 + ml * 4 + 32);
           }
-          const int m = m0 + g * 128 + ih * 64 + rcol * 8;
+          const int m = m0 + g * 128 + ih * 64 + ml;
 #pragma unroll
           for (int ps = 0; ps < 4; ++ps) {
             if (nb + ps * 8 >= N) continue;
-            if (m + 7 < M) epi.store_t8(nb + ps * 8, m, lo[ps], hi[ps], bt[ps]);
-            else if (m + 3 < M) epi.store_t(nb + ps * 8, m, lo[ps], bt[ps]);
+            if (m + 11 < M) epi.store_t8(nb + ps * 8, m, lo[ps], hi[ps], bt[ps]);
+            else {
+              if (m + 3 < M) epi.store_t(nb + ps * 8, m, lo[ps], bt[ps]);
+              if (m + 11 < M) epi.store_t(nb + ps * 8, m + 8, hi[ps], bt[ps]);
+            }
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }

@@ -331,14 +331,16 @@ __device__ __forceinline__ void g256h_epilogue_body(f32x4_t (&acc)[8][4], char* 
               *(f32x4_t*)(scr + (j2 * 16 + l15) * 272 + (i4 * 16 + l4 * 4) * 4) = acc[4 * ih + i4][2 * J + j2];
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           g256h_stamp<TRACE>(tr, g, wn, lane, 1 + 4 * (2 * J + ih));
+          // wide stores: a lane owns tokens ml .. ml + 3 and ml + 8 .. ml + 11 of a 16-token group (one 16-byte chunk of the permuted V^T row: vt_pos)
+          const int ml = 16 * ((lane & 7) >> 1) + 4 * (lane & 1);
           if (wide && m0 + G256_BM <= M && n0 + BN <= N) {  // interior tile: no per-store bounds checks
-            const int rrow = lane >> 3, rcol = lane & 7;
-            const int nb = n0 + wn * 64 + J * 32 + rrow, m = m0 + g * 128 + ih * 64 + rcol * 8;
+            const int rrow = lane >> 3;
+            const int nb = n0 + wn * 64 + J * 32 + rrow, m = m0 + g * 128 + ih * 64 + ml;
             f32x4 lo[4], hi[4];
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) {
-              lo[ps] = *(const f32x4*)(scr + (ps * 8 + rrow) * 272 + rcol * 32);
-              hi[ps] = *(const f32x4*)(scr + (ps * 8 + rrow) * 272 + rcol * 32 + 16);
+              lo[ps] = *(const f32x4*)(scr + (ps * 8 + rrow) * 272 + ml * 4);
+              hi[ps] = *(const f32x4*)(scr + (ps * 8 + rrow) * 272 + ml * 4 + 32);
             }
             if constexpr (TRACE) {
               asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -349,17 +351,20 @@ __device__ __forceinline__ void g256h_epilogue_body(f32x4_t (&acc)[8][4], char* 
               for (int ps = 0; ps < 4; ++ps) epi.store_t8(nb + ps * 8, m, lo[ps], hi[ps], bt[J][ps]);
             }
           } else if (wide) {
-            const int rrow = lane >> 3, rcol = lane & 7;
-            const int nb = n0 + wn * 64 + J * 32 + rrow, m = m0 + g * 128 + ih * 64 + rcol * 8;
+            const int rrow = lane >> 3;
+            const int nb = n0 + wn * 64 + J * 32 + rrow, m = m0 + g * 128 + ih * 64 + ml;
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) {
-              const f32x4 lo = *(const f32x4*)(scr + (ps * 8 + rrow) * 272 + rcol * 32);
-              const f32x4 hi = *(const f32x4*)(scr + (ps * 8 + rrow) * 272 + rcol * 32 + 16);
+              const f32x4 lo = *(const f32x4*)(scr + (ps * 8 + rrow) * 272 + ml * 4);
+              const f32x4 hi = *(const f32x4*)(scr + (ps * 8 + rrow) * 272 + ml * 4 + 32);
               const int n = nb + ps * 8;
               if (n >= N) continue;
               const AuxT b = bt[J][ps];
-              if (m + 7 < M) epi.store_t8(n, m, lo, hi, b);
-              else if (m + 3 < M) epi.store_t(n, m, lo, b);
+              if (m + 11 < M) epi.store_t8(n, m, lo, hi, b);
+              else {
+                if (m + 3 < M) epi.store_t(n, m, lo, b);
+                if (m + 11 < M) epi.store_t(n, m + 8, hi, b);
+              }
             }
           } else {
             const int rrow = lane >> 4, rcol = lane & 15;

@@ -380,6 +380,14 @@ struct EpiSlabF32 {
   __device__ __forceinline__ void store(int m, int n, f32x4 v, const Aux&) const { *(f32x4*)(slab + (long)m * ldn + n) = v; }
 };
 
+// V^T token order (round 4).  Inside every group of 16 tokens a V^T row stores the tokens in the order 0 1 2 3 8 9 10 11 | 4 5 6 7 12 13 14 15 (bits 2 and
+// 3 of the token index exchanged: an involution).  Why: the attention kernel's P V MFMA takes, per k-slot of 16 keys, keys {4 h + r} and {8 + 4 h + r}
+// (h = lane >> 5) from one lane -- the order its S^T = K Q^T accumulators already hold P in -- so with plain token order a lane needed TWO 8-byte LDS reads
+// per fragment, and the 32 lanes of a half-wave could only reach 16 of the 32 eight-byte slots of a bank row (2-way conflicts by construction: 40 % of the
+// kernel's LDS cycles, profiles/r03_final_pmc_in_situ.txt).  In this order the lane's eight keys are ONE 16-byte chunk: one conflict-free ds_read_b128.
+// V^T is private to the QKV projection (writer) and the attention kernels (readers).
+__host__ __device__ __forceinline__ int vt_pos(int tok) { return (tok & ~12) | ((tok & 4) << 1) | ((tok & 8) >> 1); }
+
 // QKV projection of timm Attention (DiT.py:120): columns [q | k | v], each [head][hd].
 // Q,K are stored token-major [M, D]; V is stored TRANSPOSED per (image, head): Vt[img][head][d][token],
 // which is the key-contiguous layout the attention kernel's P*V MFMA operand wants.
@@ -403,7 +411,7 @@ struct EpiQKV {
     // ((img * heads + head) * hd + d) * tokens + tok  with  head * hd + d = c  and  heads * hd = D:  no head / d split is needed
     const int c = n - 2 * D;
     const int img = tok_sh >= 0 ? (m >> tok_sh) : m / tokens, tok = m - img * tokens;
-    return Vt + ((long)img * D + c) * tokens + tok;
+    return Vt + ((long)img * D + c) * tokens + vt_pos(tok);
   }
   __device__ __forceinline__ bool direct(int n0) const { return n0 >= 2 * D; }  // V tiles: 32 consecutive tokens per lane group
   __device__ __forceinline__ Aux load(int, int n) const { return *(const f32x4*)(bias + n); }
@@ -433,8 +441,9 @@ struct EpiQKV {
     half4_t h = {(half_t)(v.x + b), (half_t)(v.y + b), (half_t)(v.z + b), (half_t)(v.w + b)};
     *(half4_t*)vt_ptr(n, m) = h;
   }
-  __device__ __forceinline__ bool wide_t_ok() const { return (tokens & 7) == 0 && ((uintptr_t)Vt & 15) == 0; }
-  __device__ __forceinline__ void store_t8(int n, int m, f32x4 lo, f32x4 hi, float b) const {  // eight consecutive tokens
+  __device__ __forceinline__ bool wide_t_ok() const { return (tokens & 15) == 0 && ((uintptr_t)Vt & 15) == 0; }
+  // one 16-byte chunk of a V^T row: lo = tokens m .. m + 3, hi = tokens m + 8 .. m + 11 (m % 16 == 0 or 4: see vt_pos)
+  __device__ __forceinline__ void store_t8(int n, int m, f32x4 lo, f32x4 hi, float b) const {
     half8_t h = {(half_t)(lo.x + b), (half_t)(lo.y + b), (half_t)(lo.z + b), (half_t)(lo.w + b),
                  (half_t)(hi.x + b), (half_t)(hi.y + b), (half_t)(hi.z + b), (half_t)(hi.w + b)};
     *(half8_t*)vt_ptr(n, m) = h;
@@ -459,7 +468,7 @@ struct EpiQKVMod {
   __device__ __forceinline__ half_t* vt_ptr(int n, int m) const {
     const int c = n - 2 * D;
     const int img = tok_sh >= 0 ? (m >> tok_sh) : m / tokens, tok = m - img * tokens;
-    return Vt + ((long)img * D + c) * tokens + tok;
+    return Vt + ((long)img * D + c) * tokens + vt_pos(tok);
   }
   __device__ __forceinline__ Aux load(int m, int n) const {
     const long o = (long)(m / tokens) * uv_stride + n;
@@ -497,10 +506,10 @@ struct EpiQKVMod {
                  (half_t)(r1.x * acc.z + (r1.y * c.x + c.y)), (half_t)(r1.z * acc.w + (r1.w * c.x + c.y))};
     *(half4_t*)vt_ptr(n, m) = h;
   }
-  __device__ __forceinline__ bool wide_t_ok() const { return (tokens & 7) == 0 && ((uintptr_t)Vt & 15) == 0; }
-  __device__ __forceinline__ void store_t8(int n, int m, f32x4 lo, f32x4 hi, f32x2 c) const {  // eight consecutive tokens
+  __device__ __forceinline__ bool wide_t_ok() const { return (tokens & 15) == 0 && ((uintptr_t)Vt & 15) == 0; }
+  __device__ __forceinline__ void store_t8(int n, int m, f32x4 lo, f32x4 hi, f32x2 c) const {  // lo = tokens m .. m + 3, hi = tokens m + 8 .. m + 11
     const float* r = rs + 2 * (m - m0);
-    const f32x4 r0 = *(const f32x4*)r, r1 = *(const f32x4*)(r + 4), r2 = *(const f32x4*)(r + 8), r3 = *(const f32x4*)(r + 12);
+    const f32x4 r0 = *(const f32x4*)r, r1 = *(const f32x4*)(r + 4), r2 = *(const f32x4*)(r + 16), r3 = *(const f32x4*)(r + 20);
     half8_t h = {(half_t)(r0.x * lo.x + (r0.y * c.x + c.y)), (half_t)(r0.z * lo.y + (r0.w * c.x + c.y)),
                  (half_t)(r1.x * lo.z + (r1.y * c.x + c.y)), (half_t)(r1.z * lo.w + (r1.w * c.x + c.y)),
                  (half_t)(r2.x * hi.x + (r2.y * c.x + c.y)), (half_t)(r2.z * hi.y + (r2.w * c.x + c.y)),

@@ -240,15 +240,25 @@ def effective_clock_mhz(device=None, iters=20000):
         e1.record(torch.cuda.current_stream(dev))
         torch.cuda.synchronize(dev)
     ms = e0.elapsed_time(e1)
-    return float(ticks.max()) / (ms * 1e3)
+    # Calibration (tools/clock_probe.py on an MI355X, round 4): the tick count is proportional to the MFMA count, not to wall time (20 802 844 ticks for
+    # 2 560 000 MFMAs per SIMD in a 21.6 ms and in a 23.7 ms run) -- 8.13 ticks per 16-pass MFMA, i.e. one s_memtime tick = TWO shader cycles here; the
+    # issue-bound estimate 16 cycles x MFMAs / wall time agrees within 2 %.
+    return 2.0 * float(ticks.max()) / (ms * 1e3)
 
 
 def set_option(key, value):
     check(lib().lfm_set_option(int(key), int(value)), "lfm_set_option")
 
 
+def vt_token_perm(T, device=None):
+    """Index tensor p with Vt_library[..., i] = Vt_plain[..., p[i]]: the V^T token order of the library (tokens of every 16-group stored as 0-3, 8-11, 4-7,
+    12-15; include/lfm_hip.h: lfm_gemm_qkv_f16).  An involution: the same index restores the plain order."""
+    i = torch.arange(T, device=device)
+    return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1)
+
+
 def dit_attention(Q, K, Vt, batch, heads, T, head_dim=64):
-    """Q, K, O: fp16 [batch*T, heads*head_dim]; Vt: fp16 [batch, heads, head_dim, T].  head_dim 64 or 72 (DiT-XL)."""
+    """Q, K, O: fp16 [batch*T, heads*head_dim]; Vt: fp16 [batch, heads, head_dim, T] in the library's token order (vt_token_perm).  head_dim 64 or 72."""
     require_gpu(Q, "dit_attention")
     O = torch.empty_like(Q)
     check(lib().lfm_dit_attention_hd(ptr(Q), ptr(K), ptr(Vt), ptr(O), batch, heads, head_dim, T, stream_ptr()), "lfm_dit_attention_hd")

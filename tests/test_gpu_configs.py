@@ -83,7 +83,7 @@ def test_bench_gemm_shapes(dev, name, N, K, epi):
         Q, Kk, Vt = outs[0]
         assert rel_l2(Q, ref[:, :D]) < 2e-3 and rel_l2(Kk, ref[:, D:2 * D]) < 2e-3
         v_ref = ref[:, 2 * D:].reshape(M // tokens, tokens, D // 64, 64).permute(0, 2, 3, 1)
-        assert rel_l2(Vt, v_ref) < 2e-3
+        assert rel_l2(Vt[..., hip.vt_token_perm(tokens, dev)], v_ref) < 2e-3  # the library's V^T token order (16-groups permuted)
         assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
         return
     X = gate = None

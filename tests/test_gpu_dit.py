@@ -150,7 +150,7 @@ def test_gemm_qkv_split(dev, batch, tokens, D, hd, kernel):
         hip.gemm_select(0)
     assert rel_l2(Q, ref[:, :D]) < 2e-3 and rel_l2(K, ref[:, D:2 * D]) < 2e-3
     v_ref = ref[:, 2 * D:].reshape(batch, tokens, D // hd, hd).permute(0, 2, 3, 1)  # [b, head, d, tok]
-    assert rel_l2(Vt, v_ref) < 2e-3
+    assert rel_l2(Vt[..., hip.vt_token_perm(tokens, dev)], v_ref) < 2e-3  # V^T rows are stored with every 16-token group permuted (hip.vt_token_perm)
 
 
 def test_gemm_detects_transpose(dev):
@@ -207,7 +207,7 @@ def test_attention(dev, T, heads, batch, hd):
     ref = ref.transpose(1, 2).reshape(batch * T, D)
     Q = q.transpose(1, 2).reshape(batch * T, D).contiguous().to(dev)
     K = k.transpose(1, 2).reshape(batch * T, D).contiguous().to(dev)
-    Vt = v.transpose(-1, -2).contiguous().to(dev)  # [b, h, hd, T]
+    Vt = v.transpose(-1, -2)[..., hip.vt_token_perm(T)].contiguous().to(dev)  # [b, h, hd, T] in the library's token order
     got = hip.dit_attention(Q, K, Vt, batch, heads, T, head_dim=hd)
     got2 = hip.dit_attention(Q, K, Vt, batch, heads, T, head_dim=hd)
     torch.cuda.synchronize()
@@ -448,7 +448,7 @@ def test_folded_ln_epilogues_match_separate_launches_and_the_oracle(dev, name, b
 def test_trained_like_dynamic_range(dev, fold):
     """Every other parity test runs on xavier / N(0, 0.02) weights.  A trained DiT has a few 'massive' residual channels, large adaLN scales and a wide
     fc1: this case puts four residual channels at +-3000 (through the patch-embedding bias, so they ride the residual stream through every block),
-    multiplies the adaLN scale rows by 8 and the fc1 weights by 32 (fp16 fc1 activations beyond 64), and checks the forward against the fp32 oracle inside the usual per-forward budget
+    multiplies the adaLN scale rows by 8 and the fc1 weights by 48 (fp16 fc1 activations beyond 64), and checks the forward against the fp32 oracle inside the usual per-forward budget
     -- with the LayerNorm folded into the GEMM epilogues (centred fp16 operand, one-pass shifted variance: the case this test was written for) and
     with the separate launches.  Finite output implies finite Q / K / V^T / H everywhere upstream (nothing masks an inf or NaN on this path); the last
     block's fp16 fc1 activation, still in the workspace, is checked directly."""
@@ -466,7 +466,7 @@ def test_trained_like_dynamic_range(dev, fold):
         for lo in (D, 4 * D):  # scale_msa, scale_mlp rows of the adaLN table
             sd[b + "adaLN_modulation.1.weight"][lo:lo + D] *= 8.0
             sd[b + "adaLN_modulation.1.bias"][lo:lo + D] *= 8.0
-        sd[b + "mlp.fc1.weight"] *= 32.0
+        sd[b + "mlp.fc1.weight"] *= 48.0
     m = DiT_models[name](img_resolution=32, in_channels=4, **kw)
     m.load_state_dict(sd, strict=True)
     m = m.to(dev).eval()
