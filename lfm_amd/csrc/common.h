@@ -68,7 +68,7 @@ __device__ __forceinline__ float xhalf(float v) {
   return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }  // explicit v_rcp_f32 (no -ffast-math: a plain division is ~10 instructions)
 
 // GELU(tanh) as torch: 0.5*x*(1+tanh(u)), u = sqrt(2/pi)*(x+0.044715 x^3)  ==  x * sigmoid(2u)  ==  x / (1 + 2^(-z)),
 // z = 2u*log2(e) = x*(c0 + c1*x^2).  Two transcendentals (v_exp_f32, v_rcp_f32) and four plain VALU per element; saturates
