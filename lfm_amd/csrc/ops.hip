@@ -515,12 +515,15 @@ __global__ void gn_coef_kernel(const float* __restrict__ part, int slabs, int ro
 template <bool SILU>
 __global__ __launch_bounds__(256) void gn_affine_kernel(GnIn in, half_t* __restrict__ y, const float* __restrict__ ab,
                                                         int HW, int C, long total8) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total8) return;
-  const int c8n = C / 8;
-  const int c0 = (int)(i % c8n) * 8;
-  const int n = (int)(i / ((long)c8n * HW));
-  const half8_t v = *(const half8_t*)in.at(i / c8n, c0);
+  // grid (chunks of one image / 256, images): 32-bit index arithmetic only (HW * C / 8 < 2^31 per image)
+  const int c8n = C / 8, n = blockIdx.y;
+  const unsigned j = blockIdx.x * 256u + threadIdx.x;
+  if (j >= (unsigned)HW * (unsigned)c8n) return;
+  const unsigned pix = j / (unsigned)c8n;
+  const int c0 = (int)(j - pix * (unsigned)c8n) * 8;
+  const long i = (long)n * HW * c8n + j;
+  (void)total8;
+  const half8_t v = *(const half8_t*)in.at((long)n * HW + pix, c0);
   const f32x4* p = (const f32x4*)(ab + ((long)n * C + c0) * 2);
   half8_t o;
 #pragma unroll
@@ -535,6 +538,46 @@ __global__ __launch_bounds__(256) void gn_affine_kernel(GnIn in, half_t* __restr
     o[2 * j + 1] = (half_t)f1;
   }
   ((half8_t*)y)[i] = o;
+}
+// The same apply for channel counts whose octets divide the block (256 % (C / 8) == 0: 256 / 512 / 1024 / 2048 channels, every large map of the
+// UNets): a thread owns ONE channel octet -- its 16 coefficients stay in registers -- and walks the pixels of its block's slab, four 16-byte
+// chunks in flight; no per-chunk 64-bit div / mod, no 64 bytes of coefficient loads per 16 bytes of data (round 4; same arithmetic per element).
+template <bool SILU>
+__global__ __launch_bounds__(256) void gn_affine_rows_kernel(GnIn in, half_t* __restrict__ y, const float* __restrict__ ab, int HW, int C,
+                                                             int pix_per_block) {
+  const int n = blockIdx.y, c8n = C / 8, tid = threadIdx.x;
+  const int oct = tid % c8n, prow = tid / c8n, pstride = 256 / c8n;
+  const f32x4* cp = (const f32x4*)(ab + ((long)n * C + oct * 8) * 2);
+  f32x4 t[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) t[j] = cp[j];  // a0 b0 a1 b1
+  long XS;
+  const half_t* xb = in.column((long)n * HW, oct * 8, XS);
+  half_t* yb = y + ((long)n * HW) * C + oct * 8;
+  auto one = [&](const half8_t v) {
+    half8_t o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float f0 = (float)v[2 * j] * t[j].x + t[j].y, f1 = (float)v[2 * j + 1] * t[j].z + t[j].w;
+      if (SILU) {
+        f0 = silu_f(f0);
+        f1 = silu_f(f1);
+      }
+      o[2 * j] = (half_t)f0;
+      o[2 * j + 1] = (half_t)f1;
+    }
+    return o;
+  };
+  const int p0 = blockIdx.x * pix_per_block, p1 = min(p0 + pix_per_block, HW);
+  int p = p0 + prow;
+  for (; p + 3 * pstride < p1; p += 4 * pstride) {
+    half8_t v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *(const half8_t*)(xb + (long)(p + u * pstride) * XS);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) *(half8_t*)(yb + (long)(p + u * pstride) * C) = one(v[u]);
+  }
+  for (; p < p1; p += pstride) *(half8_t*)(yb + (long)p * C) = one(*(const half8_t*)(xb + (long)p * XS));
 }
 
 // Fused small-tensor path (one launch instead of three): one block per (image, chunk of GPB groups) streams its channels of every pixel twice
@@ -675,9 +718,20 @@ static int groupnorm_impl(const GnIn& in, void* y, const float* gamma, const flo
   hipLaunchKernelGGL(gn_coef_kernel, dim3(cdiv((long)N * C, 256)), dim3(256), 0, st, part, slabs, rows, gamma, beta, film, film_stride, ab, N, C,
                      cpg, (float)HW * (float)cpg, eps, G);
   LFM_CHECK_LAUNCH();
+  if (C / 8 <= 256 && 256 % (C / 8) == 0) {  // a thread per channel octet
+    const int pstride = 256 / (C / 8);
+    int app = HW >= 4096 ? 256 : (HW >= 256 ? 64 : HW);
+    if (app < 4 * pstride) app = 4 * pstride < HW ? 4 * pstride : HW;
+    if (silu) hipLaunchKernelGGL(gn_affine_rows_kernel<true>, dim3(cdiv(HW, app), N), dim3(256), 0, st, in, (half_t*)y, ab, HW, C, app);
+    else hipLaunchKernelGGL(gn_affine_rows_kernel<false>, dim3(cdiv(HW, app), N), dim3(256), 0, st, in, (half_t*)y, ab, HW, C, app);
+    LFM_CHECK_LAUNCH();
+    return LFM_OK;
+  }
   const long total8 = (long)N * HW * C / 8;
-  if (silu) hipLaunchKernelGGL(gn_affine_kernel<true>, dim3(cdiv(total8, 256)), dim3(256), 0, st, in, (half_t*)y, ab, HW, C, total8);
-  else hipLaunchKernelGGL(gn_affine_kernel<false>, dim3(cdiv(total8, 256)), dim3(256), 0, st, in, (half_t*)y, ab, HW, C, total8);
+  if ((long)HW * (C / 8) >= (1L << 31)) return LFM_ERR_SHAPE;
+  const dim3 ggrid(cdiv((long)HW * (C / 8), 256), N);
+  if (silu) hipLaunchKernelGGL(gn_affine_kernel<true>, ggrid, dim3(256), 0, st, in, (half_t*)y, ab, HW, C, total8);
+  else hipLaunchKernelGGL(gn_affine_kernel<false>, ggrid, dim3(256), 0, st, in, (half_t*)y, ab, HW, C, total8);
   LFM_CHECK_LAUNCH();
   return LFM_OK;
 }

@@ -361,18 +361,17 @@ __global__ __launch_bounds__(256) void gn_finish_kernel(const float* __restrict_
   }
 }
 
+// apply: y = silu?((x - mean) rstd gamma + beta).  Round 4: a thread OWNS one channel octet (256 % (C / 8) == 0) and walks the pixels of its block's
+// slab, so the statistics, gamma and beta are read once per thread and there is no per-element 64-bit index arithmetic (the first version -- one
+// 16-byte chunk per thread, four divisions and two 64-bit div / mod per chunk -- ran at 2.3 TB/s on the 2.15 GB full-resolution tensors:
+// profiles/r03_final_bench_kernel_stats.csv, 6.2 ms of a 39.6 ms decode).  Same arithmetic per element.
 template <bool SILU>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, const float* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, int HW, int C,
-                                                       long total8) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total8) return;
-  const int c8n = C / 8, cpg = C / 32;
-  const int oct = (int)(i % c8n);
-  const int n = (int)(i / ((long)c8n * HW));
+                                                       int pix_per_block) {
+  const int n = blockIdx.y, c8n = C / 8, cpg = C / 32, tid = threadIdx.x;
+  const int oct = tid % c8n, prow = tid / c8n, pstride = 256 / c8n;
   const float cnt = (float)HW * (float)cpg;
-  const half8_t v = ((const half8_t*)x)[i];
-  half8_t o;
   float mean[2], rstd[2];
 #pragma unroll
   for (int hh = 0; hh < 2; ++hh) {
@@ -381,14 +380,30 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
     const float var = fmaxf(stats[((long)n * 32 + g) * 2 + 1] / cnt - mean[hh] * mean[hh], 0.f);
     rstd[hh] = rsqrtf(var + 1e-6f);
   }
+  const f32x4 g0 = *(const f32x4*)(gamma + oct * 8), g1 = *(const f32x4*)(gamma + oct * 8 + 4);
+  const f32x4 b0 = *(const f32x4*)(beta + oct * 8), b1 = *(const f32x4*)(beta + oct * 8 + 4);
+  const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+  const int p0 = blockIdx.x * pix_per_block, p1 = min(p0 + pix_per_block, HW);
+  const long base = ((long)n * HW) * C + oct * 8;
+  auto one = [&](const half8_t v) {
+    half8_t o;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int c = oct * 8 + j;
-    float f = ((float)v[j] - mean[j >> 2]) * rstd[j >> 2] * gamma[c] + beta[c];
-    if (SILU) f = silu_f(f);
-    o[j] = (half_t)f;
+    for (int j = 0; j < 8; ++j) {
+      float f = ((float)v[j] - mean[j >> 2]) * rstd[j >> 2] * gm[j] + bt[j];
+      if (SILU) f = silu_f(f);
+      o[j] = (half_t)f;
+    }
+    return o;
+  };
+  int p = p0 + prow;
+  for (; p + 3 * pstride < p1; p += 4 * pstride) {  // four chunks in flight per thread
+    half8_t v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *(const half8_t*)(x + base + (long)(p + u * pstride) * C);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) *(half8_t*)(y + base + (long)(p + u * pstride) * C) = one(v[u]);
   }
-  ((half8_t*)y)[i] = o;
+  for (; p < p1; p += pstride) *(half8_t*)(y + base + (long)p * C) = one(*(const half8_t*)(x + base + (long)p * C));
 }
 
 // rows of S [rows, T] fp32 -> P fp16 = softmax(S * scale); one wave per row.
@@ -472,9 +487,9 @@ static int gn(const half_t* x, half_t* y, float* stats, float* part, const float
   }
   hipLaunchKernelGGL(gn_finish_kernel, dim3(cdiv(n * 32, 4)), dim3(256), 0, st, part, stats, slabs, C, n * 32);
   LFM_CHECK_LAUNCH();
-  const long total8 = (long)n * HW * C / 8;
-  if (silu) hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(cdiv(total8, 256)), dim3(256), 0, st, x, y, stats, g, b, HW, C, total8);
-  else hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(cdiv(total8, 256)), dim3(256), 0, st, x, y, stats, g, b, HW, C, total8);
+  const int app = HW >= 4096 ? 256 : (HW >= 256 ? 64 : HW);  // pixels per block: 16 .. 4 chunks per thread at 128 .. 512 channels
+  if (silu) hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(cdiv(HW, app), n), dim3(256), 0, st, x, y, stats, g, b, HW, C, app);
+  else hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(cdiv(HW, app), n), dim3(256), 0, st, x, y, stats, g, b, HW, C, app);
   LFM_CHECK_LAUNCH();
   return LFM_OK;
 }

@@ -191,6 +191,16 @@ class DhariwalUNet(nn.Module):
                     d.update(gn2=(f32(b.norm2.weight), f32(b.norm2.bias)),
                              qkv=(f16(b.qkv.weight.reshape(3 * C, C)[perm]), f32(b.qkv.bias[perm])), proj=conv1(b.proj))
                 P[pre + name] = d
+        # every block's `affine` projection of the embedding (EDM.py:263-265) in ONE GEMM per evaluation: weights stacked row-wise, a block reads its
+        # [scale | shift] columns of the result (28 launches of ~16 us each at the ffhq_adm size otherwise: profiles/r04_config6_kernel_stats.csv)
+        offs, ws_, bs_, off = {}, [], [], 0
+        for key, d in P.items():
+            if isinstance(d, dict):
+                offs[key] = (off, d["aff"][0].shape[0])
+                ws_.append(d["aff"][0])
+                bs_.append(d["aff"][1])
+                off += d["aff"][0].shape[0]
+        P["aff_all"] = (torch.cat(ws_, 0).contiguous(), torch.cat(bs_, 0).contiguous(), offs)
         P["time"] = (f32(self.map_layer0.weight), f32(self.map_layer0.bias), f32(self.map_layer1.weight), f32(self.map_layer1.bias))
         if self.map_label is not None:  # [label_dim + 1, E]: column lookup + one all-zero row for the dropped label
             P["label"] = torch.cat([f32(self.map_label.weight).t(), torch.zeros(1, self.emb_channels, device=dev)], 0).contiguous()
@@ -247,7 +257,7 @@ class DhariwalUNet(nn.Module):
         hip.check(hip.lib().lfm_avgpool2_f16(hip.ptr(x), hip.ptr(y), N, Ho, Wo, C, hip.stream_ptr(x.device)), "lfm_avgpool2_f16")
         return y
 
-    def _block(self, name, b, x, N, H, W, emb_silu):
+    def _block(self, name, b, x, N, H, W, film_all):
         """UNetBlock.forward (EDM.py:258-292).  Returns (out, H, W)."""
         p = self._packed[name]
         Cin, Cout = b.in_channels, b.out_channels
@@ -263,7 +273,8 @@ class DhariwalUNet(nn.Module):
             h = self._conv(t, p["c0"], N, H, W, Cin, Cout, mode=1)
         else:
             h = self._conv(t, p["c0"], N, H, W, Cin, Cout)
-        film = hip.gemm_f16(emb_silu, p["aff"][0], p["aff"][1], epilogue=2)  # fp32 [N, 2*Cout] = [scale | shift]
+        fo, fw = self._packed["aff_all"][2][name]
+        film = film_all[:, fo:fo + fw]  # fp32 [N, 2*Cout] = [scale | shift]: this block's columns of the one affine GEMM (row stride = all blocks' columns)
         t = self._gn(h, N, H * W, Cout, p["gn1"], film, True)
         if b.up:  # skip(orig) with kernel 0 = nearest 2x upsample of the input (conv_transpose with the all-ones 2x2 filter)
             up = torch.empty(N * H * W, Cin, dtype=torch.float16, device=x.device)
@@ -311,6 +322,7 @@ class DhariwalUNet(nn.Module):
         hip.check(L.lfm_time_embed(hip.ptr(t), t.numel(), hip.ptr(tw[0]), hip.ptr(tw[1]), hip.ptr(tw[2]), hip.ptr(tw[3]),
                                    hip.ptr(P["label"] if yy is not None else None), hip.ptr(yy), n_labels, hip.ptr(h1), hip.ptr(emb),
                                    hip.ptr(emb_silu), N, F, E, hip.stream_ptr(dev)), "lfm_time_embed")
+        film_all = hip.gemm_f16(emb_silu, P["aff_all"][0], P["aff_all"][1], epilogue=2)  # fp32 [N, sum of 2*Cout over the blocks]
         skips, h = [], None
         for name, b in self.enc.items():
             if isinstance(b, Conv2d):
@@ -319,7 +331,7 @@ class DhariwalUNet(nn.Module):
                 hip.check(L.lfm_conv3x3_in_f32(hip.ptr(x), hip.ptr(wb[0]), hip.ptr(wb[1]), hip.ptr(h), N, H, W, Cin, b.out_channels,
                                                hip.stream_ptr(dev)), "lfm_conv3x3_in_f32")
             else:
-                h, H, W = self._block("enc." + name, b, h, N, H, W, emb_silu)
+                h, H, W = self._block("enc." + name, b, h, N, H, W, film_all)
             skips.append((h, h.shape[1]))
         for name, b in self.dec.items():
             if h.shape[1] != b.in_channels:
@@ -328,7 +340,7 @@ class DhariwalUNet(nn.Module):
                 hip.check(L.lfm_concat_channels_f16(hip.ptr(h), hip.ptr(s), hip.ptr(cat), h.shape[0], h.shape[1], cs, hip.stream_ptr(dev)),
                           "lfm_concat_channels_f16")
                 h = cat
-            h, H, W = self._block("dec." + name, b, h, N, H, W, emb_silu)
+            h, H, W = self._block("dec." + name, b, h, N, H, W, film_all)
         t1 = self._gn(h, N, H * W, h.shape[1], P["gn_out"], None, True)
         out = torch.empty(N, self.out_channels, H, W, device=dev)
         co = P["conv_out"]
