@@ -42,6 +42,8 @@ static __device__ unsigned long long att_wg_trace[ATT_WG_TRACE][4];
 // partner wave already fills those gaps.  Kept: the lazy rescale (below).
 // Measured and NOT kept on that evidence (round 2): a streamed schedule (DMAs issued key block by key block, V^T slices as 64-byte pieces, the online-softmax
 // loop started after block 0 behind one counted vmcnt + barrier per block): correct, 40.8-41.7 us vs 40.1-42.8 us.
+// (Round 4, tried and dropped: the row maxima as inline-asm v_max3_f32 to skip the few canonicalising v_max_f32 x, x that IEEE fmaxf puts in front of MFMA
+// results -- the compiler's hazard recogniser does not see an asm reading MFMA accumulators, and the hd-72 runs stopped being bit-repeatable.)
 template <int T, int JQ, int HD, int MODE = 0>
 __global__ __launch_bounds__((T / (32 * JQ)) * 64, HD == 64 ? (T / (32 * JQ)) / 2 : 2) void dit_attention_kernel(
     const half_t* __restrict__ Q, const half_t* __restrict__ K, const half_t* __restrict__ Vt, half_t* __restrict__ O, int D, int heads,
@@ -261,6 +263,37 @@ __global__ __launch_bounds__((T / (32 * JQ)) * 64, HD == 64 ? (T / (32 * JQ)) / 
     stamp(6 + 2 * kb);
   }
   // ---- normalise and store: lane owns query q, d = db*32 + 8g + 4*hsel + r
+  if constexpr (HD == 64 && MODE == 0) {
+    // Round 4: through the LDS (K / V^T are dead) so that a store instruction covers eight whole 128-byte output rows instead of 64 scattered 8-byte
+    // pieces (the store drain was ~5k of a workgroup's ~33k cycles, profiles/r03_attention_wg_timeline.txt; MI355X guide T21).  Per-wave region of
+    // 32 JQ rows x 144 B (128 B of data; the 36-dword stride keeps the 16 lanes of a ds_write_b64 group on distinct banks).
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave has finished reading K / V^T
+    asm volatile("" ::: "memory");
+    char* ob = smem + wave * (32 * JQ * 144);
+#pragma unroll
+    for (int jq = 0; jq < JQ; ++jq) {
+      const float inv = 1.0f / (lrun[jq] + xhalf(lrun[jq]));
+#pragma unroll
+      for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          half4_t h = {(half_t)(Oa[jq][db][4 * g] * inv), (half_t)(Oa[jq][db][4 * g + 1] * inv), (half_t)(Oa[jq][db][4 * g + 2] * inv),
+                       (half_t)(Oa[jq][db][4 * g + 3] * inv)};
+          *(half4_t*)(ob + (jq * 32 + l31) * 144 + (db * 32 + 8 * g + 4 * hsel) * 2) = h;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: no barrier
+    half_t* obase = O + ((long)img * T + q0) * D + head * HD;
+#pragma unroll
+    for (int i = 0; i < 4 * JQ; ++i) {
+      const int row = i * 8 + (lane >> 3), ch = lane & 7;
+      const half8_t v = *(const half8_t*)(ob + row * 144 + ch * 16);
+      *(half8_t*)(obase + (long)row * D + ch * 8) = v;
+    }
+    stamp(19);
+    return;
+  }
 #pragma unroll
   for (int jq = 0; jq < JQ; ++jq) {
     const float inv = 1.0f / (lrun[jq] + xhalf(lrun[jq]));
@@ -347,9 +380,10 @@ static int attention_launch(const half_t* Q, const half_t* K, const half_t* Vt, 
   const float sl2 = (hd == 64 ? 0.125f : 0.11785113019775793f) * 1.4426950408889634f;  // hd^-0.5 * log2(e)
   const size_t lds = (size_t)T * hd * 4;  // K + V^T, 2 bytes each
   dim3 grid(heads, batch);
-  // A/B switch (measurement only): 8 waves x 32 queries (4 waves/SIMD) measured 44.3 us vs 40.2 us for 4 waves x 64 queries --
-  // the kernel moves Q,K,V^T,O = 134 MB per launch (3.4 TB/s): more waves do not help
-  const bool narrow = T == 256 && (lfm_gemm_debug_flags() & 256);
+  // Rounds 1-3: 8 waves x 32 queries (4 waves/SIMD) measured 44.3 us vs 40.2 us for 4 waves x 64 queries (two 8-byte V^T reads per fragment then).
+  // Round 4: with the V^T operand a single conflict-free ds_read_b128 (vt_pos) the balance flipped -- 8 waves x 32 queries (126 VGPRs: four waves per
+  // SIMD) 35.7 us, 4 waves x 64 queries (228 VGPRs: two) 38.9 us -- so the narrow shape is the default; flag 256 selects the wide one (A/B)
+  const bool narrow = T == 256 && !(lfm_gemm_debug_flags() & 256);
   [[maybe_unused]] const int mode = (lfm_gemm_debug_flags() >> 25) & 3;  // flags 33554432 / 67108864 / both: the measurement-only variants MODE 1 / 2 / 3 (hd 64, 256 tokens)
 #ifdef LFM_MEASURE
   if (mode && hd == 64 && T == 256) {
