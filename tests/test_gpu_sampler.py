@@ -182,3 +182,26 @@ def test_dopri5_device_path_accepts_generic_stage_tensors(kind):
     Ad, cd = A.to(dev), c.to(dev)
     got = odeint(lambda tt, yy: field(tt, yy, Ad, cd), y0.to(dev), t.to(dev), method="dopri5", rtol=1e-6, atol=1e-6)
     assert rel_l2(got[-1], ref[-1]) < 1e-5, kind
+
+
+def test_dopri5_device_path_rejects_steps_like_the_oracle():
+    """The adaptive controller's REJECTION branch on the device fast path (one lfm_rk_error_norm read-back per attempt, step shrunk, stage derivatives
+    recomputed from the unchanged state): a field whose stiffness jumps by 50x at t = 0.5 forces rejected attempts; attempts, accepted steps and the
+    end point must follow the CPU oracle (the DiT configurations' seeded random fields are smooth: 15 / 15 accepted)."""
+    from lfm_amd.solvers import odeint
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(21)
+    y0 = torch.randn(4, 8, 16, generator=g)
+
+    def field(t, y):
+        return -y * (1.0 + 50.0 * torch.sigmoid(200.0 * (t - 0.5))) + torch.cos(3.0 * t)
+
+    t = torch.tensor([0.0, 1.0])
+    sa, sb = {}, {}
+    ref = ode_ref.odeint(field, y0, t, method="dopri5", rtol=1e-5, atol=1e-6, stats=sb)
+    got = odeint(field, y0.to(dev), t.to(dev), method="dopri5", rtol=1e-5, atol=1e-6, stats=sa)
+    assert sb["steps"] > sb["accepted"], "the oracle did not reject anything: the test field is too smooth"
+    assert sa["steps"] > sa["accepted"]
+    assert abs(sa["steps"] - sb["steps"]) <= 2 and abs(sa["accepted"] - sb["accepted"]) <= 2, (sa, sb)
+    assert rel_l2(got[-1], ref[-1]) < 1e-4

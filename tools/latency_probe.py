@@ -3,7 +3,7 @@ import sys, statistics, torch
 sys.path.insert(0, "."); sys.path.insert(0, "/root/repo")
 from lfm_amd import hip
 from lfm_amd.models import DiT_models
-from lfm_amd.solvers import odeint
+from lfm_amd.solvers import odeint, sample_torchdiffeq_euler_fused
 dev = torch.device("cuda:0")
 for name, flags in (("DiT-L/2", 0), ("DiT-L/2", 512), ("DiT-B/2", 0)):
     hip.gemm_select(flags << 4)  # flag 512: split-K off
@@ -17,13 +17,12 @@ for name, flags in (("DiT-L/2", 0), ("DiT-L/2", 512), ("DiT-B/2", 0)):
         for _ in range(20): m(t, x)
         e.record(); torch.cuda.synchronize()
         eager = s.elapsed_time(e) / 20
-        tt = torch.tensor([1.0, 0.0], device=dev)
-        f = lambda t_, x_: m(t_, x_)
-        odeint(f, x, tt, method="euler", options={"step_size": 0.02})  # captures the graph
+        # what --measure_time runs (test_flow_latent.py:223-246 -> sample_from_model -> the graph-captured fixed-grid solver, per-grid conditioning tables)
+        sample_torchdiffeq_euler_fused(m, x, 0.02, {})  # captures the graph
         torch.cuda.synchronize()
         ts = []
         for _ in range(5):
-            s.record(); odeint(f, x, tt, method="euler", options={"step_size": 0.02}); e.record(); torch.cuda.synchronize()
+            s.record(); sample_torchdiffeq_euler_fused(m, x, 0.02, {}); e.record(); torch.cuda.synchronize()
             ts.append(s.elapsed_time(e))
         nparam = sum(p.numel() for p in m.parameters())
         step = statistics.median(ts) / 50

@@ -1,4 +1,4 @@
-"""(M) The one-wave-per-SIMD 256x256 GEMM (csrc/gemm256w_kernel.h, kernel 6) against the eight-wave one (kernel 5): the four DiT-L/2 block shapes with their
+"""(M) The one-wave-per-SIMD 256x256 GEMMs (csrc/gemm256w_kernel.h = kernel 6, its quadrant-phased successor gemm256x_kernel.h = kernel 7) against the eight-wave one (kernel 5): the four DiT-L/2 block shapes with their
 real epilogue families, bit equality of the results, the main-loop ablations of kernel 6 (LFM_MEASURE build: no epilogue; no LDS-DMA / no fragment reads /
 neither; DMA placement variant), and the whole DiT-L/2 batch-64 forward with LFM_OPT_GEMM_V6 off / on.  Interleaved medians.
 usage: LFM_MEASURE=1 python -m lfm_amd._build && python tools/w6_probe.py"""
@@ -38,8 +38,7 @@ for name, N, K, epi in shapes:
     same = all(torch.equal(a, c) for a, c in zip(outs[5], outs[6]))
     variants = [("v5 full", 5), ("v6 full", 6), ("v5 no epilogue", 5 | (4 << 4)), ("v6 no epilogue", 6 | (4 << 4))]
     if epi == 1:
-        variants += [("v6 no epi, no DMA", 6 | ((4 | (1 << 21)) << 4)), ("v6 no epi, no reads", 6 | ((4 | (2 << 21)) << 4)), ("v6 no epi, MFMA+barrier only", 6 | ((4 | (3 << 21)) << 4)),
-                     ("v6 no epi, DMA 2/group early", 6 | ((4 | (8 << 21)) << 4)), ("v6 full, DMA 2/group early", 6 | ((8 << 21) << 4))]
+        variants += [("v6 no epi, no DMA", 6 | ((4 | (1 << 21)) << 4)), ("v6 no epi, no reads", 6 | ((4 | (2 << 21)) << 4)), ("v6 no epi, MFMA+barrier only", 6 | ((4 | (3 << 21)) << 4))]
     res = {n: [] for n, _ in variants}
     for rnd in range(5):
         for n, sel in variants:
@@ -56,7 +55,7 @@ for p in m.parameters():
     if not bool(p.any()): torch.nn.init.normal_(p, std=0.02)
 m = m.to(dev).eval()
 x = torch.randn(64, 4, 32, 32, device=dev); t = torch.tensor(0.5, device=dev)
-cfgs = [("v5", 0, 0), ("v5 + epilogue X prefetch", 0, 1), ("v6", 1, 0)]
+cfgs = [("v5", 0, 0), ("v6", 1, 0)]
 o = {}
 for name, v6, xpf in cfgs:
     hip.set_option(hip.OPT_GEMM_V6, v6); hip.set_option(hip.OPT_EPI_PREFETCH, xpf); o[name] = m(t, x).clone()
