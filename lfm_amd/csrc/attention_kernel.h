@@ -91,6 +91,10 @@ __global__ __launch_bounds__((T / (32 * JQ)) * 64, HD == 64 ? (T / (32 * JQ)) / 
   wg_stamp(0);
   const half_t* Kg = K + (long)img * T * D + head * HD;
   const half_t* Vg = Vt + ((long)img * heads + head) * HD * T;
+  // buffer-addressed LDS-DMA (SGPR resource + 32-bit VGPR byte offset: +13 % LDS-DMA throughput per CU over 64-bit VGPR addresses,
+  // tools/ubench/ldsdma_rate.hip -- the load phase is a third of a workgroup's life)
+  const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)Kg, 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)Vg, 0, -1, 0x00020000);
 
   // ---- stage K, fetch this wave's Q fragments, then stage V^T.  Issue order = completion order for loads, so
   // vmcnt(VMIN) below means "K and Q are here, V^T may still be flying"; V^T is awaited before the first PV.
@@ -107,7 +111,7 @@ __global__ __launch_bounds__((T / (32 * JQ)) * 64, HD == 64 ? (T / (32 * JQ)) / 
     if (SLOTS % NTHR == 0 || p + 1 < NPASS || s < SLOTS) {
       const int row = s / KCH, ch = s - row * KCH;
       const int c = KSWZ ? (ch ^ ((row >> 1) & 7)) : ch;
-      if (MODE != 2) glds16(Kg + (long)row * D + c * 8, Ks + (p * NTHR + wave * 64) * 16);
+      if (MODE != 2) glds16_buf(rs_k, (unsigned)(row * D + c * 8) * 2u, 0u, Ks + (p * NTHR + wave * 64) * 16);
     }
   }
   const int q0 = wave * 32 * JQ;
@@ -128,7 +132,7 @@ __global__ __launch_bounds__((T / (32 * JQ)) * 64, HD == 64 ? (T / (32 * JQ)) / 
     if (SLOTS % NTHR == 0 || p + 1 < NPASS || s < SLOTS) {
       constexpr int CPR = T / 8;  // 16-B chunks per V^T row
       const int row = s / CPR, c = (s % CPR) ^ (row & VKEY);
-      if (MODE != 2) glds16(Vg + (long)row * T + c * 8, Vs + (p * NTHR + wave * 64) * 16);
+      if (MODE != 2) glds16_buf(rs_v, (unsigned)(row * T + c * 8) * 2u, 0u, Vs + (p * NTHR + wave * 64) * 16);
     }
   }
 
