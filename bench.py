@@ -39,7 +39,7 @@ CONFIG3_FIELD_GAIN = 100.0  # output-layer scale of config 3's synthetic field (
 # rocprofv3 PMC passes of the shipped kernel IN SITU (inside DiT-L/2 batch-64 forwards, tools/profile_round.sh): FETCH_SIZE x 2 (gfx950 correction
 # for 16-B-per-lane streams, MI355X_MICROARCH.md) + WRITE_SIZE, KiB.  These are fabric-side request counters: Infinity-Cache hits are INCLUDED (the
 # whole working set of this GEMM fits the 256 MiB cache), so this is an upper bound on HBM bytes, not HBM bytes.  Source file named in `traffic_source`.
-FC1_TRAFFIC = {"fetch_kib": 99350.6, "write_kib": 131136.0, "source": "profiles/r03_final_pmc_in_situ.txt (EpiModGeluF16: fetch / write passes)"}
+FC1_TRAFFIC = {"fetch_kib": 99350.8, "write_kib": 131136.0, "source": "profiles/r04_final_pmc_in_situ.txt (EpiModGeluF16: fetch / write passes)"}
 
 
 def parse():
