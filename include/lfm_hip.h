@@ -150,9 +150,6 @@ int lfm_profile_fc1(int enable);
 /* key 2 (LFM_OPT_GEMM_V6), value 0 / 1: the chip-filling row-major GEMMs (the four linears of a DiT block) on the one-wave-per-SIMD 256x256 kernel
  * (csrc/gemm256w_kernel.h) instead of the eight-wave one.  Same accumulation order per output element: bit-identical results. */
 #define LFM_OPT_GEMM_V6 2
-/* key 3 (LFM_OPT_EPI_PREFETCH), value 0 / 1: the gated-residual epilogues of the eight-wave kernel on the folded path request the residual rows of
- * the next 32-row pass before they issue the stores of the current one (the four-wave kernel always does).  Bit-identical results. */
-#define LFM_OPT_EPI_PREFETCH 3
 int lfm_set_option(int key, int value);
 
 /* Measurement aid (bench.py): the clock the chip sustains under matrix load.  `blocks` workgroups of 512 threads each stream iters x 64 MFMAs per wave on

@@ -20,21 +20,10 @@ int lfm_gemm_prefers_v4(int M, int N, int K) {
 static int g_opt_fold_ln = 1;
 static int g_opt_v6 = 0;
 int lfm_gemm_v6_default() { return g_opt_v6; }
-static int g_opt_xpf = 0;  // producer epilogues of the eight-wave kernel request the next pass's residual rows ahead of the current pass's stores
-static inline EpiGateResidModP as_xpf(const EpiGateResidMod& e) {
-  static_assert(sizeof(EpiGateResidModP) == sizeof(EpiGateResidMod), "same members");
-  EpiGateResidModP p;
-  memcpy((void*)&p, (const void*)&e, sizeof p);
-  return p;
-}
 
 extern "C" int lfm_set_option(int key, int value) {  // key 1 (LFM_OPT_FOLD_LN): adaLN LayerNorm-modulate folded into the GEMM epilogues (default 1)
   if (key == 1) {
     g_opt_fold_ln = value != 0;
-    return LFM_OK;
-  }
-  if (key == 3) {  // LFM_OPT_EPI_PREFETCH
-    g_opt_xpf = value != 0;
     return LFM_OK;
   }
   if (key == 2) {  // LFM_OPT_GEMM_V6: the one-wave-per-SIMD 256x256 kernel for the chip-filling row-major GEMMs
@@ -64,7 +53,7 @@ __global__ __launch_bounds__(256) void temb1_kernel(const float* __restrict__ t,
 #pragma unroll
   for (int k = lane; k < 256; k += 64) {
     const int i = k & 127;
-    const float a = tv * __expf(-9.210340371976184f * (float)i / 128.0f);  // t * exp(-ln(1e4) i/half)
+    const float a = tv * expf(-9.210340371976184f * (float)i / 128.0f);  // t * exp(-ln(1e4) i/half)
     s += w[k] * (k < 128 ? cosf(a) : sinf(a));
   }
   s = wave_sum(s);
@@ -1265,8 +1254,7 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
       if (rc) return rc;
       // proj: X += gate_msa * (.), A' for fc1 with scale_mlp, partials; c = the row means the qkv GEMM just published
       const EpiGateResidMod e_proj{ws.X, D, w->proj_b + (size_t)i * D, mod + 2 * D, mstride, T, ws.A2, mod + 4 * D, mstride, ws.cen[cen_cur], ws.ln_part, tiles_p};
-      rc = g_opt_xpf ? launch_fold(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D, as_xpf(e_proj))
-                     : launch_fold(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D, e_proj);
+      rc = launch_fold(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D, e_proj);
       if (rc) return rc;
       const bool prof = g_prof_on && g_prof_count < LFM_PROF_MAX;
       if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_count], st);
@@ -1276,8 +1264,7 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
       if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_count++ + 1], st);
       if (i + 1 < s->depth) {  // fc2 writes the NEXT block's A' (its scale_msa)
         const EpiGateResidMod e_fc2{ws.X, D, w->fc2_b + (size_t)i * D, mod + 5 * D, mstride, T, ws.A, mod + 7 * D, mstride, ws.cen[cen_cur], ws.ln_part, tiles_p};
-        rc = g_opt_xpf ? launch_fold(ASrcRowMajor{ws.QKVH, H, M, 0}, (const half_t*)w->fc2_w + (size_t)i * D * H, H, M, D, H, as_xpf(e_fc2))
-                       : launch_fold(ASrcRowMajor{ws.QKVH, H, M, 0}, (const half_t*)w->fc2_w + (size_t)i * D * H, H, M, D, H, e_fc2);
+        rc = launch_fold(ASrcRowMajor{ws.QKVH, H, M, 0}, (const half_t*)w->fc2_w + (size_t)i * D * H, H, M, D, H, e_fc2);
       } else {
         const EpiGateResidF32 e_fc2{ws.X, D, w->fc2_b + (size_t)i * D, mod + 5 * D, mstride, T};
         rc = launch_fold(ASrcRowMajor{ws.QKVH, H, M, 0}, (const half_t*)w->fc2_w + (size_t)i * D * H, H, M, D, H, e_fc2);

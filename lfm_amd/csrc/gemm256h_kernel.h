@@ -197,12 +197,6 @@ __device__ __forceinline__ void g256h_epilogue_mod(f32x4_t (&acc)[8][4], char* s
   const f32x4 bias = *(const f32x4*)(epi.bias + n);
   const f32x4 gate = *(const f32x4*)(epi.gate + (long)img * epi.gate_stride + n);
   const f32x4 sc1 = *(const f32x4*)(epi.scale + (long)img * epi.mod_stride + n) + 1.0f;
-  f32x4 xo[2][8];  // [pass parity][row]: with Epi::xpf the next pass's rows are in flight while this pass's stores are issued
-  auto load_x = [&](int buf, int i) {
-#pragma unroll
-    for (int ps = 0; ps < 8; ++ps) xo[buf][ps] = *(const f32x4*)(epi.X + (long)(m0 + g * 128 + i * 32 + rrow + ps * 4) * epi.ldx + n);
-  };
-  if constexpr (Epi::xpf) load_x(0, 0);
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -212,16 +206,14 @@ __device__ __forceinline__ void g256h_epilogue_mod(f32x4_t (&acc)[8][4], char* s
       for (int j = 0; j < 4; ++j) *(f32x4_t*)(scr + (h2 * 16 + l15) * 272 + (j * 16 + l4 * 4) * 4) = acc[2 * i + h2][j];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const int rl = g * 128 + i * 32 + rrow;  // + 4 ps: row inside the tile
-    if constexpr (Epi::xpf) {
-      if (i + 1 < 4) load_x((i + 1) & 1, i + 1);
-    } else {
-      load_x(i & 1, i);
-    }
+    f32x4 xo[8];
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) xo[ps] = *(const f32x4*)(epi.X + (long)(m0 + rl + ps * 4) * epi.ldx + n);
 #pragma unroll
     for (int ps = 0; ps < 8; ++ps) {
       const f32x4 v = *(const f32x4*)(scr + (ps * 4 + rrow) * 272 + rcol * 16);
       const float c = cen_s[rl + ps * 4];
-      const f32x4 xn = xo[i & 1][ps] + gate * (v + bias);
+      const f32x4 xn = xo[ps] + gate * (v + bias);
       *(f32x4*)(epi.X + (long)(m0 + rl + ps * 4) * epi.ldx + n) = xn;
       const f32x4 d = xn - c;
       const f32x4 ap = d * sc1;

@@ -1033,7 +1033,7 @@ __global__ __launch_bounds__(256) void time_embed1_kernel(const float* __restric
   float s = 0.f;
   for (int k = lane; k < 2 * half; k += 64) {
     const int i = k < half ? k : k - half;
-    const float a = tv * __expf(-9.210340371976184f * (float)i / (float)half);
+    const float a = tv * expf(-9.210340371976184f * (float)i / (float)half);
     s += w[k] * (k < half ? cosf(a) : sinf(a));
   }
   s = wave_sum(s);

@@ -223,7 +223,6 @@ def ln_modulate(X, shift, scale, tokens, mod_stride):
 
 
 OPT_FOLD_LN = 1  # adaLN LayerNorm-modulate folded into the GEMM epilogues, default on (include/lfm_hip.h)
-OPT_EPI_PREFETCH = 3  # producer epilogues of the eight-wave GEMM prefetch the next pass's residual rows (A/B; include/lfm_hip.h)
 OPT_GEMM_V6 = 2  # chip-filling row-major GEMMs on the one-wave-per-SIMD 256x256 kernel (csrc/gemm256w_kernel.h) instead of the 8-wave one
 
 

@@ -55,16 +55,16 @@ for p in m.parameters():
     if not bool(p.any()): torch.nn.init.normal_(p, std=0.02)
 m = m.to(dev).eval()
 x = torch.randn(64, 4, 32, 32, device=dev); t = torch.tensor(0.5, device=dev)
-cfgs = [("v5", 0, 0), ("v6", 1, 0)]
+cfgs = [("v5", 0), ("v6", 1)]
 o = {}
-for name, v6, xpf in cfgs:
-    hip.set_option(hip.OPT_GEMM_V6, v6); hip.set_option(hip.OPT_EPI_PREFETCH, xpf); o[name] = m(t, x).clone()
+for name, v6 in cfgs:
+    hip.set_option(hip.OPT_GEMM_V6, v6); o[name] = m(t, x).clone()
 torch.cuda.synchronize()
-for name, _, _ in cfgs[1:]:
+for name, _ in cfgs[1:]:
     print(f"DiT-L/2 b64 forward, {name} vs v5: bitwise equal {torch.equal(o['v5'], o[name])}, rel-L2 {float((o['v5'] - o[name]).norm() / o['v5'].norm()):.2e}", flush=True)
-res = {n: [] for n, _, _ in cfgs}
+res = {n: [] for n, _ in cfgs}
 for rnd in range(5):
-    for name, v6, xpf in cfgs:
-        hip.set_option(hip.OPT_GEMM_V6, v6); hip.set_option(hip.OPT_EPI_PREFETCH, xpf); res[name].append(timeit(lambda: m(t, x), n=6, warm=2))
-hip.set_option(hip.OPT_GEMM_V6, 0); hip.set_option(hip.OPT_EPI_PREFETCH, 0)
-for name, _, _ in cfgs: print(f"forward DiT-L/2 b64 {name:28s}: median {statistics.median(res[name]) / 1e3:7.3f} ms  min {min(res[name]) / 1e3:7.3f} ms", flush=True)
+    for name, v6 in cfgs:
+        hip.set_option(hip.OPT_GEMM_V6, v6); res[name].append(timeit(lambda: m(t, x), n=6, warm=2))
+hip.set_option(hip.OPT_GEMM_V6, 0)
+for name, _ in cfgs: print(f"forward DiT-L/2 b64 {name:28s}: median {statistics.median(res[name]) / 1e3:7.3f} ms  min {min(res[name]) / 1e3:7.3f} ms", flush=True)
