@@ -118,8 +118,8 @@ __device__ __forceinline__ void g256w_epilogue_mod(f32x4_t (&acc)[2][8][4], char
 
 // ABL (LFM_MEASURE builds; results are garbage, timings are the point): 1 = no LDS-DMA after the prologue, 2 = no fragment reads, 3 = neither,
 // 4 = 3 without the barrier and the waits in the middle of a K-tile (the bare MFMA stream).
-// VAR: where the sixteen LDS-DMAs of a K-tile go in its second step: 0 = one per group of four MFMAs, 1 = two per group in the first eight groups,
-//      2 = one per group, the position inside the group rotated by the wave id (the four SIMDs' issues do not coincide)
+// VAR: where the sixteen LDS-DMAs of a K-tile go in its second step: 0 = one per group of four MFMAs (shipped), 1 = two per group in the first eight groups
+//      (measurement builds: 100.8 vs 97.5 us on the fc1 loop)
 // OPT bit 0: LDS-DMAs through buffer resources (see gemm256h_kernel.h)
 template <class ASrc, class Epi, int ABL = 0, int VAR = 0, int OPT = G256H_DEFAULT_OPT>
 __global__ __launch_bounds__(256) void gemm256w_tn_kernel(ASrc asrc, const half_t* __restrict__ W, long ldw, int M, int N, int K, int tiles_n,

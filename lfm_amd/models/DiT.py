@@ -210,7 +210,7 @@ class DiT(nn.Module):
         return (f"depth={self.depth}, hidden={self.hidden_size}, heads={self.num_heads}, patch={self.patch_size}, "
                 f"res={self.img_resolution}, in_ch={self.in_channels}")
 
-    # ---- the single entry to the device code
+    # ---- per-grid conditioning tables (unconditional models under a fixed-grid solver)
     @torch.no_grad()
     def cond_table(self, ts, batch):
         """Per-grid conditioning table (include/lfm_hip.h: lfm_dit_cond_table_build) for the grid times `ts` (device fp32 [n]): what every evaluation of
@@ -229,6 +229,7 @@ class DiT(nn.Module):
         hip.check(rc, "lfm_dit_cond_table_build")
         return table
 
+    # ---- the single entry to the device code
     @torch.no_grad()
     def _run(self, t, x, y, cfg, cfg_scale, out=None, axpy_base=None, axpy_dt=None, cond=None):
         hip.require_gpu(x, "DiT.forward")
