@@ -353,3 +353,22 @@ def test_conv_split_k_plan_for_the_small_maps():
     assert ws(32, 4, 1024, 1024) == 16 * 512 * 1024 * 4                      # 32 tiles -> sixteen slices of 576
     assert ws(2, 8, 64, 128) == 0                                            # K = 576: a half (288) is not a multiple of the 64-deep K-tile
     assert ws(0, 8, 64, 128) == 0
+
+
+def test_seeded_edm_state_is_order_independent_and_fp16_exact():
+    """oracle/edm_state.py: the weights of the full-size EDM fixtures are regenerated from (tensor name, shape, seed) on both sides -- the reference module in
+    oracle/make_golden.py, the product module in the GPU tests -- so the draw must not depend on the order parameters are registered in, and every value must
+    be fp16-representable (the product packs GEMM operands in fp16: the fixture is about arithmetic, not weight rounding)."""
+    from oracle.edm_state import seeded_edm_state
+
+    names = [("enc.32x32_block0.conv0.weight", (8, 4, 3, 3)), ("enc.32x32_block0.conv1.weight", (8, 8, 3, 3)), ("enc.32x32_block0.norm0.weight", (8,)),
+             ("enc.32x32_block0.conv0.bias", (8,)), ("map_label.weight", (16, 10)), ("enc.32x32_block0.conv0.resample_filter", (1, 1, 2, 2))]
+    a = seeded_edm_state(names, 7)
+    b = seeded_edm_state(list(reversed(names)), 7)
+    assert set(a) == set(b) and "enc.32x32_block0.conv0.resample_filter" not in a
+    for k in a:
+        assert torch.equal(a[k], b[k]) and torch.equal(a[k], a[k].half().float())
+    assert not torch.equal(a["enc.32x32_block0.conv0.weight"], seeded_edm_state(names, 8)["enc.32x32_block0.conv0.weight"])
+    assert float(a["enc.32x32_block0.conv1.weight"].std()) < float(a["enc.32x32_block0.conv0.weight"].std())  # the reference's zero-init layers stay small
+    assert abs(float(a["enc.32x32_block0.norm0.weight"].mean()) - 1.0) < 0.2
+

@@ -226,6 +226,11 @@ def test_bench_flop_closed_forms_match_the_oracle():
     for name in ("DiT-S/2", "DiT-B/2", "DiT-L/2", "DiT-XL/2", "DiT-B/4", "DiT-L/8"):
         c = dit_ref.DiTCfg.named(name, num_classes=1, label_dropout=0.0)
         assert bench.dit_flops_per_image(c.tokens, c.hidden, c.depth, c.patch * c.patch * c.in_ch) == dit_ref.dit_flops_per_image(c)
+    # config 6: the constant is the hook count the reference module produced for the fixture (oracle/make_golden.py::golden_edm_full)
+    import torch
+
+    rec = torch.load(os.path.join(root, "tests", "golden", "edm_full.pt"), map_location="cpu", weights_only=False)["ffhq_adm"]
+    assert bench.EDM_FFHQ_FLOP_PER_IMAGE == rec["flops_per_image"]
 
 
 # ----------------------------------------------------------------------------- world 8: the shape of the round-end scaling run
