@@ -175,7 +175,7 @@ int lfm_profile_fc1_read(float* host_ms_out, int max_n);
 int lfm_ln_modulate(const float* X, void* A, int M, int D, int tokens, const float* shift, const float* scale, long mod_stride,
                     lfm_stream_t stream);
 
-/* softmax(q k^T / sqrt(hd)) v for hd = 64, T in {64,128,256} (timm Attention as called at models/DiT.py:120).
+/* softmax(q k^T / sqrt(hd)) v for hd = 64, T in {16,64,128,256,1024} (timm Attention as called at models/DiT.py:120; 1024 = four key chunks of 256).
  * Q,K: fp16 [batch*T, D] token-major; Vt: fp16 [batch, heads, hd, T] in the token order lfm_gemm_qkv_f16 writes (16-groups permuted); O: fp16 [batch*T, D]. */
 int lfm_dit_attention(const void* Q, const void* K, const void* Vt, void* O, int batch, int heads, int T, lfm_stream_t stream);
 /* The same with the head size as an argument: head_dim 64 (DiT-S / B / L) or 72 (DiT-XL/{2,4,8}: 1152 / 16, models/DiT.py:354-363);

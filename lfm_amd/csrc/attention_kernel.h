@@ -44,10 +44,15 @@ static __device__ unsigned long long att_wg_trace[ATT_WG_TRACE][4];
 // loop started after block 0 behind one counted vmcnt + barrier per block): correct, 40.8-41.7 us vs 40.1-42.8 us.
 // (Round 4, tried and dropped: the row maxima as inline-asm v_max3_f32 to skip the few canonicalising v_max_f32 x, x that IEEE fmaxf puts in front of MFMA
 // results -- the compiler's hazard recogniser does not see an asm reading MFMA accumulators, and the hd-72 runs stopped being bit-repeatable.)
-template <int T, int JQ, int HD, int MODE = 0>
+// NCH > 1 (round 4: DiT at 1024 tokens, models/DiT.py:179-182 with --image_size 512): the sequence has NCH * T tokens.  A workgroup owns T QUERIES
+// (blockIdx.z = which block of T) and walks the keys in NCH chunks of T through the same LDS image -- the online softmax state carries over; a chunk
+// is re-staged behind a barrier (no cross-chunk prefetch: this shape is off the benchmarked path).
+template <int T, int JQ, int HD, int MODE = 0, int NCH = 1>
 __global__ __launch_bounds__((T / (32 * JQ)) * 64, HD == 64 ? (T / (32 * JQ)) / 2 : 2) void dit_attention_kernel(
     const half_t* __restrict__ Q, const half_t* __restrict__ K, const half_t* __restrict__ Vt, half_t* __restrict__ O, int D, int heads,
     float scale_log2e) {
+  constexpr int TT = T * NCH;  // tokens of the sequence
+  static_assert(NCH == 1 || MODE == 0, "measurement variants are single-chunk");
   static_assert(HD % 8 == 0 && HD >= 32 && HD <= 128, "head_dim: whole 16-byte chunks");
   constexpr int NKB = T / 32;         // 32-key blocks
   constexpr int NW = T / (32 * JQ);   // waves: each owns JQ blocks of 32 queries
@@ -89,8 +94,9 @@ __global__ __launch_bounds__((T / (32 * JQ)) * 64, HD == 64 ? (T / (32 * JQ)) / 
     }
   };
   wg_stamp(0);
-  const half_t* Kg = K + (long)img * T * D + head * HD;
-  const half_t* Vg = Vt + ((long)img * heads + head) * HD * T;
+  const int qblk = NCH > 1 ? (int)blockIdx.z : 0;
+  const half_t* Kg = K + (long)img * TT * D + head * HD;
+  const half_t* Vg = Vt + ((long)img * heads + head) * HD * TT;
   // buffer-addressed LDS-DMA (SGPR resource + 32-bit VGPR byte offset: +13 % LDS-DMA throughput per CU over 64-bit VGPR addresses,
   // tools/ubench/ldsdma_rate.hip -- the load phase is a third of a workgroup's life)
   const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)Kg, 0, -1, 0x00020000);
@@ -105,15 +111,29 @@ __global__ __launch_bounds__((T / (32 * JQ)) * 64, HD == 64 ? (T / (32 * JQ)) / 
   constexpr int VMIN = SLOTS / NTHR;  // V^T DMAs every wave issues
   static_assert(VMIN == 8 || VMIN == 4, "the counted wait below is vmcnt(VMIN)");
   static_assert(SLOTS % NTHR == 0 || (SLOTS % NTHR) % 64 == 0, "a partial pass is made of whole waves");
+  auto stage_k = [&](int chunk) {
 #pragma unroll
-  for (int p = 0; p < NPASS; ++p) {
-    const int s = p * NTHR + tid;
-    if (SLOTS % NTHR == 0 || p + 1 < NPASS || s < SLOTS) {
-      const int row = s / KCH, ch = s - row * KCH;
-      const int c = KSWZ ? (ch ^ ((row >> 1) & 7)) : ch;
-      if (MODE != 2) glds16_buf(rs_k, (unsigned)(row * D + c * 8) * 2u, 0u, Ks + (p * NTHR + wave * 64) * 16);
+    for (int p = 0; p < NPASS; ++p) {
+      const int s = p * NTHR + tid;
+      if (SLOTS % NTHR == 0 || p + 1 < NPASS || s < SLOTS) {
+        const int row = s / KCH, ch = s - row * KCH;
+        const int c = KSWZ ? (ch ^ ((row >> 1) & 7)) : ch;
+        if (MODE != 2) glds16_buf(rs_k, (unsigned)((chunk * T + row) * D + c * 8) * 2u, 0u, Ks + (p * NTHR + wave * 64) * 16);
+      }
     }
-  }
+  };
+  auto stage_v = [&](int chunk) {
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+      const int s = p * NTHR + tid;
+      if (SLOTS % NTHR == 0 || p + 1 < NPASS || s < SLOTS) {
+        constexpr int CPR = T / 8;  // 16-B chunks per V^T row of the staged key chunk
+        const int row = s / CPR, c = (s % CPR) ^ (row & VKEY);
+        if (MODE != 2) glds16_buf(rs_v, (unsigned)(row * TT + chunk * T + c * 8) * 2u, 0u, Vs + (p * NTHR + wave * 64) * 16);
+      }
+    }
+  };
+  stage_k(0);
   const int q0 = wave * 32 * JQ;
   const int hsel = lane >> 5, l31 = lane & 31;
   const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -122,19 +142,11 @@ __global__ __launch_bounds__((T / (32 * JQ)) * 64, HD == 64 ? (T / (32 * JQ)) / 
   for (int jq = 0; jq < JQ; ++jq)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const half_t* qp = Q + ((long)img * T + q0 + jq * 32 + l31) * D + head * HD;
+      const half_t* qp = Q + ((long)img * TT + qblk * T + q0 + jq * 32 + l31) * D + head * HD;
       if (ks * 16 + 16 <= HD) qf[jq][ks] = *(const half8_t*)(qp + ks * 16 + hsel * 8);
       else qf[jq][ks] = hsel ? zero8 : *(const half8_t*)(qp + ks * 16);
     }
-#pragma unroll
-  for (int p = 0; p < NPASS; ++p) {
-    const int s = p * NTHR + tid;
-    if (SLOTS % NTHR == 0 || p + 1 < NPASS || s < SLOTS) {
-      constexpr int CPR = T / 8;  // 16-B chunks per V^T row
-      const int row = s / CPR, c = (s % CPR) ^ (row & VKEY);
-      if (MODE != 2) glds16_buf(rs_v, (unsigned)(row * T + c * 8) * 2u, 0u, Vs + (p * NTHR + wave * 64) * 16);
-    }
-  }
+  stage_v(0);
 
   if constexpr (MODE == 1) {  // everything has landed -> one output row per query, straight from the Q registers
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -143,7 +155,7 @@ __global__ __launch_bounds__((T / (32 * JQ)) * 64, HD == 64 ? (T / (32 * JQ)) / 
     for (int jq = 0; jq < JQ; ++jq)
 #pragma unroll
       for (int ks = 0; ks < HD / 16; ++ks)
-        *(half8_t*)(O + ((long)img * T + q0 + jq * 32 + l31) * D + head * HD + ks * 16 + hsel * 8) = qf[jq][ks];
+        *(half8_t*)(O + ((long)img * TT + qblk * T + q0 + jq * 32 + l31) * D + head * HD + ks * 16 + hsel * 8) = qf[jq][ks];
     return;
   }
   stamp(1);
@@ -191,6 +203,7 @@ __global__ __launch_bounds__((T / (32 * JQ)) * 64, HD == 64 ? (T / (32 * JQ)) / 
   // online softmax update for the queries this lane owns, then O^T[d][q] += sum_key V^T[d][key] P[q][key].
   // VALU diet (the kernel is VALU-issue-bound: ~1.9k VALU per wave vs 128 MFMAs): 3-input max, packed fp32 FMA / ADD on
   // register pairs, one v_permlane32_swap instead of a ds_bpermute round trip for the lane^32 exchange.
+  bool first_chunk = true;
   auto softmax_pv = [&](f32x16 (&S)[JQ], int kb) {
     half8_t P[JQ][2];
 #pragma unroll
@@ -228,7 +241,7 @@ __global__ __launch_bounds__((T / (32 * JQ)) * 64, HD == 64 ? (T / (32 * JQ)) / 
       }
       lrun[jq] += sum2.x + sum2.y;
     }
-    if (kb == 0) {  // V^T was issued after K and Q: only now must it have landed (every wave's share)
+    if (kb == 0 && first_chunk) {  // V^T was issued after K and Q: only now must it have landed (every wave's share)
       stamp(21);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -254,17 +267,31 @@ __global__ __launch_bounds__((T / (32 * JQ)) * 64, HD == 64 ? (T / (32 * JQ)) / 
   // software pipeline over the key blocks: the S MFMAs of block kb+1 are issued BEFORE the softmax VALU of block kb, so
   // the matrix pipe works underneath the VALU-heavy part instead of the wave idling on the MFMA -> max -> exp -> MFMA chain
   f32x16 Sa[JQ], Sb[JQ];
-  qk(Sa, 0);
 #pragma unroll 1
-  for (int kb = 0; kb < NKB; kb += 2) {
-    qk(Sb, kb + 1);
-    stamp(3 + 2 * kb);
-    softmax_pv(Sa, kb);
-    stamp(4 + 2 * kb);
-    if (kb + 2 < NKB) qk(Sa, kb + 2);
-    stamp(5 + 2 * kb);
-    softmax_pv(Sb, kb + 1);
-    stamp(6 + 2 * kb);
+  for (int chunk = 0; chunk < NCH; ++chunk) {
+    if (NCH > 1 && chunk > 0) {  // every wave is done with the previous chunk of keys: stage the next one, wait for all of it
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      stage_k(chunk);
+      stage_v(chunk);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      first_chunk = false;
+    }
+    qk(Sa, 0);
+#pragma unroll 1
+    for (int kb = 0; kb < NKB; kb += 2) {
+      qk(Sb, kb + 1);
+      stamp(3 + 2 * kb);
+      softmax_pv(Sa, kb);
+      stamp(4 + 2 * kb);
+      if (kb + 2 < NKB) qk(Sa, kb + 2);
+      stamp(5 + 2 * kb);
+      softmax_pv(Sb, kb + 1);
+      stamp(6 + 2 * kb);
+    }
   }
   // ---- normalise and store: lane owns query q, d = db*32 + 8g + 4*hsel + r
   if constexpr (HD == 64 && MODE == 0) {
@@ -288,7 +315,7 @@ __global__ __launch_bounds__((T / (32 * JQ)) * 64, HD == 64 ? (T / (32 * JQ)) / 
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: no barrier
-    half_t* obase = O + ((long)img * T + q0) * D + head * HD;
+    half_t* obase = O + ((long)img * TT + qblk * T + q0) * D + head * HD;
 #pragma unroll
     for (int i = 0; i < 4 * JQ; ++i) {
       const int row = i * 8 + (lane >> 3), ch = lane & 7;
@@ -301,7 +328,7 @@ __global__ __launch_bounds__((T / (32 * JQ)) * 64, HD == 64 ? (T / (32 * JQ)) / 
 #pragma unroll
   for (int jq = 0; jq < JQ; ++jq) {
     const float inv = 1.0f / (lrun[jq] + xhalf(lrun[jq]));
-    half_t* orow = O + ((long)img * T + q0 + jq * 32 + l31) * D + head * HD;
+    half_t* orow = O + ((long)img * TT + qblk * T + q0 + jq * 32 + l31) * D + head * HD;
 #pragma unroll
     for (int db = 0; db < NDB; ++db)
 #pragma unroll
@@ -377,7 +404,7 @@ __global__ __launch_bounds__(64) void dit_attention_t16_kernel(const half_t* __r
   }
 }
 
-// Q, K: [batch*T, heads*hd] token-major; Vt: [batch][heads*hd][T]; O: [batch*T, heads*hd].  hd 64 / 72; T in {16, 64, 128, 256}.
+// Q, K: [batch*T, heads*hd] token-major; Vt: [batch][heads*hd][T]; O: [batch*T, heads*hd].  hd 64 / 72; T in {16, 64, 128, 256, 1024}.
 static int attention_launch(const half_t* Q, const half_t* K, const half_t* Vt, half_t* O, int batch, int heads, int hd, int T, hipStream_t st) {
   if (hd != 64 && hd != 72) return LFM_ERR_SHAPE;
   const int D = heads * hd;
@@ -420,6 +447,20 @@ static int attention_launch(const half_t* Q, const half_t* K, const half_t* Vt, 
       set = true;                                                                                                                       \
     }                                                                                                                                   \
     hipLaunchKernelGGL((dit_attention_kernel<TT, JQ, HD>), grid, dim3((TT / (32 * JQ)) * 64), lds, st, Q, K, Vt, O, D, heads, sl2);    \
+  }
+  if (T == 1024) {  // four key chunks of 256 through the LDS, one workgroup per 256 queries
+    static bool set = false;
+    const dim3 grid4(heads, batch, 4);
+    if (hd == 64) {
+      if (!set) (void)hipFuncSetAttribute((const void*)dit_attention_kernel<256, 1, 64, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 64 * 4);
+      hipLaunchKernelGGL((dit_attention_kernel<256, 1, 64, 0, 4>), grid4, dim3(512), (size_t)256 * 64 * 4, st, Q, K, Vt, O, D, heads, sl2);
+    } else {
+      if (!set) (void)hipFuncSetAttribute((const void*)dit_attention_kernel<256, 1, 72, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 72 * 4);
+      hipLaunchKernelGGL((dit_attention_kernel<256, 1, 72, 0, 4>), grid4, dim3(512), (size_t)256 * 72 * 4, st, Q, K, Vt, O, D, heads, sl2);
+    }
+    set = true;
+    LFM_CHECK_LAUNCH();
+    return LFM_OK;
   }
   if (hd == 64) {
     if (T == 64) ATT_CASE(64, 2, 64)

@@ -871,7 +871,7 @@ static int check_shape(const lfm_dit_shape* s) {
   if (hd != 64 && hd != 72) return LFM_ERR_SHAPE;  // S / B / L: 64; XL: 1152 / 16 = 72
   if (s->res % s->patch) return LFM_ERR_SHAPE;
   const int T = (s->res / s->patch) * (s->res / s->patch);
-  if (T != 16 && T != 64 && T != 128 && T != 256) return LFM_ERR_SHAPE;  // attention kernels: LDS-resident K / V^T up to 256 tokens
+  if (T != 16 && T != 64 && T != 128 && T != 256 && T != 1024) return LFM_ERR_SHAPE;  // attention kernels: LDS-resident K / V^T up to 256 tokens; 1024 = four key chunks
   if (s->hidden % 64 || s->hidden > 256 * LN_MAXV || s->mlp_hidden % 64) return LFM_ERR_SHAPE;
   const int kk = s->patch * s->patch * s->in_ch;
   if (kk > FIN_MAXO || (kk > PE_MAXK && (kk % 64))) return LFM_ERR_SHAPE;  // small patches: register kernel; large: GEMM (K % 64 == 0)

@@ -99,8 +99,8 @@ class DiT(nn.Module):
         if hidden_size % num_heads or hidden_size // num_heads not in (64, 72):
             raise NotImplementedError(f"DiT with head_dim {hidden_size / num_heads:g}: the LDS-resident attention kernel is built for head_dim 64 "
                                       "(DiT-S / B / L) and 72 (DiT-XL: 1152 / 16)")
-        if tokens not in (16, 64, 128, 256) or (kk > 16 and kk % 64) or kk > 256 or hidden_size % 64 or hidden_size > 1280:
-            raise NotImplementedError(f"DiT shape not built: {tokens} tokens (need 16 / 64 / 128 / 256), patch inputs {kk} (need <= 16 or a multiple of 64 up "
+        if tokens not in (16, 64, 128, 256, 1024) or (kk > 16 and kk % 64) or kk > 256 or hidden_size % 64 or hidden_size > 1280:
+            raise NotImplementedError(f"DiT shape not built: {tokens} tokens (need 16 / 64 / 128 / 256 / 1024), patch inputs {kk} (need <= 16 or a multiple of 64 up "
                                       f"to 256), hidden {hidden_size} (multiple of 64, <= 1280)")
         self.learn_sigma = learn_sigma
         self.in_channels = in_channels

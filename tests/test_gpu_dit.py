@@ -191,7 +191,8 @@ def test_ln_modulate(dev, D, tokens, shared, n_img):
 
 
 @pytest.mark.parametrize("T,heads,batch,hd", [(256, 16, 3, 64), (256, 2, 1, 64), (64, 6, 2, 64), (128, 4, 2, 64), (256, 16, 17, 64), (256, 16, 64, 64),
-                                              (256, 12, 43, 64), (256, 16, 3, 72), (64, 16, 5, 72), (128, 3, 2, 72), (256, 16, 33, 72), (16, 6, 7, 64), (16, 16, 3, 72)])
+                                              (256, 12, 43, 64), (256, 16, 3, 72), (64, 16, 5, 72), (128, 3, 2, 72), (256, 16, 33, 72), (16, 6, 7, 64), (16, 16, 3, 72),
+                                              (1024, 6, 2, 64), (1024, 16, 5, 64), (1024, 16, 2, 72)])
 def test_attention(dev, T, heads, batch, hd):
     """Up to the benchmark's own shape (64 images x 16 heads x 256 tokens); every (image, head) item is checked on its own.
     head_dim 72 = the DiT-XL family (4.5 MFMA k-slots, 2.25 output row blocks: the padding lanes must contribute exactly nothing)."""
@@ -203,6 +204,8 @@ def test_attention(dev, T, heads, batch, hd):
     k = (torch.randn(batch, heads, T, hd, generator=g) * 1.5).half()
     v = torch.randn(batch, heads, T, hd, generator=g).half()
     k[0, 0, 5] *= 6  # a spiky key row exercises the running-max rescale of the online softmax
+    if T == 1024:
+        k[0, 0, 700] *= 8  # ... and one in a LATER key chunk of the 1024-token kernel (the state carried across chunks must rescale)
     ref = torch.softmax((q.float() @ k.float().transpose(-1, -2)) * hd ** -0.5, -1) @ v.float()
     ref = ref.transpose(1, 2).reshape(batch * T, D)
     Q = q.transpose(1, 2).reshape(batch * T, D).contiguous().to(dev)
@@ -332,6 +335,34 @@ def test_dit_matches_oracle_fullsize(dev, name, batch, kw):
         got = m(t.to(dev), x.to(dev), y.to(dev) if y is not None else None)
         assert float(ref.abs().mean()) > 1e-3
         assert rel_l2(got, ref) < 2e-3, (name, t)
+
+
+@pytest.mark.parametrize("name,batch,kw", [
+    ("DiT-S/2", 3, dict(num_classes=10, label_dropout=0.1)),     # 384 wide: the 128x128 GEMM tiles
+    ("DiT-L/2", 2, dict(num_classes=1, label_dropout=0.0)),      # 1024 wide: the 256x256 tiles and the folded LayerNorm-modulate over 1024-token images
+    ("DiT-XL/2", 1, dict(num_classes=1000, label_dropout=0.1)),  # head_dim 72
+])
+def test_dit_1024_tokens_matches_oracle(dev, name, batch, kw):
+    """64x64 latents (the f8 latent of a 512x512 image, train_flow_latent.py --image_size 512 with models/DiT.py:179-182's patch 2): 1024 tokens per
+    image, past what the attention kernel keeps in the LDS at once -- its four key chunks, the token split of the QKV epilogue (shift 10) and the
+    positional table at grid 32 against the oracle."""
+    from lfm_amd.models import DiT_models
+
+    cfg = dit_ref.DiTCfg.named(name, img_resolution=64, **kw)
+    sd = dit_ref.make_dit_state(cfg, seed=5)
+    m = DiT_models[name](img_resolution=64, in_channels=4, **kw)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).eval()
+    g = torch.Generator().manual_seed(64)
+    x = torch.randn(batch, 4, 64, 64, generator=g)
+    y = torch.randint(0, kw["num_classes"], (batch,), generator=g) if kw["num_classes"] > 1 else None
+    t = torch.linspace(0.3, 0.8, batch)
+    ref = dit_ref.dit_forward(sd, cfg, t, x, y)
+    got = m(t.to(dev), x.to(dev), y.to(dev) if y is not None else None)
+    got2 = m(t.to(dev), x.to(dev), y.to(dev) if y is not None else None)
+    assert float(ref.abs().mean()) > 1e-3
+    assert rel_l2(got, ref) < 2e-3, name
+    assert torch.equal(got, got2)
 
 
 @functools.lru_cache(maxsize=4)

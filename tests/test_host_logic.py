@@ -320,8 +320,9 @@ def test_unbuilt_dit_shapes_are_refused_at_construction():
         DiT(img_resolution=32, hidden_size=1280, depth=2, num_heads=16, num_classes=1, label_dropout=0.0)   # head_dim 80: no attention kernel
     DiT_models["DiT-XL/2"](img_resolution=32, in_channels=4, num_classes=1, label_dropout=0.0)       # head_dim 72: built
     DiT_models["DiT-B/8"](img_resolution=32, in_channels=4, num_classes=1, label_dropout=0.0)        # 16 tokens: built
+    DiT_models["DiT-S/2"](img_resolution=64, in_channels=4, num_classes=1, label_dropout=0.0)        # 1024 tokens: built (four key chunks)
     with pytest.raises(NotImplementedError):
-        DiT_models["DiT-S/2"](img_resolution=64, in_channels=4, num_classes=1, label_dropout=0.0)    # 1024 tokens: K / V^T do not fit the LDS
+        DiT_models["DiT-S/2"](img_resolution=128, in_channels=4, num_classes=1, label_dropout=0.0)   # 4096 tokens: no attention kernel
     DiT_models["DiT-S/4"](img_resolution=32, in_channels=4, num_classes=1, label_dropout=0.0)        # 64 tokens, K = 64: built
     DiT_models["DiT-S/8"](img_resolution=64, in_channels=4, num_classes=1, label_dropout=0.0)        # 64 tokens, K = 256: built
 
