@@ -51,10 +51,13 @@ struct epi_has_finish_slab<Epi, decltype((void)&Epi::finish_slab)> {
 template <class Epi, int UPS>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const half_t* __restrict__ in, const half_t* __restrict__ zeros,
                                                                const half_t* __restrict__ Wt, long ldw, int H, int W, int Cin, int tiles_x,
-                                                               int tiles_per_img, int total_wg, int nb, Epi epi) {
+                                                               int tiles_per_img, int total_wg, int nb, Epi epi, int stag) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
+#ifdef LFM_MEASURE
+  lfm_stagger_start(stag);
+#endif
   // consecutive workgroup ids go round the 8 XCDs: give every XCD a contiguous range of (tile, channel block) pairs, channel block fastest, so
   // that the channel blocks of a tile (same halo) and neighbouring tiles (shared rims) meet in one L2
   int l = blockIdx.x;
@@ -243,7 +246,7 @@ static inline int launch_conv3x3_halo(const half_t* in, const half_t* zeros, con
     attr_set |= 1ull << (devid & 63);
   }
   hipLaunchKernelGGL((conv3x3_halo_kernel<Epi, UPS>), dim3((unsigned)total), dim3(256), CH_LDS_BYTES, st, in, zeros, Wt, 9L * Cin, H, W, Cin, tiles_x,
-                     tiles_per_img, (int)total, nb, epi);
+                     tiles_per_img, (int)total, nb, epi, lfm_stagger_ticks());
   LFM_CHECK_LAUNCH();
   return LFM_OK;
 }

@@ -20,6 +20,8 @@ int lfm_gemm_prefers_v4(int M, int N, int K) {
 static int g_opt_fold_ln = 1;
 static int g_opt_v6 = 0;
 int lfm_gemm_v6_default() { return g_opt_v6; }
+static int g_stagger = 0;
+int lfm_stagger_ticks() { return g_stagger; }
 
 extern "C" int lfm_set_option(int key, int value) {  // key 1 (LFM_OPT_FOLD_LN): adaLN LayerNorm-modulate folded into the GEMM epilogues (default 1)
   if (key == 1) {
@@ -30,6 +32,12 @@ extern "C" int lfm_set_option(int key, int value) {  // key 1 (LFM_OPT_FOLD_LN):
     g_opt_v6 = value != 0;
     return LFM_OK;
   }
+#ifdef LFM_MEASURE
+  if (key == 3) {  // measurement: start offset (s_memtime ticks) of the second resident workgroups of the two-per-CU kernels (gemm256_common.h)
+    g_stagger = value > 0 ? value : 0;
+    return LFM_OK;
+  }
+#endif
   return LFM_ERR_ARG;
 }
 extern "C" int lfm_gemm_select(int which) {  // low 4 bits: kernel choice (0 auto, 1, 4, 5, 6); bits 4+: ablation flags (measurement only)

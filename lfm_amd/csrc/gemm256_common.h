@@ -9,6 +9,18 @@
 
 int lfm_gemm_selected();     // 0 auto, 1 force the 128x128 kernel, 4 the 256x128 one, 5 the 256x256 one (set by lfm_gemm_select)
 int lfm_gemm_debug_flags();  // ablation switches, measurement only
+int lfm_stagger_ticks();  // measurement builds (lfm_set_option key 3): s_memtime ticks by which workgroups 256..511 of a co-resident-pair kernel start late; else 0
+#ifdef LFM_MEASURE
+// Two workgroups share a CU in the 256x128 GEMM and the halo convolution; dispatched together they run in lockstep (both in their main loops, then both in
+// their epilogues).  The experiment: delay the second resident of every CU in the FIRST wave of workgroups (ids 256..511: consecutive ids go round the
+// XCDs and then the CUs, so id + 256 is the partner of id); later workgroups inherit the offset because a slot frees when its predecessor ends.
+__device__ __forceinline__ void lfm_stagger_start(int ticks) {
+  if (ticks > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    while ((long long)(__builtin_amdgcn_s_memtime() - t0) < (long long)ticks) __builtin_amdgcn_s_sleep(16);
+  }
+}
+#endif
 int lfm_gemm_prefers_v4(int M, int N, int K);  // shapes where the 256x128 two-workgroups-per-CU kernel measured faster than the 256x256 one
 
 #define G256_BM 256

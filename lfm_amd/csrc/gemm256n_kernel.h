@@ -38,10 +38,13 @@ struct g256n_ic {
 
 template <class ASrc, class Epi>
 __global__ __launch_bounds__(256, 2) void gemm256n_tn_kernel(ASrc asrc, const half_t* __restrict__ W, long ldw, int M, int N, int K, int tiles_n,
-                                                              Epi epi, long bsA, long bsW, long bsC, int dbg) {
+                                                              Epi epi, long bsA, long bsW, long bsC, int dbg, int stag) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
+#ifdef LFM_MEASURE
+  lfm_stagger_start(stag);
+#endif
 
   int tile_m, tile_n;
   g256_tile_order(blockIdx.x, gridDim.x, tiles_n, dbg | 32, tile_m, tile_n);  // GM = 8: an XCD runs ~64 of these tiles at a time
@@ -195,7 +198,7 @@ static inline int launch_gemm256n_tn(const ASrc& asrc, const half_t* W, long ldw
     attr_set = true;
   }
   hipLaunchKernelGGL((gemm256n_tn_kernel<ASrc, Epi>), dim3(tm * tn, batch), dim3(256), G256N_LDS_BYTES, stream, asrc, W, ldw, M, N, K, tn, epi, bsA,
-                     bsW, bsC, lfm_gemm_debug_flags());
+                     bsW, bsC, lfm_gemm_debug_flags(), lfm_stagger_ticks());
   LFM_CHECK_LAUNCH();
   return LFM_OK;
 }
