@@ -50,8 +50,17 @@ static __device__ unsigned long long att_wg_trace[ATT_WG_TRACE][4];
 template <int T, int JQ, int HD, int MODE = 0, int NCH = 1>
 __global__ __launch_bounds__((T / (32 * JQ)) * 64, HD == 64 ? (T / (32 * JQ)) / 2 : 2) void dit_attention_kernel(
     const half_t* __restrict__ Q, const half_t* __restrict__ K, const half_t* __restrict__ Vt, half_t* __restrict__ O, int D, int heads,
-    float scale_log2e) {
+    float scale_log2e, int stag) {
   constexpr int TT = T * NCH;  // tokens of the sequence
+#ifdef LFM_MEASURE
+  if (stag > 0) {  // measurement (tools/stagger_probe.py): the second residents of the first wave of workgroups start late
+    const int lin = blockIdx.x + blockIdx.y * gridDim.x;
+    if (lin >= 256 && lin < 512) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+      while ((long long)(__builtin_amdgcn_s_memtime() - t0) < (long long)stag) __builtin_amdgcn_s_sleep(16);
+    }
+  }
+#endif
   static_assert(NCH == 1 || MODE == 0, "measurement variants are single-chunk");
   static_assert(HD % 8 == 0 && HD >= 32 && HD <= 128, "head_dim: whole 16-byte chunks");
   constexpr int NKB = T / 32;         // 32-key blocks
@@ -425,9 +434,9 @@ static int attention_launch(const half_t* Q, const half_t* K, const half_t* Vt, 
       (void)hipFuncSetAttribute((const void*)dit_attention_kernel<256, 2, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 64 * 4);
       set = true;
     }
-    if (mode == 3) hipLaunchKernelGGL((dit_attention_kernel<256, 2, 64, 3>), grid, dim3(256), lds, st, Q, K, Vt, O, D, heads, sl2);
-    else if (mode == 1) hipLaunchKernelGGL((dit_attention_kernel<256, 2, 64, 1>), grid, dim3(256), lds, st, Q, K, Vt, O, D, heads, sl2);
-    else hipLaunchKernelGGL((dit_attention_kernel<256, 2, 64, 2>), grid, dim3(256), lds, st, Q, K, Vt, O, D, heads, sl2);
+    if (mode == 3) hipLaunchKernelGGL((dit_attention_kernel<256, 2, 64, 3>), grid, dim3(256), lds, st, Q, K, Vt, O, D, heads, sl2, lfm_stagger_ticks());
+    else if (mode == 1) hipLaunchKernelGGL((dit_attention_kernel<256, 2, 64, 1>), grid, dim3(256), lds, st, Q, K, Vt, O, D, heads, sl2, lfm_stagger_ticks());
+    else hipLaunchKernelGGL((dit_attention_kernel<256, 2, 64, 2>), grid, dim3(256), lds, st, Q, K, Vt, O, D, heads, sl2, lfm_stagger_ticks());
     LFM_CHECK_LAUNCH();
     return LFM_OK;
   }
@@ -446,17 +455,17 @@ static int attention_launch(const half_t* Q, const half_t* K, const half_t* Vt, 
       (void)hipFuncSetAttribute((const void*)dit_attention_kernel<TT, JQ, HD>, hipFuncAttributeMaxDynamicSharedMemorySize, TT * HD * 4); \
       set = true;                                                                                                                       \
     }                                                                                                                                   \
-    hipLaunchKernelGGL((dit_attention_kernel<TT, JQ, HD>), grid, dim3((TT / (32 * JQ)) * 64), lds, st, Q, K, Vt, O, D, heads, sl2);    \
+    hipLaunchKernelGGL((dit_attention_kernel<TT, JQ, HD>), grid, dim3((TT / (32 * JQ)) * 64), lds, st, Q, K, Vt, O, D, heads, sl2, lfm_stagger_ticks()); \
   }
   if (T == 1024) {  // four key chunks of 256 through the LDS, one workgroup per 256 queries
     static bool set = false;
     const dim3 grid4(heads, batch, 4);
     if (hd == 64) {
       if (!set) (void)hipFuncSetAttribute((const void*)dit_attention_kernel<256, 1, 64, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 64 * 4);
-      hipLaunchKernelGGL((dit_attention_kernel<256, 1, 64, 0, 4>), grid4, dim3(512), (size_t)256 * 64 * 4, st, Q, K, Vt, O, D, heads, sl2);
+      hipLaunchKernelGGL((dit_attention_kernel<256, 1, 64, 0, 4>), grid4, dim3(512), (size_t)256 * 64 * 4, st, Q, K, Vt, O, D, heads, sl2, lfm_stagger_ticks());
     } else {
       if (!set) (void)hipFuncSetAttribute((const void*)dit_attention_kernel<256, 1, 72, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 72 * 4);
-      hipLaunchKernelGGL((dit_attention_kernel<256, 1, 72, 0, 4>), grid4, dim3(512), (size_t)256 * 72 * 4, st, Q, K, Vt, O, D, heads, sl2);
+      hipLaunchKernelGGL((dit_attention_kernel<256, 1, 72, 0, 4>), grid4, dim3(512), (size_t)256 * 72 * 4, st, Q, K, Vt, O, D, heads, sl2, lfm_stagger_ticks());
     }
     set = true;
     LFM_CHECK_LAUNCH();
