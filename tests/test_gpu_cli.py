@@ -38,6 +38,17 @@ def test_single_process_driver_euler_and_karras_heun(tmp_path):
     assert sorted(os.listdir(tmp_path / "d"), key=lambda s: int(s.split(".")[0])) == ["0.jpg", "1.jpg", "2.jpg", "3.jpg"]
 
 
+def test_single_process_driver_dit_at_512(tmp_path):
+    """--image_size 512 with a DiT-x/2: 64x64 latents = 1024 tokens per image through the graph-captured Euler solver, decoded at 512x512."""
+    common = [("512" if a == "256" else a) for a in COMMON]
+    out = _run([sys.executable, "-m", "lfm_amd.test_flow_latent", "--model_type", "DiT-S/2", "--num_classes", "1", "--label_dropout", "0.",
+                "--method", "euler", "--step_size", "0.25", "--save_dir", str(tmp_path / "f"), *common])
+    assert "Samples are save at" in out
+    from PIL import Image
+
+    assert Image.open(tmp_path / "f" / os.listdir(tmp_path / "f")[0]).size == (1024, 512)
+
+
 def test_ddp_driver_one_rank_rccl(tmp_path):
     out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                 "--master-port", "29517", "-m", "lfm_amd.test_flow_latent_ddp", "--model_type", "DiT-S/2", "--num_classes", "1",
