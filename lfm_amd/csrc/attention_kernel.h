@@ -426,6 +426,20 @@ static int attention_launch(const half_t* Q, const half_t* K, const half_t* Vt, 
   const bool narrow = T == 256 && !(lfm_gemm_debug_flags() & 256);
   [[maybe_unused]] const int mode = (lfm_gemm_debug_flags() >> 25) & 3;  // flags 33554432 / 67108864 / both: the measurement-only variants MODE 1 / 2 / 3 (hd 64, 256 tokens)
 #ifdef LFM_MEASURE
+  if (mode && hd == 64 && T == 256 && narrow) {  // the shipped shape (8 waves x 32 queries); flag 256 + mode = the wide one below
+    static bool set = false;
+    if (!set) {
+      (void)hipFuncSetAttribute((const void*)dit_attention_kernel<256, 1, 64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 64 * 4);
+      (void)hipFuncSetAttribute((const void*)dit_attention_kernel<256, 1, 64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 64 * 4);
+      (void)hipFuncSetAttribute((const void*)dit_attention_kernel<256, 1, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 64 * 4);
+      set = true;
+    }
+    if (mode == 3) hipLaunchKernelGGL((dit_attention_kernel<256, 1, 64, 3>), grid, dim3(512), lds, st, Q, K, Vt, O, D, heads, sl2, lfm_stagger_ticks());
+    else if (mode == 1) hipLaunchKernelGGL((dit_attention_kernel<256, 1, 64, 1>), grid, dim3(512), lds, st, Q, K, Vt, O, D, heads, sl2, lfm_stagger_ticks());
+    else hipLaunchKernelGGL((dit_attention_kernel<256, 1, 64, 2>), grid, dim3(512), lds, st, Q, K, Vt, O, D, heads, sl2, lfm_stagger_ticks());
+    LFM_CHECK_LAUNCH();
+    return LFM_OK;
+  }
   if (mode && hd == 64 && T == 256) {
     static bool set = false;
     if (!set) {
