@@ -507,7 +507,9 @@ class GraphedFixedGrid:
                 self.step.copy_(saved[1])
             torch.cuda.current_stream(self.dev).wait_stream(side)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread_local: only THIS thread's calls are policed during capture -- a multi-rank run has the RCCL watchdog thread polling
+            # events of the previous batch's image all-gather (side stream), which the default global mode would turn into a capture error
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 fn()
             self.x.copy_(saved[0])
             self.step.copy_(saved[1])
