@@ -54,6 +54,9 @@ def parse():
     p.add_argument("--field-gain", type=float, default=0.0,
                    help="scale of the DiT's output layer (0 = 1, the baseline-comparable field).  Config 3 with --field-gain 100 (CONFIG3_FIELD_GAIN) makes the seeded "
                         "random field stiff enough for dopri5 at 1e-5 to take >= 15 steps (92 NFE) -- the solver-loop stress variant of profiles/r03_config3_*")
+    p.add_argument("--in-flight", type=int, default=1, choices=[1, 2],
+                   help="batches in flight per GPU (config 2): 2 = consecutive steps alternate between two HIP streams with their own scratch (same weights, "
+                        "same per-batch results); the default line keeps one batch in flight, as every earlier round")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--stub", action="store_true", help="(tests) CPU / gloo rehearsal of the launcher + rank logic: a stub step instead of the HIP path")
@@ -419,7 +422,37 @@ def main():
     pipe = GatherPipeline(world, dev)
     gather_ms = []
 
+    lanes = None
+    if a.in_flight > 1:
+        # two batches in flight: consecutive steps go to two HIP streams, each with its own solver buffers / captured graphs / workspaces on the SAME weights
+        if a.config != 2 or world != 1:
+            raise SystemExit("--in-flight 2 is built for config 2 on one GPU")
+        from lfm_amd.solvers import GraphedFixedGrid, concurrency_twin, torchdiffeq_euler_grid
+
+        tm, tv = concurrency_twin(w["model"]), concurrency_twin(vae)
+        sv = GraphedFixedGrid(tm, B)
+        sv.set_grid(*torchdiffeq_euler_grid(1.0 / a.nfe))
+        lanes = [(solve, vae, x_dev, torch.cuda.Stream(dev)), (sv.run, tv, torch.empty_like(x_dev), torch.cuda.Stream(dev))]
+        first = []
+        for sol, va, xd, st in lanes:  # capture each lane's graphs and size its workspaces outside the counted steps
+            st.wait_stream(torch.cuda.current_stream(dev))  # weights, packed operands and the per-grid tables were produced on the launching stream
+            with torch.cuda.stream(st):
+                xd.copy_(w["x_host"], non_blocking=True)
+                first.append(images_to_uint8(va.decode(sol(xd) / 0.18215).sample))
+        torch.cuda.synchronize()
+        # same latents through both lanes: identical images up to the known open issue of co-scheduled evaluations (profiles/r04_two_batches_in_flight.txt:
+        # about 1 in 15-40 co-scheduled folded-LayerNorm evaluations differs from its solo result at rounding level, |d latent| < 1e-4) -- at most one u8 step
+        dl = (first[0].int() - first[1].int()).abs()
+        assert int(dl.max()) <= 1 and float((dl > 0).float().mean()) < 0.02, "the two lanes must produce the same images for the same latents"
+    nstep = [0]
+
     def step():
+        if lanes is not None:
+            sol, va, xd, st = lanes[nstep[0] % len(lanes)]
+            nstep[0] += 1
+            with torch.cuda.stream(st):
+                xd.copy_(w["x_host"], non_blocking=True)
+                return images_to_uint8(va.decode(sol(xd) / 0.18215).sample)
         x_dev.copy_(w["x_host"], non_blocking=True)  # the batch's latents cross PCIe inside the timed region (1 MiB at batch 64)
         lat = solve(x_dev)
         img = vae.decode(lat / 0.18215).sample
@@ -464,6 +497,9 @@ def main():
     cfg = {"workload": w["workload"] + (" + RCCL all-gather of images (side stream)" if world > 1 else ""), "baseline_config": a.config,
            "per_gpu_batch": B, "global_batch": B * world, "sharding": f"dp{world}", "h2d_of_latents": "inside the timed step"}
     cfg.update({k: v for k, v in w["extra"].items() if k in ("nfe", "field_gain")})
+    if lanes is not None:
+        cfg["batches_in_flight"] = len(lanes)
+        cfg["workload"] += f"; {len(lanes)} batches in flight on {len(lanes)} HIP streams (same weights, own scratch)"
     if "solver_stats" in w["extra"]:
         cfg["dopri5"] = dict(w["extra"]["solver_stats"])
     res = {
