@@ -373,3 +373,20 @@ def test_seeded_edm_state_is_order_independent_and_fp16_exact():
     assert float(a["enc.32x32_block0.conv1.weight"].std()) < float(a["enc.32x32_block0.conv0.weight"].std())  # the reference's zero-init layers stay small
     assert abs(float(a["enc.32x32_block0.norm0.weight"].mean()) - 1.0) < 0.2
 
+
+
+def test_concurrency_twin_shares_weights_not_scratch():
+    """solvers.concurrency_twin: a second handle for a second HIP stream -- the same parameter tensors, its own workspace and its own solver cache."""
+    from lfm_amd.models import DiT_models
+    from lfm_amd.solvers import concurrency_twin
+
+    m = DiT_models["DiT-S/2"](img_resolution=32, in_channels=4, num_classes=1, label_dropout=0.0).eval()
+    m.__dict__["_fused_solvers"] = {"k": object()}
+    m._ws = (4, torch.zeros(8))
+    t = concurrency_twin(m)
+    assert t is not m and type(t) is type(m)
+    assert all(a is b for a, b in zip(m.parameters(), t.parameters()))  # shared weights
+    assert t._ws is None and m._ws is not None  # own scratch
+    assert "_fused_solvers" not in t.__dict__ and "_fused_solvers" in m.__dict__  # own captured solvers
+    t._gen += 5
+    assert m._gen != t._gen  # plain attributes are per handle
