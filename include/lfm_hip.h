@@ -167,6 +167,9 @@ int lfm_attention_trace_read(unsigned long long* host_out, int n);
 /* Measurement only (LFM_MEASURE builds, same trace build): per attention workgroup {HW_ID | XCC_ID << 32, start, loads landed, end} -- which CU it ran on
  * and when; host_out receives 4 x n_wg values (n_wg <= 2048). */
 int lfm_attention_wg_trace_read(unsigned long long* host_out, int n_wg);
+/* Measurement only: per-kernel checksums of the evaluations that run on `workspace` (csrc/dit.hip: slot [block][8]); tools/concurrency_ws_diff.py. */
+int lfm_dit_chk_arm(const void* workspace);
+int lfm_dit_chk_read(unsigned long long* host_out, int n);
 #endif /* LFM_MEASURE */
 int lfm_profile_fc1_read(float* host_ms_out, int max_n);
 

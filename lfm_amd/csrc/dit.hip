@@ -1074,6 +1074,32 @@ extern "C" int lfm_attention_wg_trace_read(unsigned long long* host_out, int n_w
   if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(att_wg_trace), sizeof(unsigned long long) * 4 * n_wg, 0, hipMemcpyDeviceToHost) != hipSuccess) return LFM_ERR_LAUNCH;
   return LFM_OK;
 }
+// Per-kernel checksums of one armed evaluation (tools/concurrency_ws_diff.py): after every kernel of the folded block loop the 64-bit wrap-around sum of
+// its output buffer's 32-bit words (integer adds: order-independent, so equal data <=> equal sum whatever the reduction order) goes into a slot
+// [block][8]: 0 Q|K|V^T after qkv, 1 O after attention, 2 X / 3 A' (A2) / 4 row partials after proj, 5 H after fc1, 6 X / 7 A' (A) after fc2.
+#define DIT_CHK_SLOTS (64 * 8)
+static unsigned long long* g_chk = nullptr;
+static const void* g_chk_ws = nullptr;
+__global__ __launch_bounds__(256) void chk_kernel(const unsigned* __restrict__ p, long nwords, unsigned long long* __restrict__ out) {
+  unsigned long long s = 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (long)gridDim.x * 256) s += p[i];
+  atomicAdd(out, s);
+}
+static void dit_chk(const void* buf, size_t bytes, int block, int slot, hipStream_t st) {
+  if (!g_chk || block >= 64) return;
+  hipLaunchKernelGGL(chk_kernel, dim3(1024), dim3(256), 0, st, (const unsigned*)buf, (long)(bytes / 4), g_chk + block * 8 + slot);
+}
+extern "C" int lfm_dit_chk_arm(const void* workspace) {  // the evaluations that run on THIS workspace record their checksums (nullptr: off)
+  if (!g_chk && hipMalloc((void**)&g_chk, DIT_CHK_SLOTS * 8) != hipSuccess) return LFM_ERR_LAUNCH;
+  g_chk_ws = workspace;
+  return LFM_OK;
+}
+extern "C" int lfm_dit_chk_read(unsigned long long* host_out, int n) {
+  if (!host_out || n <= 0 || n > DIT_CHK_SLOTS || !g_chk) return LFM_ERR_ARG;
+  if (hipDeviceSynchronize() != hipSuccess) return LFM_ERR_LAUNCH;
+  if (hipMemcpy(host_out, g_chk, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) return LFM_ERR_LAUNCH;
+  return LFM_OK;
+}
 #endif  // LFM_MEASURE
 
 // ------------------------------------------------------------------ conditioning (everything the forward derives from t and y alone)
@@ -1250,6 +1276,14 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
   auto launch_fold = [&](const ASrcRowMajor& a, const half_t* Wp, long ldw_, int M_, int N_, int K_, const auto& e) {
     return w6 ? launch_gemm256w_tn(a, Wp, ldw_, M_, N_, K_, e, st) : launch_gemm256h_tn(a, Wp, ldw_, M_, N_, K_, e, st);
   };
+#ifdef LFM_MEASURE
+  const bool chk = g_chk && workspace == g_chk_ws;
+  if (chk) (void)hipMemsetAsync(g_chk, 0, DIT_CHK_SLOTS * 8, st);
+#define DIT_CHK(buf, bytes, slot) \
+  if (chk) dit_chk(buf, bytes, i, slot, st)
+#else
+#define DIT_CHK(buf, bytes, slot)
+#endif
   if (fold) {
     for (int i = 0; i < s->depth; ++i) {
       const float* mod = ws.mod + (long)i * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
@@ -1258,18 +1292,24 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
       const EpiQKVMod e_qkv{Qb, Kb, Vb, uq, uq + (long)rows * 3 * D, uvs_q, D, D / s->heads, T, EpiQKV::log2_or_neg(T), rowstat_src(), nullptr, 0};
       rc = launch_fold(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->qkv_w + (size_t)i * 3 * D * D, D, M, 3 * D, D, e_qkv);
       if (rc) return rc;
+      DIT_CHK(ws.QKVH, (size_t)3 * M * D * 2, 0);
       rc = attention_launch(Qb, Kb, Vb, ws.A, B, s->heads, D / s->heads, T, st);
       if (rc) return rc;
+      DIT_CHK(ws.A, (size_t)M * D * 2, 1);
       // proj: X += gate_msa * (.), A' for fc1 with scale_mlp, partials; c = the row means the qkv GEMM just published
       const EpiGateResidMod e_proj{ws.X, D, w->proj_b + (size_t)i * D, mod + 2 * D, mstride, T, ws.A2, mod + 4 * D, mstride, ws.cen[cen_cur], ws.ln_part, tiles_p};
       rc = launch_fold(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D, e_proj);
       if (rc) return rc;
+      DIT_CHK(ws.X, (size_t)M * D * 4, 2);
+      DIT_CHK(ws.A2, (size_t)M * D * 2, 3);
+      DIT_CHK(ws.ln_part, (size_t)M * tiles_p * 8, 4);
       const bool prof = g_prof_on && g_prof_count < LFM_PROF_MAX;
       if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_count], st);
       const EpiModGeluF16 e_fc1{ws.QKVH, H, uf, uf + (long)rows * H, uvs_f, T, rowstat_src(), nullptr, 0};
       rc = launch_fold(ASrcRowMajor{ws.A2, D, M, 0}, (const half_t*)w->fc1_w + (size_t)i * H * D, D, M, H, D, e_fc1);
       if (rc) return rc;
       if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_count++ + 1], st);
+      DIT_CHK(ws.QKVH, (size_t)M * H * 2, 5);
       if (i + 1 < s->depth) {  // fc2 writes the NEXT block's A' (its scale_msa)
         const EpiGateResidMod e_fc2{ws.X, D, w->fc2_b + (size_t)i * D, mod + 5 * D, mstride, T, ws.A, mod + 7 * D, mstride, ws.cen[cen_cur], ws.ln_part, tiles_p};
         rc = launch_fold(ASrcRowMajor{ws.QKVH, H, M, 0}, (const half_t*)w->fc2_w + (size_t)i * D * H, H, M, D, H, e_fc2);
@@ -1278,8 +1318,11 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
         rc = launch_fold(ASrcRowMajor{ws.QKVH, H, M, 0}, (const half_t*)w->fc2_w + (size_t)i * D * H, H, M, D, H, e_fc2);
       }
       if (rc) return rc;
+      DIT_CHK(ws.X, (size_t)M * D * 4, 6);
+      DIT_CHK(ws.A, (size_t)M * D * 2, 7);
     }
   }
+#undef DIT_CHK
   bool a_ready = false;  // latency mode: the previous split-K finish already wrote this LayerNorm's output
   for (int i = 0; i < (fold ? 0 : s->depth); ++i) {
     const float* mod = ws.mod + (long)i * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp

@@ -37,6 +37,23 @@ print("mode:", mode or "shipped", flush=True)
 out_ref = m(t, x).clone(); ws = m._ws[1]
 assert off <= ws.numel(), (off, ws.numel())
 torch.cuda.synchronize(); ws_ref = ws.clone()
+# (M) LFM_MEASURE builds: per-kernel checksums of m's evaluations (csrc/dit.hip lfm_dit_chk_*): WHERE does a co-scheduled run leave the solo one first?
+import ctypes as C
+L = hip.lib()
+chk_ref = None
+SLOT = ["Q|K|V^T after qkv", "O after attention", "X after proj", "A' (A2) after proj", "row partials after proj", "H after fc1", "X after fc2", "A' (A) after fc2"]
+def read_chk():
+    buf = (C.c_ulonglong * (depth * 8))()
+    L.lfm_dit_chk_read.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+    hip.check(L.lfm_dit_chk_read(buf, depth * 8), "lfm_dit_chk_read")
+    return list(buf)
+if hasattr(L, "lfm_dit_chk_arm"):
+    L.lfm_dit_chk_arm.argtypes = [C.c_void_p]
+    hip.check(L.lfm_dit_chk_arm(ws.data_ptr()), "lfm_dit_chk_arm")
+    m(t, x); chk_ref = read_chk(); m(t, x)
+    assert chk_ref == read_chk(), "solo checksums must repeat"
+    out_ref = m(t, x).clone(); torch.cuda.synchronize(); ws_ref = ws.clone()
+    print("per-kernel checksums armed (the checksum launches sit between the block's kernels: timing is not the shipped one)", flush=True)
 out2 = m(t, x); torch.cuda.synchronize()
 solo_same = [torch.equal(ws[o:o + n], ws_ref[o:o + n]) for _, o, n in regions]
 print("solo repeat: every region identical:", all(solo_same), [r[0] for r, s in zip(regions, solo_same) if not s], flush=True)
@@ -53,10 +70,26 @@ for rep in range(reps):
     if bad or not torch.equal(o, out_ref):
         found += 1
         print(f"rep {rep}: output equal {torch.equal(o, out_ref)}; differing regions (bytes): {bad}", flush=True)
+        if chk_ref is not None:
+            cur_chk = read_chk()
+            firsts = [i for i in range(depth * 8) if cur_chk[i] != chk_ref[i]]
+            if firsts:
+                print("    first differing checksums: " + "; ".join(f"block {i // 8}: {SLOT[i % 8]}" for i in firsts[:6]) + f"  ({len(firsts)} slots differ)", flush=True)
+            else:
+                print("    all per-kernel checksums equal (the difference is outside the block loop)", flush=True)
         reg = {n_: (o_, b_) for n_, o_, b_ in regions}
         def f32(name, ref=False):
             o_, b_ = reg[name]
             return (ws_ref if ref else ws)[o_:o_ + b_].view(torch.float32)
+        o_, b_ = reg["QKVH (fc1 activation H)"]
+        hh, hr = ws[o_:o_ + M * H * 2].view(torch.int16).view(M, H), ws_ref[o_:o_ + M * H * 2].view(torch.int16).view(M, H)
+        nz = (hh != hr).nonzero()
+        if 0 < nz.shape[0] <= 4000:  # few elements: the LAST block's fc1 output itself is where the runs part -- where are they?
+            rows, cols = nz[:, 0], nz[:, 1]
+            print(f"    H: {nz.shape[0]} elements differ; rows mod 256 {sorted(set((rows % 256).tolist()))[:40]}; cols mod 256 {sorted(set((cols % 256).tolist()))[:40]}; "
+                  f"col tiles {sorted(set((cols // 256).tolist()))}; first pairs {nz[:12].tolist()}", flush=True)
+            d16 = (hh.view(torch.float16)[rows, cols].float() - hr.view(torch.float16)[rows, cols].float()).abs()
+            print(f"       max |dH| {float(d16.max()):.3e} at |H| {float(hr.view(torch.float16)[rows, cols].float().abs().max()):.3e}", flush=True)
         for nm in ("cen0", "cen1"):
             a_, r_ = f32(nm), f32(nm, True)
             d_ = (a_ - r_).abs(); idx = (d_ > 0).nonzero().flatten()
@@ -67,5 +100,5 @@ for rep in range(reps):
         dx = (a_ - r_).abs()
         print(f"    X: images {imgs}; max |dX| {float(dx.max()):.3e} (|X| max {float(r_.abs().max()):.1f}); per affected image fraction of elements differing "
               f"{[round(float((a_[i] != r_[i]).float().mean()), 2) for i in imgs[:8]]}", flush=True)
-        if found >= 3: break
+        if found >= 8: break
 print(f"{found} of {rep + 1} co-scheduled runs differ", flush=True)
