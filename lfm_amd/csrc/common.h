@@ -85,11 +85,34 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2_t gelu_tanh_pk(f32x2_t x) {
   const f32x2_t c0 = {2.3022081985f, 2.3022081985f}, c1 = {0.1029432397f, 0.1029432397f}, one = {1.0f, 1.0f};
-  const f32x2_t z = x * __builtin_elementwise_fma(x * x, c1, c0);
+  f32x2_t z = x * __builtin_elementwise_fma(x * x, c1, c0);
+#ifdef LFM_EXP_NOP_TRANS  // (experiment build) idle cycles between the packed chain and the transcendental that reads its result, and again before v_rcp
+  asm volatile("s_nop 7" : "+v"(z));
+#endif
   const f32x2_t e = {__builtin_amdgcn_exp2f(-z.x), __builtin_amdgcn_exp2f(-z.y)};
-  const f32x2_t d = one + e;
+  f32x2_t d = one + e;
+#ifdef LFM_EXP_NOP_TRANS
+  asm volatile("s_nop 7" : "+v"(d));
+#endif
   const f32x2_t r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
   return x * r;
+}
+
+// a * b + c as ONE plain v_fma_f32 per element (inline asm: the compiler cannot re-pack it).  The row-affine epilogues of the folded LayerNorm path
+// (gemm_kernel.h: a[m] * acc + (b[m] * u[n] + v[n]) with (a, b) in a register pair) are written with it INSTEAD of the vector expression, for which the
+// compiler selects v_pk_fma_f32 with op_sel:[0,1,0] -- the LOW half of the packed operation takes src1 from the HIGH register of the pair.  On MI355X
+// that form sporadically evaluates with the operand read as 0.0 in lanes 48-63 when a foreign wave shares the SIMD (two HIP streams in flight): the
+// product term b * u vanished from ~500 elements per affected fc1 launch, 1-2 fp16 ulp in H (profiles/r05_cosched_root_cause.txt:
+// operand dump of the epilogue solo vs co-scheduled; 6 of 11-19 co-scheduled evaluations differ with the packed form in four builds, 0 of 24 and
+// 0 of the stress suite with this one).  tests/test_host_logic.py::test_no_packed_fp32_op_sel keeps every op_sel'd packed-fp32 form out of the library.
+__device__ __forceinline__ float fma_v(float a, float b, float c) {
+  float r;
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// a * acc + (b * u + v), four columns of one row
+__device__ __forceinline__ f32x4 row_affine4(float a, float b, f32x4 acc, f32x4 u, f32x4 v) {
+  return (f32x4){fma_v(a, acc.x, fma_v(b, u.x, v.x)), fma_v(a, acc.y, fma_v(b, u.y, v.y)), fma_v(a, acc.z, fma_v(b, u.z, v.z)), fma_v(a, acc.w, fma_v(b, u.w, v.w))};
 }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1100,6 +1100,18 @@ extern "C" int lfm_dit_chk_read(unsigned long long* host_out, int n) {
   if (hipMemcpy(host_out, g_chk, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) return LFM_ERR_LAUNCH;
   return LFM_OK;
 }
+#ifdef LFM_EXP_DUMP
+// (experiment build, tools/cosched_dump.py) the folded fc1 epilogue of every block of the evaluations on THIS workspace dumps the operands of its affine
+static float* g_dbg = nullptr;
+static long g_dbg_stride = 0;
+static const void* g_dbg_ws = nullptr;
+extern "C" int lfm_dit_dbg_arm(const void* workspace, float* dump, long stride_floats) {
+  g_dbg = dump;
+  g_dbg_stride = stride_floats;
+  g_dbg_ws = workspace;
+  return LFM_OK;
+}
+#endif
 #endif  // LFM_MEASURE
 
 // ------------------------------------------------------------------ conditioning (everything the forward derives from t and y alone)
@@ -1305,7 +1317,12 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
       DIT_CHK(ws.ln_part, (size_t)M * tiles_p * 8, 4);
       const bool prof = g_prof_on && g_prof_count < LFM_PROF_MAX;
       if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_count], st);
+#if defined(LFM_MEASURE) && defined(LFM_EXP_DUMP)
+      const EpiModGeluF16 e_fc1{ws.QKVH, H, uf, uf + (long)rows * H, uvs_f, T, rowstat_src(), nullptr, 0,
+                                (g_dbg && workspace == g_dbg_ws) ? g_dbg + (long)i * g_dbg_stride : (float*)nullptr};
+#else
       const EpiModGeluF16 e_fc1{ws.QKVH, H, uf, uf + (long)rows * H, uvs_f, T, rowstat_src(), nullptr, 0};
+#endif
       rc = launch_fold(ASrcRowMajor{ws.A2, D, M, 0}, (const half_t*)w->fc1_w + (size_t)i * H * D, D, M, H, D, e_fc1);
       if (rc) return rc;
       if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_count++ + 1], st);

@@ -82,6 +82,10 @@ __device__ __forceinline__ void g256h_epilogue_rows(f32x4_t (&acc)[8][4], char* 
             f32x2 ra[4];
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) ra[ps] = epi.row_aux(mb + ps * 8);
+#ifdef LFM_EXP_WAIT_ALL  // (experiment build) every LDS read of the pass has landed, plus 16 idle cycles, before the first VALU instruction that consumes one
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) epi.store8r(mb + ps * 8, n, lo[ps], hi[ps], cl, ch, ra[ps]);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

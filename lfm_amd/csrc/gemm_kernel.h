@@ -278,7 +278,7 @@ struct EpiModF16 {
   }
   __device__ __forceinline__ f32x4 affine(int m, f32x4 acc, const Aux& c) const {
     const f32x2 ab = *(const f32x2*)(rs + 2 * (m - m0));
-    return ab.x * acc + (ab.y * c.u + c.v);
+    return row_affine4(ab.x, ab.y, acc, c.u, c.v);  // plain FMAs, not the packed form: common.h fma_v
   }
   __device__ __forceinline__ void store(int m, int n, f32x4 acc, const Aux& c) const {
     const f32x4 o = affine(m, acc, c);
@@ -288,8 +288,8 @@ struct EpiModF16 {
   __device__ __forceinline__ bool wide_ok() const { return (ldc & 7) == 0 && ((uintptr_t)C & 15) == 0; }
   __device__ __forceinline__ f32x2 row_aux(int m) const { return *(const f32x2*)(rs + 2 * (m - m0)); }
   __device__ __forceinline__ void store8r(int m, int n, f32x4 lo, f32x4 hi, const Aux& cl, const Aux& ch, f32x2 ab) const {
-    lo = ab.x * lo + (ab.y * cl.u + cl.v);
-    hi = ab.x * hi + (ab.y * ch.u + ch.v);
+    lo = row_affine4(ab.x, ab.y, lo, cl.u, cl.v);
+    hi = row_affine4(ab.x, ab.y, hi, ch.u, ch.v);
     half8_t h = {(half_t)lo.x, (half_t)lo.y, (half_t)lo.z, (half_t)lo.w, (half_t)hi.x, (half_t)hi.y, (half_t)hi.z, (half_t)hi.w};
     *(half8_t*)(C + (long)m * ldc + n) = h;
   }
@@ -323,7 +323,7 @@ struct EpiModGeluF16 {
   }
   __device__ __forceinline__ void store(int m, int n, f32x4 acc, const Aux& c) const {
     const f32x2 ab = *(const f32x2*)(rs + 2 * (m - m0));
-    const f32x4 x = ab.x * acc + (ab.y * c.u + c.v);
+    const f32x4 x = row_affine4(ab.x, ab.y, acc, c.u, c.v);
     const f32x2_t p = gelu_tanh_pk((f32x2_t){x.x, x.y}), q = gelu_tanh_pk((f32x2_t){x.z, x.w});
     half4_t h = {(half_t)p.x, (half_t)p.y, (half_t)q.x, (half_t)q.y};
     *(half4_t*)(C + (long)m * ldc + n) = h;
@@ -334,13 +334,36 @@ struct EpiModGeluF16 {
     store8r(m, n, lo, hi, cl, ch, row_aux(m));
   }
   __device__ __forceinline__ void store8r(int m, int n, f32x4 lo, f32x4 hi, const Aux& cl, const Aux& ch, f32x2 ab) const {
+#if defined(LFM_MEASURE) && defined(LFM_EXP_DUMP)
+    // (experiment build, tools/cosched_dump.py) every operand of the affine as THIS lane saw it, 16 floats per (row, 8-column group):
+    // acc lo | acc hi | t = b u + v for columns 0, 2, 4, 6 | (a, b) | x for columns 0, 2
+    const f32x4 acc_lo = lo, acc_hi = hi;
+    const f32x4 tl = ab.y * cl.u + cl.v, th = ab.y * ch.u + ch.v;
+    lo = ab.x * lo + tl;
+    hi = ab.x * hi + th;
+    if (dbg && (m & 7) >= 6) {  // lanes 48-63 of the hand-over
+      f32x4* d = (f32x4*)(dbg + ((long)m * (ldc / 8) + n / 8) * 16);
+      d[0] = acc_lo;
+      d[1] = acc_hi;
+      d[2] = (f32x4){tl.x, tl.z, th.x, th.z};
+      d[3] = (f32x4){ab.x, ab.y, lo.x, lo.z};
+    }
+#elif defined(LFM_EXP_AFFINE_PACKED)
+    // (experiment build) the vector expression: v_pk_fma_f32 with op_sel -- the form that leaves the solo result under co-scheduling
     lo = ab.x * lo + (ab.y * cl.u + cl.v);
     hi = ab.x * hi + (ab.y * ch.u + ch.v);
+#else
+    lo = row_affine4(ab.x, ab.y, lo, cl.u, cl.v);
+    hi = row_affine4(ab.x, ab.y, hi, ch.u, ch.v);
+#endif
     const f32x2_t a = gelu_tanh_pk((f32x2_t){lo.x, lo.y}), c = gelu_tanh_pk((f32x2_t){lo.z, lo.w});
     const f32x2_t e = gelu_tanh_pk((f32x2_t){hi.x, hi.y}), g = gelu_tanh_pk((f32x2_t){hi.z, hi.w});
     half8_t h = {(half_t)a.x, (half_t)a.y, (half_t)c.x, (half_t)c.y, (half_t)e.x, (half_t)e.y, (half_t)g.x, (half_t)g.y};
     *(half8_t*)(C + (long)m * ldc + n) = h;
   }
+#if defined(LFM_MEASURE) && defined(LFM_EXP_DUMP)
+  float* dbg;  // [M][N / 8][16] or null
+#endif
 };
 template <class Epi, class = void>
 struct epi_has_rowstat {
@@ -476,7 +499,7 @@ struct EpiQKVMod {
   }
   __device__ __forceinline__ void store(int m, int n, f32x4 acc, const Aux& c) const {  // generic path (edge tiles of odd shapes only)
     const f32x2 ab = *(const f32x2*)(rs + 2 * (m - m0));
-    const f32x4 o = ab.x * acc + (ab.y * c.u + c.v);
+    const f32x4 o = row_affine4(ab.x, ab.y, acc, c.u, c.v);
     if (n < 2 * D) {
       half_t* dst = (n < D) ? (Q + (long)m * D + n) : (K + (long)m * D + (n - D));
       half4_t h = {(half_t)o.x, (half_t)o.y, (half_t)o.z, (half_t)o.w};
@@ -499,18 +522,18 @@ struct EpiQKVMod {
   }
   __device__ __forceinline__ void store_t(int n, int m, f32x4 acc, f32x2 c) const {  // four consecutive tokens m .. m + 3 of column n
     const f32x4 r0 = *(const f32x4*)(rs + 2 * (m - m0)), r1 = *(const f32x4*)(rs + 2 * (m - m0) + 4);  // (a, b) x 4 rows
-    half4_t h = {(half_t)(r0.x * acc.x + (r0.y * c.x + c.y)), (half_t)(r0.z * acc.y + (r0.w * c.x + c.y)),
-                 (half_t)(r1.x * acc.z + (r1.y * c.x + c.y)), (half_t)(r1.z * acc.w + (r1.w * c.x + c.y))};
+    half4_t h = {(half_t)fma_v(r0.x, acc.x, fma_v(r0.y, c.x, c.y)), (half_t)fma_v(r0.z, acc.y, fma_v(r0.w, c.x, c.y)),
+                 (half_t)fma_v(r1.x, acc.z, fma_v(r1.y, c.x, c.y)), (half_t)fma_v(r1.z, acc.w, fma_v(r1.w, c.x, c.y))};
     *(half4_t*)vt_ptr(n, m) = h;
   }
   __device__ __forceinline__ bool wide_t_ok() const { return (tokens & 15) == 0 && ((uintptr_t)Vt & 15) == 0; }
   __device__ __forceinline__ void store_t8(int n, int m, f32x4 lo, f32x4 hi, f32x2 c) const {  // lo = tokens m .. m + 3, hi = tokens m + 8 .. m + 11
     const float* r = rs + 2 * (m - m0);
     const f32x4 r0 = *(const f32x4*)r, r1 = *(const f32x4*)(r + 4), r2 = *(const f32x4*)(r + 16), r3 = *(const f32x4*)(r + 20);
-    half8_t h = {(half_t)(r0.x * lo.x + (r0.y * c.x + c.y)), (half_t)(r0.z * lo.y + (r0.w * c.x + c.y)),
-                 (half_t)(r1.x * lo.z + (r1.y * c.x + c.y)), (half_t)(r1.z * lo.w + (r1.w * c.x + c.y)),
-                 (half_t)(r2.x * hi.x + (r2.y * c.x + c.y)), (half_t)(r2.z * hi.y + (r2.w * c.x + c.y)),
-                 (half_t)(r3.x * hi.z + (r3.y * c.x + c.y)), (half_t)(r3.z * hi.w + (r3.w * c.x + c.y))};
+    half8_t h = {(half_t)fma_v(r0.x, lo.x, fma_v(r0.y, c.x, c.y)), (half_t)fma_v(r0.z, lo.y, fma_v(r0.w, c.x, c.y)),
+                 (half_t)fma_v(r1.x, lo.z, fma_v(r1.y, c.x, c.y)), (half_t)fma_v(r1.z, lo.w, fma_v(r1.w, c.x, c.y)),
+                 (half_t)fma_v(r2.x, hi.x, fma_v(r2.y, c.x, c.y)), (half_t)fma_v(r2.z, hi.y, fma_v(r2.w, c.x, c.y)),
+                 (half_t)fma_v(r3.x, hi.z, fma_v(r3.y, c.x, c.y)), (half_t)fma_v(r3.z, hi.w, fma_v(r3.w, c.x, c.y))};
     *(half8_t*)vt_ptr(n, m) = h;
   }
 };

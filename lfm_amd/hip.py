@@ -39,7 +39,14 @@ def lib():
         return _lib
     from . import _build
 
-    if os.path.exists(_build.HIPCC) or not os.path.exists(LIB_PATH):
+    override = os.environ.get("LFM_HIP_LIBRARY")  # measurement A/B only (tools/): a prebuilt experiment build of the SAME ABI instead of the in-tree one
+    if override:
+        if not os.path.exists(override):
+            raise LfmHipError(f"LFM_HIP_LIBRARY={override} does not exist")
+        path = override
+    else:
+        path = LIB_PATH
+    if not override and (os.path.exists(_build.HIPCC) or not os.path.exists(LIB_PATH)):
         try:
             _build.build()
         except Exception as e:  # noqa
@@ -47,9 +54,9 @@ def lib():
                 raise LfmHipError(f"liblfm_hip.so is missing and could not be built: {e}") from e
             raise LfmHipError(f"liblfm_hip.so is stale and could not be rebuilt: {e}") from e
     try:
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
     except OSError as e:
-        raise LfmHipError(f"cannot load {LIB_PATH}: {e}") from e
+        raise LfmHipError(f"cannot load {path}: {e}") from e
     L.lfm_strerror.restype = C.c_char_p
     L.lfm_strerror.argtypes = [C.c_int]
     L.lfm_abi_version.restype = C.c_int
