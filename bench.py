@@ -35,11 +35,22 @@ MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense fp16/bf16 (MI355X_MICROARCH.md)
 EDM_FFHQ_FLOP_PER_IMAGE = 73.053765632e9  # one DhariwalUNet evaluation at the ffhq_adm size: hook-counted on the reference module (tests/golden/edm_full.pt, oracle/make_golden.py::golden_edm_full)
 CONFIG3_FIELD_GAIN = 100.0  # output-layer scale of config 3's synthetic field (see --field-gain)
 
-# L2-miss traffic of the dominant GEMM of config 2 (fc1: M 16384 x N 4096 x K 1024, folded-LayerNorm + GELU epilogue) per launch, from separate
-# rocprofv3 PMC passes of the shipped kernel IN SITU (inside DiT-L/2 batch-64 forwards, tools/profile_round.sh): FETCH_SIZE x 2 (gfx950 correction
-# for 16-B-per-lane streams, MI355X_MICROARCH.md) + WRITE_SIZE, KiB.  These are fabric-side request counters: Infinity-Cache hits are INCLUDED (the
-# whole working set of this GEMM fits the 256 MiB cache), so this is an upper bound on HBM bytes, not HBM bytes.  Source file named in `traffic_source`.
-FC1_TRAFFIC = {"fetch_kib": 99350.8, "write_kib": 131136.0, "source": "profiles/r04_final_pmc_in_situ.txt (EpiModGeluF16: fetch / write passes)"}
+# L2-miss traffic of the dominant GEMM of config 2 (fc1: M 16384 x N 4096 x K 1024, folded-LayerNorm + GELU epilogue) per launch comes from a TRACKED
+# measurement file, profiles/fc1_traffic.json, written by tools/profile_round.sh from separate rocprofv3 PMC passes of the shipped kernel IN SITU
+# (inside DiT-L/2 batch-64 forwards): FETCH_SIZE x 2 (gfx950 correction for 16-B-per-lane streams, MI355X_MICROARCH.md) + WRITE_SIZE, KiB.  These are
+# fabric-side request counters: Infinity-Cache hits are INCLUDED (the whole working set of this GEMM fits the 256 MiB cache), so this is an upper bound
+# on HBM bytes, not HBM bytes.  The file names the kernel symbol it was measured on; `traffic` is null unless that symbol is the one this bench times.
+FC1_KERNEL_SYMBOL = "gemm256h_tn_kernel<ASrcRowMajor, EpiModGeluF16, false, 0, 1>"
+
+
+def fc1_traffic():
+    path = os.path.join(ROOT, "profiles", "fc1_traffic.json")
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    if d.get("kernel") != FC1_KERNEL_SYMBOL or not os.path.exists(os.path.join(ROOT, d.get("source", "").split(" ")[0])):
+        return None  # measured on another kernel generation (or its evidence file is gone): a stale constant is worse than null
+    return d
 
 
 def parse():
@@ -54,9 +65,11 @@ def parse():
     p.add_argument("--field-gain", type=float, default=0.0,
                    help="scale of the DiT's output layer (0 = 1, the baseline-comparable field).  Config 3 with --field-gain 100 (CONFIG3_FIELD_GAIN) makes the seeded "
                         "random field stiff enough for dopri5 at 1e-5 to take >= 15 steps (92 NFE) -- the solver-loop stress variant of profiles/r03_config3_*")
-    p.add_argument("--in-flight", type=int, default=1, choices=[1, 2],
-                   help="batches in flight per GPU (config 2): 2 = consecutive steps alternate between two HIP streams with their own scratch (same weights, "
-                        "same per-batch results); the default line keeps one batch in flight, as every earlier round")
+    p.add_argument("--in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4],
+                   help="batches in flight per GPU: 2 = consecutive steps alternate between two HIP streams with their own scratch (same weights, bit-identical "
+                        "per-batch results: tests/test_gpu_cosched.py); 0 = the configuration's default -- 2 for config 2 (a sampling job's batches are independent, "
+                        "test_flow_latent_ddp.py:128-146; while one lane's workgroups sit in their HBM-bound GEMM epilogues the other's run their MFMA loops), "
+                        "1 for the others.  Rounds 1-4 reported one batch in flight: --in-flight 1 reproduces that line")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--stub", action="store_true", help="(tests) CPU / gloo rehearsal of the launcher + rank logic: a stub step instead of the HIP path")
@@ -289,19 +302,36 @@ def roofline_dit(model, lat, rows, dev):
         buf = (C.c_float * 64)()
         n = L.lfm_profile_fc1_read(buf, 64)
         durs += [buf[i] for i in range(n)]
+    # the whole block loop, no events between its kernels: the quantity north_star's ">= 40 % MFMA utilisation in the DiT block" is about
+    blk = []
+    for _ in range(3):
+        hip.check(L.lfm_profile_fc1(2), "lfm_profile_fc1")
+        model(tmid, x, y)
+        buf = (C.c_float * 16)()
+        n = L.lfm_profile_blocks_read(buf, 16)
+        blk += [buf[i] for i in range(n)]
     L.lfm_profile_fc1(0)
+    T = model.x_embedder.num_patches
+    blk_flop = 2.0 * rows * (12.0 * T * D * D + 2.0 * T * T * D)  # qkv + proj + fc1 + fc2 + QK^T + PV of one block, all rows
+    blk_s = sum(blk) / len(blk) * 1e-3 / model.depth
+    block = {"bound": "mfma", "block_us": blk_s * 1e6, "algorithmic_flop": blk_flop, "achieved": blk_flop / blk_s / 1e12, "peak": MFMA_PEAK_TFLOPS,
+             "unit": "TFLOP/s", "frac": blk_flop / blk_s / 1e12 / MFMA_PEAK_TFLOPS, "evaluations_timed": len(blk),
+             "what": "one DiTBlock (qkv GEMM, attention, proj GEMM, fc1 GEMM, fc2 GEMM with their fused epilogues) = the eager block loop of an evaluation "
+                     "/ depth, HIP events on the launching stream, one batch in flight"}
     dur = sum(durs) / len(durs) * 1e-3
     ach = 2.0 * M * H * D / dur / 1e12
     r = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
          "algorithmic_bytes": 2.0 * (M * D + H * D + M * H), "algorithmic_flop": 2.0 * M * H * D,
-         "kernel": "gemm256h_tn_kernel<ASrcRowMajor,EpiModGeluF16 | EpiBiasGeluF16> (DiT fc1: folded-LayerNorm correction + bias + GELU epilogue)",
+         "kernel": FC1_KERNEL_SYMBOL + " (DiT fc1: folded-LayerNorm correction + bias + GELU epilogue; EpiBiasGeluF16 where the fold does not apply)",
          "shape": {"M": M, "N": H, "K": D}, "avg_launch_us": dur * 1e6,
          "launches_timed": len(durs)}
-    if (M, H, D) == (16384, 4096, 1024):
-        r["traffic"] = (2 * FC1_TRAFFIC["fetch_kib"] + FC1_TRAFFIC["write_kib"]) * 1024
+    tr = fc1_traffic()
+    if (M, H, D) == (16384, 4096, 1024) and tr is not None:
+        r["traffic"] = (2 * tr["fetch_kib"] + tr["write_kib"]) * 1024
         r["traffic_unit"] = "bytes/launch leaving the L2s (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes); Infinity-Cache hits included, so an upper bound on HBM bytes"
-        r["traffic_source"] = FC1_TRAFFIC["source"]
-    return r
+        r["traffic_source"] = tr["source"]
+        r["traffic_kernel"] = tr["kernel"]
+    return r, block
 
 
 def roofline_adm(B, dev, side=64, ch=256):
@@ -423,16 +453,19 @@ def main():
     gather_ms = []
 
     lanes = None
-    if a.in_flight > 1:
+    in_flight = a.in_flight or (2 if a.config == 2 else 1)
+    if in_flight > 1:
         # two batches in flight: consecutive steps go to two HIP streams, each with its own solver buffers / captured graphs / workspaces on the SAME weights
-        if a.config != 2 or world != 1:
-            raise SystemExit("--in-flight 2 is built for config 2 on one GPU")
+        if a.config != 2:
+            raise SystemExit("--in-flight 2 is built for config 2")
         from lfm_amd.solvers import GraphedFixedGrid, concurrency_twin, torchdiffeq_euler_grid
 
-        tm, tv = concurrency_twin(w["model"]), concurrency_twin(vae)
-        sv = GraphedFixedGrid(tm, B)
-        sv.set_grid(*torchdiffeq_euler_grid(1.0 / a.nfe))
-        lanes = [(solve, vae, x_dev, torch.cuda.Stream(dev)), (sv.run, tv, torch.empty_like(x_dev), torch.cuda.Stream(dev))]
+        lanes = [(solve, vae, x_dev, torch.cuda.Stream(dev))]
+        for _ in range(in_flight - 1):
+            tm, tv = concurrency_twin(w["model"]), concurrency_twin(vae)
+            sv = GraphedFixedGrid(tm, B)
+            sv.set_grid(*torchdiffeq_euler_grid(1.0 / a.nfe))
+            lanes.append((sv.run, tv, torch.empty_like(x_dev), torch.cuda.Stream(dev)))
         first = []
         for sol, va, xd, st in lanes:  # capture each lane's graphs and size its workspaces outside the counted steps
             st.wait_stream(torch.cuda.current_stream(dev))  # weights, packed operands and the per-grid tables were produced on the launching stream
@@ -440,10 +473,9 @@ def main():
                 xd.copy_(w["x_host"], non_blocking=True)
                 first.append(images_to_uint8(va.decode(sol(xd) / 0.18215).sample))
         torch.cuda.synchronize()
-        # same latents through both lanes: identical images up to the known open issue of co-scheduled evaluations (profiles/r04_two_batches_in_flight.txt:
-        # about 1 in 15-40 co-scheduled folded-LayerNorm evaluations differs from its solo result at rounding level, |d latent| < 1e-4) -- at most one u8 step
-        dl = (first[0].int() - first[1].int()).abs()
-        assert int(dl.max()) <= 1 and float((dl > 0).float().mean()) < 0.02, "the two lanes must produce the same images for the same latents"
+        # same latents through both lanes: the SAME images, bit for bit (the co-scheduling non-determinism of rounds 4 is root-caused and fixed:
+        # profiles/r05_cosched_root_cause.txt; tests/test_gpu_cosched.py)
+        assert all(torch.equal(first[0], f) for f in first[1:]), "the lanes must produce identical images for the same latents"
     nstep = [0]
 
     def step():
@@ -452,7 +484,12 @@ def main():
             nstep[0] += 1
             with torch.cuda.stream(st):
                 xd.copy_(w["x_host"], non_blocking=True)
-                return images_to_uint8(va.decode(sol(xd) / 0.18215).sample)
+                u8 = images_to_uint8(va.decode(sol(xd) / 0.18215).sample)
+                if world > 1:
+                    t0 = time.perf_counter()
+                    pipe.submit(u8)  # the side stream waits for THIS lane's stream; the collective runs under the other lane's batch
+                    gather_ms.append((time.perf_counter() - t0) * 1e3)
+                return u8
         x_dev.copy_(w["x_host"], non_blocking=True)  # the batch's latents cross PCIe inside the timed region (1 MiB at batch 64)
         lat = solve(x_dev)
         img = vae.decode(lat / 0.18215).sample
@@ -542,7 +579,7 @@ def main():
         elif a.config == 6:  # the 32x32 level (256 channels: 10 of the evaluation's 3x3 convolutions run at this shape or its 512-input variant)
             res["roofline"] = roofline_adm(B, dev, side=32, ch=256)
         else:
-            res["roofline"] = roofline_dit(w["model"], lat, B if a.config == 2 else 2 * B, dev)
+            res["roofline"], res["roofline_block"] = roofline_dit(w["model"], lat, B if a.config == 2 else 2 * B, dev)
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.config == 2:
         res["cpu_baseline"] = cpu_baseline(w["name"], a.nfe)
     if rank == 0:

@@ -38,7 +38,7 @@ int lfm_abi_version(void);
 typedef struct lfm_dit_shape {
   int depth;      /* number of DiTBlocks */
   int hidden;     /* D */
-  int heads;      /* D / heads must be 64 */
+  int heads;      /* head_dim = D / heads must be 64 or 72 (DiT-S / B / L: 64; DiT-XL: 1152 / 16 = 72) */
   int patch;      /* p: 2 (register patch-embed kernel), 4 or 8 (p*p*C % 64 == 0: patch embedding on the MFMA GEMM) */
   int in_ch;      /* C (4 for f8 latents) */
   int res;        /* latent side R = image_size / f */
@@ -93,7 +93,15 @@ typedef struct lfm_dit_call {
   const void* cond_table;
   const int* cond_step;   /* device int (a fixed-grid solver's interval counter) */
   int cond_offset;
+  /* ABI 4.  Callers ZERO-INITIALISE the struct (memset / `= {0}`): every field below reads 0 as "as before". */
+  int cond_rows;          /* rows of cond_table (the n_times it was built with).  > 0: a row index *cond_step + cond_offset outside [0, cond_rows) is not
+                             read -- the evaluation's conditioning, and with it its output, becomes NaN (a kernel cannot return an error); 0: unchecked */
+  int fold_ln;            /* per-call LFM_OPT_FOLD_LN: 0 = the library default (lfm_set_option), LFM_CALL_OFF = separate LayerNorm launches, LFM_CALL_ON = folded */
+  int gemm_select;        /* per-call kernel selection: 0 = the library default (lfm_gemm_select), else LFM_CALL_GEMM_SELECT(value lfm_gemm_select would take) */
 } lfm_dit_call;
+#define LFM_CALL_OFF 1
+#define LFM_CALL_ON 2
+#define LFM_CALL_GEMM_SELECT(which) ((which) + 1)
 
 /* Bytes of caller-owned scratch for batches up to max_batch: residual stream, LN / attention buffers, Q|K|Vt (reused for the fc1
  * activation), conditioning vectors, the adaLN table and -- for small batches (<= 1024 tokens, latency mode) -- the fp32 slabs of the
@@ -131,7 +139,11 @@ int lfm_gemm_f16(const void* A, long lda, const void* W, long ldw, void* C, long
 int lfm_gemm_qkv_f16(const void* A, long lda, const void* W, long ldw, void* Q, void* K_out, void* Vt, int M, int D, int K,
                      const float* bias, int head_dim, int tokens, lfm_stream_t stream);
 
-/* Kernel selection for the GEMMs: 0 = automatic (the 256x256 quadrant-phased kernel on 16x16x32 MFMAs for chip-filling shapes with K % 64 == 0,
+/* Scope of the three library-wide switches below (lfm_gemm_select, lfm_set_option, lfm_profile_fc1): they set process-wide DEFAULTS and are meant for
+ * measurement and tests; they are read when a call is ENQUEUED, on the calling thread.  A caller that needs a setting for ONE evaluation -- two
+ * lanes in flight, several host threads -- passes it in lfm_dit_call (fold_ln, gemm_select): the per-call values live in thread-local state for the
+ * duration of lfm_dit_forward and never touch the defaults, so concurrent callers do not see each other's choices (tests/test_c_abi.py).
+ * Kernel selection for the GEMMs: 0 = automatic (the 256x256 quadrant-phased kernel on 16x16x32 MFMAs for chip-filling shapes with K % 64 == 0,
  * the 256x128 two-workgroups-per-CU kernel for chip-filling shapes that are only 128 columns wide, the 128x128 kernel otherwise), 1 = force
  * 128x128, 4 = force 256x128, 5 = force 256x256 with eight waves, 6 = force 256x256 with one wave per SIMD (128x128 wave tiles; row-major A
  * operands, K % 64 == 0 -- other cases take kernel 5) (other values are refused); | flags << 4 = ablation / A-B switches.  For measurement and
@@ -139,8 +151,14 @@ int lfm_gemm_qkv_f16(const void* A, long lda, const void* W, long ldw, void* Q, 
 int lfm_gemm_select(int which);
 
 /* Measurement only: when enabled, every eager lfm_dit_forward records a HIP event pair around each block's fc1 GEMM (the
- * dominant kernel); lfm_profile_fc1_read synchronises and returns the per-launch durations in ms (bench.py roofline row). */
+ * dominant kernel); lfm_profile_fc1_read synchronises and returns the per-launch durations in ms (bench.py roofline row).  One stream at a time:
+ * the first stream that launches an evaluation while the probe is on owns it; an evaluation enqueued on ANOTHER stream meanwhile is not recorded
+ * and makes lfm_profile_fc1_read return LFM_ERR_ARG (event pairs of interleaved streams would time the other stream's kernels too). */
 int lfm_profile_fc1(int enable);
+/* With the same probe on, every recorded evaluation also brackets its WHOLE block loop (all DiTBlocks: qkv .. fc2, models/DiT.py:112-131) with one
+ * event pair: host_ms_out receives one duration per evaluation (at most 16); block time = duration / depth (bench.py `roofline_block`).
+ * lfm_profile_fc1(2) records ONLY these (no events between the block's kernels). */
+int lfm_profile_blocks_read(float* host_ms_out, int max_n);
 /* Library-wide options.  key 1 (LFM_OPT_FOLD_LN), value 0 / 1, default 1: modulate(LayerNorm(x), shift, scale) (models/DiT.py:20-21, 129-130) FOLDED
  * into the GEMM epilogues around it -- the gated-residual GEMMs (proj, fc2) emit the centred, (1 + scale)-weighted fp16 operand and per-row partial
  * sums, the consuming GEMMs (qkv, fc1) apply rstd, the mean correction and the shift term in their epilogues -- wherever the shape allows it
@@ -151,6 +169,9 @@ int lfm_profile_fc1(int enable);
  * (csrc/gemm256w_kernel.h) instead of the eight-wave one.  Same accumulation order per output element: bit-identical results. */
 #define LFM_OPT_GEMM_V6 2
 int lfm_set_option(int key, int value);
+/* The settings lfm_dit_forward would run `call` with if it were enqueued by the calling thread now (per-call fields over the library defaults):
+ * *gemm_select_out = kernel | flags << 4, *fold_ln_out = 0 / 1.  No launch; usable without a GPU. */
+int lfm_dit_call_settings(const lfm_dit_call* call, int* gemm_select_out, int* fold_ln_out);
 
 /* Measurement aid (bench.py): the clock the chip sustains under matrix load.  `blocks` workgroups of 512 threads each stream iters x 64 MFMAs per wave on
  * pseudo-random fp16 operands between two s_memtime reads; ticks_out[blocks] (device) receives the tick count of every workgroup (one tick = one shader

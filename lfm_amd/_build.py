@@ -16,7 +16,12 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # No -ffast-math (round 4, profiles/r04_fastmath_ab.txt: parity unchanged to four digits, bench within noise with or without it): the fp32 timestep
 # sinusoid, softmax, GELU and LayerNorm statistics compile under IEEE rules; the approximate instructions this path wants (v_exp_f32, v_rcp_f32) are
 # written out where they are used.  LFM_FAST_MATH=1 restores the flag for an A/B (tools/fastmath_ab.sh).
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-macro-redefined"]
+# -fno-slp-vectorize (round 5): the SLP vectorizer re-packs scalar fp32 code into v_pk_*_f32 and, where the two halves come from different places, gives the
+# instruction an op_sel operand -- the form that reads its operand as 0.0 in lanes 48-63 under co-scheduling (csrc/common.h: fma_v; profiles/
+# r05_cosched_root_cause.txt).  Without the pass the library holds NO op_sel'd packed-fp32 instruction (tests/test_host_logic.py asserts it on the built
+# code objects); the packed GELU / epilogue arithmetic is written with vector types and stays packed.  A/B on one box: 109.4 vs 109.4 img/s (one batch in
+# flight), 114.4 vs 114.4 (two) -- profiles/r05_noslp_ab.txt.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-macro-redefined", "-fno-slp-vectorize"]
 if os.environ.get("LFM_FAST_MATH") == "1":
     FLAGS += ["-ffast-math", "-fno-finite-math-only"]
 if os.environ.get("LFM_MEASURE") == "1":  # measurement builds: the s_memtime-stamped GEMM epilogues and the attention phase / trace variants (tools/)

@@ -3,9 +3,17 @@
 #include "../../include/lfm_hip.h"
 #include "gemm_dispatch.h"
 
-static int g_gemm_sel = 0;
+// Library-wide switches = process-wide DEFAULTS (lfm_gemm_select, lfm_set_option); a call that carries its own values (lfm_dit_call.fold_ln /
+// .gemm_select, ABI 4) overrides them in THREAD-LOCAL state for the duration of lfm_dit_forward: every launcher reads the effective value on the
+// calling thread while it enqueues, so two host threads (or two lanes in flight with different settings) never see each other's choice.
+static int g_gemm_sel_default = 0, g_gemm_dbg_default = 0;
+static int g_opt_fold_ln_default = 1;
+static thread_local int tl_sel_set = 0, tl_gemm_sel = 0, tl_gemm_dbg = 0;  // per-call kernel selection active on this thread
+static thread_local int tl_fold = 0;                                       // 0: default, LFM_CALL_OFF, LFM_CALL_ON
+#define g_gemm_sel (tl_sel_set ? tl_gemm_sel : g_gemm_sel_default)
+#define g_gemm_dbg (tl_sel_set ? tl_gemm_dbg : g_gemm_dbg_default)
+#define g_opt_fold_ln (tl_fold ? (tl_fold == LFM_CALL_ON ? 1 : 0) : g_opt_fold_ln_default)
 int lfm_gemm_selected() { return g_gemm_sel; }
-static int g_gemm_dbg = 0;
 int lfm_gemm_debug_flags() { return g_gemm_dbg; }
 int lfm_gemm_selected_v1_ok() { return g_gemm_sel < 2 && !(g_gemm_dbg & 512); }  // flag 512: split-K off (A/B)
 // flag 4096: never pick v4 for 256-wide-capable shapes; flag 8192: always (A/B of the automatic choice)
@@ -17,15 +25,51 @@ int lfm_gemm_prefers_v4(int M, int N, int K) {
   if (g_gemm_dbg & 8192) return 1;
   return 0;
 }
-static int g_opt_fold_ln = 1;
 static int g_opt_v6 = 0;
 int lfm_gemm_v6_default() { return g_opt_v6; }
 static int g_stagger = 0;
 int lfm_stagger_ticks() { return g_stagger; }
+static inline bool gemm_select_valid(int which) {
+  const int k = which & 15;
+  return which >= 0 && (k == 0 || k == 1 || k == 4 || k == 5 || k == 6);
+}
+struct CallScope {  // per-call settings of one lfm_dit_forward on this thread (restored on every return path)
+  int sel_set, sel, dbg, fold;
+  CallScope() : sel_set(tl_sel_set), sel(tl_gemm_sel), dbg(tl_gemm_dbg), fold(tl_fold) {}
+  ~CallScope() {
+    tl_sel_set = sel_set;
+    tl_gemm_sel = sel;
+    tl_gemm_dbg = dbg;
+    tl_fold = fold;
+  }
+};
+
+static int call_scope_enter(const lfm_dit_call* c) {  // after a CallScope was opened on this thread
+  if (c->fold_ln < 0 || c->fold_ln > LFM_CALL_ON || c->gemm_select < 0 || (c->gemm_select && !gemm_select_valid(c->gemm_select - 1)) || c->cond_rows < 0)
+    return LFM_ERR_ARG;
+  if (c->fold_ln) tl_fold = c->fold_ln;
+  if (c->gemm_select) {
+    tl_sel_set = 1;
+    tl_gemm_sel = (c->gemm_select - 1) & 15;
+    tl_gemm_dbg = (c->gemm_select - 1) >> 4;
+  }
+  return LFM_OK;
+}
+// What lfm_dit_forward would run `call` with on the calling thread, right now: gemm_select_out = kernel | flags << 4, fold_ln_out = 0 / 1.  Goes through
+// the same scope code as the forward (no launch, no GPU needed): the CPU test of the per-call / per-thread scoping (tests/test_c_abi.py).
+extern "C" int lfm_dit_call_settings(const lfm_dit_call* call, int* gemm_select_out, int* fold_ln_out) {
+  if (!call || !gemm_select_out || !fold_ln_out) return LFM_ERR_ARG;
+  CallScope scope;
+  const int rc = call_scope_enter(call);
+  if (rc) return rc;
+  *gemm_select_out = g_gemm_sel | (g_gemm_dbg << 4);
+  *fold_ln_out = g_opt_fold_ln;
+  return LFM_OK;
+}
 
 extern "C" int lfm_set_option(int key, int value) {  // key 1 (LFM_OPT_FOLD_LN): adaLN LayerNorm-modulate folded into the GEMM epilogues (default 1)
   if (key == 1) {
-    g_opt_fold_ln = value != 0;
+    g_opt_fold_ln_default = value != 0;
     return LFM_OK;
   }
   if (key == 2) {  // LFM_OPT_GEMM_V6: the one-wave-per-SIMD 256x256 kernel for the chip-filling row-major GEMMs
@@ -41,10 +85,9 @@ extern "C" int lfm_set_option(int key, int value) {  // key 1 (LFM_OPT_FOLD_LN):
   return LFM_ERR_ARG;
 }
 extern "C" int lfm_gemm_select(int which) {  // low 4 bits: kernel choice (0 auto, 1, 4, 5, 6); bits 4+: ablation flags (measurement only)
-  const int k = which & 15;
-  if (which < 0 || !(k == 0 || k == 1 || k == 4 || k == 5 || k == 6)) return LFM_ERR_ARG;
-  g_gemm_sel = which & 15;
-  g_gemm_dbg = which >> 4;
+  if (!gemm_select_valid(which)) return LFM_ERR_ARG;
+  g_gemm_sel_default = which & 15;
+  g_gemm_dbg_default = which >> 4;
   return LFM_OK;
 }
 
@@ -898,7 +941,7 @@ extern "C" const char* lfm_strerror(int code) {
   }
   return "unknown";
 }
-extern "C" int lfm_abi_version(void) { return 3; }  // 2: lfm_time_embed takes label_rows; 3: lfm_dit_call carries the per-grid conditioning table
+extern "C" int lfm_abi_version(void) { return 4; }  // 2: lfm_time_embed takes label_rows; 3: lfm_dit_call carries the per-grid conditioning table; 4: + cond_rows, per-call fold_ln / gemm_select
 
 extern "C" size_t lfm_dit_workspace_bytes(const lfm_dit_shape* shape, int max_batch) {
   if (check_shape(shape) != LFM_OK || max_batch <= 0) return 0;
@@ -1012,25 +1055,63 @@ extern "C" int lfm_gemm_f16(const void* A, long lda, const void* W, long ldw, vo
 // bench.py's roofline row needs the fc1 GEMM's duration INSIDE a real forward (real activations, real cache state); the
 // captured graph cannot be bracketed from outside, so an eager forward can record one HIP event pair per block here.
 #define LFM_PROF_MAX 64
+#define LFM_PROF_BLK_MAX 16
 static hipEvent_t g_prof_ev[2 * LFM_PROF_MAX];
 static bool g_prof_init = false, g_prof_on = false;
 static int g_prof_count = 0;
+static hipEvent_t g_prof_blk_ev[2 * LFM_PROF_BLK_MAX];  // around the whole block loop of an evaluation (all blocks' qkv .. fc2)
+static int g_prof_blk_count = 0;
+static int g_prof_mode = 0;  // 1: an event pair around every fc1 launch (+ the block loop); 2: around the block loop only (no events between the kernels)
+static hipStream_t g_prof_stream = nullptr;  // the stream that owns the probe (the first one that launches while it is on)
+static bool g_prof_owned = false, g_prof_conflict = false;
 extern "C" int lfm_profile_fc1(int enable) {
   if (enable && !g_prof_init) {
     for (int i = 0; i < 2 * LFM_PROF_MAX; ++i)
       if (hipEventCreate(&g_prof_ev[i]) != hipSuccess) return LFM_ERR_LAUNCH;
+    for (int i = 0; i < 2 * LFM_PROF_BLK_MAX; ++i)
+      if (hipEventCreate(&g_prof_blk_ev[i]) != hipSuccess) return LFM_ERR_LAUNCH;
     g_prof_init = true;
   }
   g_prof_on = enable != 0;
-  if (enable) g_prof_count = 0;
+  g_prof_mode = enable;
+  if (enable) {
+    g_prof_count = 0;
+    g_prof_blk_count = 0;
+    g_prof_owned = false;
+    g_prof_conflict = false;
+  }
   return LFM_OK;
+}
+static bool prof_claim(hipStream_t st) {  // may THIS evaluation record its fc1 launches?
+  if (!g_prof_on) return false;
+  if (!g_prof_owned) {
+    g_prof_owned = true;
+    g_prof_stream = st;
+  }
+  if (st != g_prof_stream) {
+    g_prof_conflict = true;
+    return false;
+  }
+  return true;
 }
 extern "C" int lfm_profile_fc1_read(float* ms_out, int max_n) {  // synchronises; returns the number of samples written
   if (!ms_out || !g_prof_init) return LFM_ERR_ARG;
+  if (g_prof_conflict) return LFM_ERR_ARG;  // a second stream launched evaluations while the probe was on: the samples would time its kernels too
   const int n = g_prof_count < max_n ? g_prof_count : max_n;
   for (int i = 0; i < n; ++i) {
     if (hipEventSynchronize(g_prof_ev[2 * i + 1]) != hipSuccess) return LFM_ERR_LAUNCH;
     if (hipEventElapsedTime(&ms_out[i], g_prof_ev[2 * i], g_prof_ev[2 * i + 1]) != hipSuccess) return LFM_ERR_LAUNCH;
+  }
+  return n;
+}
+
+extern "C" int lfm_profile_blocks_read(float* ms_out, int max_n) {  // one sample per recorded evaluation: its whole block loop; synchronises
+  if (!ms_out || !g_prof_init) return LFM_ERR_ARG;
+  if (g_prof_conflict) return LFM_ERR_ARG;
+  const int n = g_prof_blk_count < max_n ? g_prof_blk_count : max_n;
+  for (int i = 0; i < n; ++i) {
+    if (hipEventSynchronize(g_prof_blk_ev[2 * i + 1]) != hipSuccess) return LFM_ERR_LAUNCH;
+    if (hipEventElapsedTime(&ms_out[i], g_prof_blk_ev[2 * i], g_prof_blk_ev[2 * i + 1]) != hipSuccess) return LFM_ERR_LAUNCH;
   }
   return n;
 }
@@ -1164,26 +1245,30 @@ static inline long cond_row_floats(const lfm_dit_shape* s) {
 }
 __global__ __launch_bounds__(256) void cond_row_copy_kernel(const float* __restrict__ table, long row_floats, const int* __restrict__ step, int offset,
                                                             int fixed_row, float* __restrict__ mod, long nmod, float* __restrict__ uvq, long nq,
-                                                            float* __restrict__ uvf, long nf, int to_table) {
+                                                            float* __restrict__ uvf, long nf, int to_table, int rows) {
   const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= nmod + nq + nf) return;
   const long row = step ? (long)(*step + offset) : (long)fixed_row;
   float* ws = i < nmod ? mod + i : (i < nmod + nq ? uvq + (i - nmod) : uvf + (i - nmod - nq));  // nmod, nq, nf are multiples of 4
+  if (rows > 0 && (row < 0 || row >= rows)) {  // a row the table does not have (wrong offset / counter): poison instead of reading out of bounds
+    if (!to_table) *(f32x4*)ws = (f32x4){__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+    return;
+  }
   float* tb = (float*)table + row * row_floats + i;
   if (to_table) *(f32x4*)tb = *(const f32x4*)ws;
   else *(f32x4*)ws = *(const f32x4*)tb;
 }
 static int dit_cond_copy(const lfm_dit_shape* s, const DitWs& ws, const float* table, const int* step, int offset, int fixed_row, int to_table,
-                         hipStream_t st) {
+                         hipStream_t st, int rows = 0) {
   const long D = s->hidden, H = s->mlp_hidden, J = (long)s->depth * 6 * D + 2 * D;
   const long nq = cond_uv_shape(s) ? (long)s->depth * 2 * 3 * D : 0, nf = cond_uv_shape(s) ? (long)s->depth * 2 * H : 0;
   hipLaunchKernelGGL(cond_row_copy_kernel, dim3(cdiv((J + nq + nf) / 4, 256)), dim3(256), 0, st, table, cond_row_floats(s), step, offset, fixed_row, ws.mod, J,
-                     ws.uvq, nq, ws.uvf, nf, to_table);
+                     ws.uvq, nq, ws.uvf, nf, to_table, rows);
   LFM_CHECK_LAUNCH();
   return LFM_OK;
 }
-static int dit_cond_select(const lfm_dit_shape* s, const DitWs& ws, const float* table, const int* step, int offset, hipStream_t st) {
-  return dit_cond_copy(s, ws, table, step, offset, 0, 0, st);
+static int dit_cond_select(const lfm_dit_shape* s, const DitWs& ws, const float* table, const int* step, int offset, int rows, hipStream_t st) {
+  return dit_cond_copy(s, ws, table, step, offset, 0, 0, st, rows);
 }
 
 extern "C" size_t lfm_dit_cond_table_bytes(const lfm_dit_shape* shape, int n_times) {
@@ -1204,7 +1289,7 @@ extern "C" int lfm_dit_cond_table_build(const lfm_dit_shape* s, const lfm_dit_we
   for (int i = 0; i < n_times; ++i) {
     rc = dit_conditioning(s, w, ws, t_values + i, 1, nullptr, 1, cond_uv_shape(s), st);
     if (rc) return rc;
-    rc = dit_cond_copy(s, ws, (const float*)table, nullptr, 0, i, 1, st);
+    rc = dit_cond_copy(s, ws, (const float*)table, nullptr, 0, i, 1, st, n_times);
     if (rc) return rc;
   }
   return LFM_OK;
@@ -1226,6 +1311,10 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
   hipStream_t st = (hipStream_t)stream;
   const int D = s->hidden, H = s->mlp_hidden, grid = s->res / s->patch, T = grid * grid, M = B * T;
   const long J = (long)s->depth * 6 * D + 2 * D;
+  // per-call settings (ABI 4): thread-local for the duration of this call, the library defaults are not touched
+  CallScope scope;
+  if ((rc = call_scope_enter(c)) != LFM_OK) return rc;
+  const bool prof_ok = prof_claim(st);
 
   // conditioning rows: one shared row when time is scalar and there are no labels
   const int rows = (c->t_len == 1 && !c->y) ? 1 : B;
@@ -1241,7 +1330,7 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
   const bool w6 = g_gemm_sel == 6 || (g_gemm_sel == 0 && g_opt_v6);  // the block GEMMs of the folded path on the one-wave-per-SIMD kernel
   const bool pe_mfma = s->patch == 2 && s->in_ch == 4 && (D % 256 == 0) && D <= 1280 && (s->res % 2 == 0) && !(g_gemm_dbg & 2097152);  // flag: round-1 kernel
   if (tab) {
-    rc = dit_cond_select(s, ws, (const float*)c->cond_table, c->cond_step, c->cond_offset, st);
+    rc = dit_cond_select(s, ws, (const float*)c->cond_table, c->cond_step, c->cond_offset, c->cond_rows, st);
   } else {
     rc = dit_conditioning(s, w, ws, c->t, c->t_len, c->y, rows, fold, st);
   }
@@ -1296,6 +1385,8 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
 #else
 #define DIT_CHK(buf, bytes, slot)
 #endif
+  const bool prof_blk = prof_ok && g_prof_blk_count < LFM_PROF_BLK_MAX;
+  if (prof_blk) (void)hipEventRecord(g_prof_blk_ev[2 * g_prof_blk_count], st);
   if (fold) {
     for (int i = 0; i < s->depth; ++i) {
       const float* mod = ws.mod + (long)i * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
@@ -1315,7 +1406,7 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
       DIT_CHK(ws.X, (size_t)M * D * 4, 2);
       DIT_CHK(ws.A2, (size_t)M * D * 2, 3);
       DIT_CHK(ws.ln_part, (size_t)M * tiles_p * 8, 4);
-      const bool prof = g_prof_on && g_prof_count < LFM_PROF_MAX;
+      const bool prof = prof_ok && g_prof_mode == 1 && g_prof_count < LFM_PROF_MAX;
       if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_count], st);
 #if defined(LFM_MEASURE) && defined(LFM_EXP_DUMP)
       const EpiModGeluF16 e_fc1{ws.QKVH, H, uf, uf + (long)rows * H, uvs_f, T, rowstat_src(), nullptr, 0,
@@ -1364,7 +1455,7 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
       rc = ln_modulate_launch(ws.X, ws.A, M, D, T, mod + 3 * D, mod + 4 * D, mstride, st);
     }
     if (rc) return rc;
-    const bool prof = g_prof_on && g_prof_count < LFM_PROF_MAX;
+    const bool prof = prof_ok && g_prof_mode == 1 && g_prof_count < LFM_PROF_MAX;
     if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_count], st);
     const EpiBiasGeluF16 e_fc1{ws.QKVH, H, w->fc1_b + (size_t)i * H};
     rc = launch_gemm_splitk(ws.A, D, (const half_t*)w->fc1_w + (size_t)i * H * D, D, M, H, D, e_fc1, ws.slab, ws.slab_bytes, st);
@@ -1379,6 +1470,7 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
     if (rc == 1) rc = launch_gemm_auto(ASrcRowMajor{ws.QKVH, H, M, 0}, (const half_t*)w->fc2_w + (size_t)i * D * H, H, M, D, H, e_fc2, st);
     if (rc) return rc;
   }
+  if (prof_blk) (void)hipEventRecord(g_prof_blk_ev[2 * g_prof_blk_count++ + 1], st);
   const float* fmod = ws.mod + (long)s->depth * 6 * D;
   const int Mh = cfg ? M / 2 : M;
   // skinny MFMA GEMM (16 rows per wave) when the shape allows it: whole 16-row tiles inside one image half, 16-column output tiles, D % 32 == 0

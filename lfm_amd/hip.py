@@ -28,7 +28,17 @@ class DitWeights(C.Structure):
 class DitCall(C.Structure):
     _fields_ = [("batch", C.c_int), ("x", C.c_void_p), ("t", C.c_void_p), ("t_len", C.c_int), ("y", C.c_void_p),
                 ("cfg", C.c_int), ("cfg_scale", C.c_float), ("out", C.c_void_p), ("axpy_base", C.c_void_p), ("axpy_dt", C.c_void_p),
-                ("cond_table", C.c_void_p), ("cond_step", C.c_void_p), ("cond_offset", C.c_int)]
+                ("cond_table", C.c_void_p), ("cond_step", C.c_void_p), ("cond_offset", C.c_int),
+                ("cond_rows", C.c_int), ("fold_ln", C.c_int), ("gemm_select", C.c_int)]  # ABI 4; zero = "as before" (ctypes zero-fills omitted fields)
+
+
+ABI_VERSION = 4  # include/lfm_hip.h: lfm_abi_version()
+CALL_OFF, CALL_ON = 1, 2  # lfm_dit_call.fold_ln
+
+
+def call_gemm_select(which):
+    """lfm_dit_call.gemm_select value for the kernel selection `which` (what lfm_gemm_select would take): per call, not library-wide."""
+    return int(which) + 1
 
 
 def lib():
@@ -60,6 +70,8 @@ def lib():
     L.lfm_strerror.restype = C.c_char_p
     L.lfm_strerror.argtypes = [C.c_int]
     L.lfm_abi_version.restype = C.c_int
+    if L.lfm_abi_version() != ABI_VERSION:  # a stale prebuilt library would read the call structs of another layout
+        raise LfmHipError(f"{path} has ABI {L.lfm_abi_version()}, this package binds ABI {ABI_VERSION}: rebuild it (python -m lfm_amd._build --force)")
     L.lfm_dit_workspace_bytes.restype = C.c_size_t
     L.lfm_dit_workspace_bytes.argtypes = [C.POINTER(DitShape), C.c_int]
     L.lfm_dit_forward.restype = C.c_int
@@ -87,12 +99,16 @@ def lib():
     L.lfm_profile_fc1.argtypes = [C.c_int]
     L.lfm_profile_fc1_read.restype = C.c_int
     L.lfm_profile_fc1_read.argtypes = [C.POINTER(C.c_float), C.c_int]
+    L.lfm_profile_blocks_read.restype = C.c_int
+    L.lfm_profile_blocks_read.argtypes = [C.POINTER(C.c_float), C.c_int]
     L.lfm_ln_modulate.restype = C.c_int
     L.lfm_ln_modulate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
     L.lfm_dit_attention.restype = C.c_int
     L.lfm_dit_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.lfm_set_option.restype = C.c_int
     L.lfm_set_option.argtypes = [C.c_int, C.c_int]
+    L.lfm_dit_call_settings.restype = C.c_int
+    L.lfm_dit_call_settings.argtypes = [C.POINTER(DitCall), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.lfm_dit_attention_hd.restype = C.c_int
     L.lfm_dit_attention_hd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.lfm_grid_advance.restype = C.c_int

@@ -231,7 +231,7 @@ class DiT(nn.Module):
 
     # ---- the single entry to the device code
     @torch.no_grad()
-    def _run(self, t, x, y, cfg, cfg_scale, out=None, axpy_base=None, axpy_dt=None, cond=None):
+    def _run(self, t, x, y, cfg, cfg_scale, out=None, axpy_base=None, axpy_dt=None, cond=None, fold_ln=0, gemm_select=0):
         hip.require_gpu(x, "DiT.forward")
         if self.training:
             raise hip.LfmHipError("the HIP DiT is inference-only: call .eval() (label dropout / autograd are training features)")
@@ -258,7 +258,9 @@ class DiT(nn.Module):
                            float(cfg_scale), out.data_ptr(), axpy_base.data_ptr() if axpy_base is not None else None,
                            axpy_dt.data_ptr() if axpy_dt is not None else None,
                            cond[0].data_ptr() if cond is not None else None, cond[1].data_ptr() if cond is not None else None,
-                           int(cond[2]) if cond is not None else 0)  # cond = (table, device step counter, row offset): see cond_table()
+                           int(cond[2]) if cond is not None else 0,  # cond = (table, device step counter, row offset, rows): see cond_table()
+                           int(cond[3]) if cond is not None and len(cond) > 3 else 0,
+                           int(fold_ln), int(gemm_select))  # per-call settings (ABI 4): 0 = the library defaults
         rc = hip.lib().lfm_dit_forward(C.byref(shape), C.byref(w), hip.ptr(ws), ws.numel(), C.byref(call), hip.stream_ptr(x.device))
         hip.check(rc, "lfm_dit_forward")
         return out

@@ -427,6 +427,7 @@ class GraphedFixedGrid:
         # persistent buffer that is only re-FILLED when the grid or the weights change (re-allocated, and the graphs dropped, when a longer grid arrives)
         self.use_cond_table = self.is_dit and self.y is None and not self.use_cfg and os.environ.get("LFM_COND_TABLE", "1") != "0"
         self.cond_buf = None
+        self._cond_rows = 0  # rows of the table the evaluations may index (0: no table in use)
         self._cond_key = None
         self._grid_host = ()
 
@@ -449,17 +450,33 @@ class GraphedFixedGrid:
         n = self.n_intervals
         if self._cond_key == (self._grid_host, getattr(self.model, "_gen", 0)):
             return
+        import ctypes as _C
+        shape = self.model.shape_struct()
+        if hip.lib().lfm_dit_cond_table_bytes(_C.byref(shape), n + 1) > self.COND_TABLE_MAX_BYTES:  # a 1.6 % saving is not worth gigabytes
+            if self._cond_rows:
+                self.graphs.clear()  # captured with table rows: re-capture without
+            self._cond_rows = 0
+            self._cond_key = (self._grid_host, getattr(self.model, "_gen", 0))
+            return
         table = self.model.cond_table(self.ts[: n + 1], self.batch)  # may (re)pack weights / size the workspace: read the generation after it
         if self.cond_buf is None or self.cond_buf.numel() < table.numel():
             self.cond_buf = table
             self.graphs.clear()  # they point at the old buffer
         else:
             self.cond_buf[: table.numel()].copy_(table)
+        if self._cond_rows != n + 1:
+            self.graphs.clear()  # the row count is baked into the captured calls (lfm_dit_call.cond_rows)
+        self._cond_rows = n + 1
         self._cond_key = (self._grid_host, getattr(self.model, "_gen", 0))
 
     def _cond(self, offset):
         """(table, interval counter, row offset) of an evaluation at grid time ts[step + offset]; _advance has already incremented the counter."""
-        return (self.cond_buf, self.step, offset) if self.use_cond_table and self.cond_buf is not None else None
+        return (self.cond_buf, self.step, offset, self._cond_rows) if self._cond_active() else None
+
+    COND_TABLE_MAX_BYTES = 1 << 30  # ~2 MB per grid time for DiT-L/2: 50-500 intervals; finer grids (step_size 1e-3) recompute the conditioning per evaluation
+
+    def _cond_active(self):
+        return self.use_cond_table and self.cond_buf is not None and self._cond_rows > 0
 
     def _advance(self):
         hip.check(hip.lib().lfm_grid_advance(hip.ptr(self.ts), hip.ptr(self.dts), hip.ptr(self.step), hip.ptr(self.tcur), hip.ptr(self.tnext),
