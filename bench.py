@@ -67,9 +67,10 @@ def parse():
                         "random field stiff enough for dopri5 at 1e-5 to take >= 15 steps (92 NFE) -- the solver-loop stress variant of profiles/r03_config3_*")
     p.add_argument("--in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4],
                    help="batches in flight per GPU: 2 = consecutive steps alternate between two HIP streams with their own scratch (same weights, bit-identical "
-                        "per-batch results: tests/test_gpu_cosched.py); 0 = the configuration's default -- 2 for config 2 (a sampling job's batches are independent, "
-                        "test_flow_latent_ddp.py:128-146; while one lane's workgroups sit in their HBM-bound GEMM epilogues the other's run their MFMA loops), "
-                        "1 for the others.  Rounds 1-4 reported one batch in flight: --in-flight 1 reproduces that line")
+                        "per-batch results: tests/test_gpu_cosched.py); 0 = the configuration's default -- 2 for the fixed-grid configurations 2, 5, 6 (a sampling "
+                        "job's batches are independent, test_flow_latent_ddp.py:128-146; while one lane's workgroups sit in their HBM-bound epilogues or run a "
+                        "small-map kernel that cannot fill the chip, the other lane's kernels use it), 1 for configs 3 / 4.  Rounds 1-4 reported one batch in "
+                        "flight: --in-flight 1 reproduces that line")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--stub", action="store_true", help="(tests) CPU / gloo rehearsal of the launcher + rank logic: a stub step instead of the HIP path")
@@ -192,9 +193,12 @@ def build_workload(a, dev, rank):
         model = dezero_(DiT_models[name](img_resolution=32, in_channels=4, label_dropout=0.0, num_classes=1)).to(dev).eval()
         ts, dts = torchdiffeq_euler_grid(1.0 / a.nfe)
         assert dts.numel() == a.nfe
-        solver = GraphedFixedGrid(model, B)
-        solver.set_grid(ts, dts)
-        solve = lambda x: solver.run(x)  # noqa: E731
+        def lane_solver(mod):  # a fixed-grid solver (own buffers, own captured graphs) on `mod`: the model itself or a concurrency twin of it
+            sv = GraphedFixedGrid(mod, B)
+            sv.set_grid(ts, dts)
+            return sv.run
+
+        solve = lane_solver(model)
         f_model = a.nfe * dit_flops(model)
         wl = f"{name} celeb256 f8 (4x32x32 latents), batch {B}/GPU, {a.nfe}-step Euler (torchdiffeq grid) + f8 VAE decode to 256x256 + uint8 NHWC"
         x_shape, res, extra = (B, 4, 32, 32), 32, {"nfe": a.nfe}
@@ -250,9 +254,12 @@ def build_workload(a, dev, rank):
         torch.manual_seed(0)
         model = dezero_(create_network(cfg)).to(dev).eval()
         ts, dts = torchdiffeq_euler_grid(1.0 / a.nfe)
-        solver = GraphedFixedGrid(model, B, resolution=32)
-        solver.set_grid(ts, dts)
-        solve = lambda x: solver.run(x)  # noqa: E731
+        def lane_solver(mod):
+            sv = GraphedFixedGrid(mod, B, resolution=32)
+            sv.set_grid(ts, dts)
+            return sv.run
+
+        solve = lane_solver(model)
         f_model = a.nfe * EDM_FFHQ_FLOP_PER_IMAGE
         wl = (f"EDM-style ADM UNet ffhq_adm (DhariwalUNet, 406 M params), 4x32x32 latents, batch {B}/GPU, {a.nfe}-step Euler (torchdiffeq grid) + f8 VAE decode to "
               "256x256 + uint8 NHWC")
@@ -267,14 +274,18 @@ def build_workload(a, dev, rank):
         torch.manual_seed(0)
         model = dezero_(create_network(cfg)).to(dev).eval()
         ts, dts = torchdiffeq_euler_grid(1.0 / a.nfe)
-        solver = GraphedFixedGrid(model, B, resolution=64)
-        solver.set_grid(ts, dts)
-        solve = lambda x: solver.run(x)  # noqa: E731
+        def lane_solver(mod):
+            sv = GraphedFixedGrid(mod, B, resolution=64)
+            sv.set_grid(ts, dts)
+            return sv.run
+
+        solve = lane_solver(model)
         f_model = a.nfe * 189.7e9  # hook-counted on the reference module
         wl = f"origin-ADM celeb512 (352 M params), 4x64x64 latents, batch {B}/GPU, {a.nfe}-step Euler + f8 VAE decode to 512x512 + uint8 NHWC"
         x_shape, res, extra = (B, 4, 64, 64), 64, {"nfe": a.nfe}
     x_host = torch.randn(*x_shape, generator=g).pin_memory()
-    return dict(model=model, vae=vae, solve=solve, B=B, res=res, x_host=x_host, workload=wl, f_model=f_model, f_vae=vae_decode_flops(res),
+    return dict(model=model, vae=vae, solve=solve, lane_solver=locals().get("lane_solver"), B=B, res=res, x_host=x_host, workload=wl, f_model=f_model,
+                f_vae=vae_decode_flops(res),
                 extra=extra, name=(a.model or {2: "DiT-L/2", 3: "DiT-L/2", 4: "DiT-B/2", 5: "ADM-celeb512", 6: "EDM-ADM-ffhq"}[a.config]))
 
 
@@ -453,19 +464,16 @@ def main():
     gather_ms = []
 
     lanes = None
-    in_flight = a.in_flight or (2 if a.config == 2 else 1)
+    in_flight = a.in_flight or (2 if w["lane_solver"] is not None else 1)
     if in_flight > 1:
         # two batches in flight: consecutive steps go to two HIP streams, each with its own solver buffers / captured graphs / workspaces on the SAME weights
-        if a.config != 2:
-            raise SystemExit("--in-flight 2 is built for config 2")
-        from lfm_amd.solvers import GraphedFixedGrid, concurrency_twin, torchdiffeq_euler_grid
+        if w["lane_solver"] is None:
+            raise SystemExit("--in-flight 2 is built for the fixed-grid configurations (2, 5, 6)")
+        from lfm_amd.solvers import concurrency_twin
 
         lanes = [(solve, vae, x_dev, torch.cuda.Stream(dev))]
         for _ in range(in_flight - 1):
-            tm, tv = concurrency_twin(w["model"]), concurrency_twin(vae)
-            sv = GraphedFixedGrid(tm, B)
-            sv.set_grid(*torchdiffeq_euler_grid(1.0 / a.nfe))
-            lanes.append((sv.run, tv, torch.empty_like(x_dev), torch.cuda.Stream(dev)))
+            lanes.append((w["lane_solver"](concurrency_twin(w["model"])), concurrency_twin(vae), torch.empty_like(x_dev), torch.cuda.Stream(dev)))
         first = []
         for sol, va, xd, st in lanes:  # capture each lane's graphs and size its workspaces outside the counted steps
             st.wait_stream(torch.cuda.current_stream(dev))  # weights, packed operands and the per-grid tables were produced on the launching stream

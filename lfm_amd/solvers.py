@@ -589,7 +589,7 @@ def concurrency_twin(module):
     """A second handle on the SAME weights with its own device scratch (workspace, captured solver graphs), so that two batches can be in flight on two
     HIP streams: a sampling job's batches are independent (test_flow_latent_ddp.py:116-146), and two chip-filling evaluations launched side by side run
     ~5 % faster than one after the other -- while one stream's workgroups sit in their HBM-bound GEMM epilogues, the other's are in their MFMA main loops
-    (profiles/r04_two_batches_in_flight.txt).  Works for the DiT family and the VAE (modules whose scratch is `_ws` / `_fused_solvers`).  Take the twin AFTER
+    (profiles/r04_two_batches_in_flight.txt).  Works for the DiT family, the VAE and the two UNets (modules whose scratch is `_ws` / `_scratch` / `_conv_ws` / `_fused_solvers`).  Take the twin AFTER
     the weights are final: it shares the packed weight buffers of the original and does not follow a later load_state_dict.  The stream a twin (or the
     original) is then driven on must first wait for the stream its setup ran on (packing, set_grid's conditioning tables): `s.wait_stream(current)`."""
     import copy
@@ -598,8 +598,9 @@ def concurrency_twin(module):
         module._pack()  # pack once, share the buffers
     t = copy.copy(module)
     t.__dict__.pop("_fused_solvers", None)
-    if "_ws" in t.__dict__:
-        t._ws = None
+    for scratch in ("_ws", "_scratch", "_conv_ws", "_film_all"):  # DiT / VAE workspace; the UNets' GroupNorm / split-K scratch and FiLM rows (allocated on first use)
+        if scratch in t.__dict__:
+            setattr(t, scratch, None)
     return t
 
 

@@ -134,6 +134,8 @@ def build_parser():
     p = argparse.ArgumentParser("flow-matching parameters")
     p.add_argument("--generator", type=str, default="determ", choices=["dummy", "determ", "determ-indiv", "device"])
     p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--in_flight", type=int, default=0, help="(_ddp driver) batches in flight per GPU on alternating HIP streams; 0 = 2 on a GPU (bit-identical "
+                   "to 1: the batches of a job are independent), 1 = strictly one after the other")
     p.add_argument("--compute_fid", action="store_true", default=False)
     p.add_argument("--compute_nfe", action="store_true", default=False)
     p.add_argument("--measure_time", action="store_true", default=False)

@@ -69,6 +69,10 @@ class GatherPipeline:
         k = self.k
         self.k ^= 1
         if self.world == 1:
+            if self.cuda and u8.is_cuda:  # no collective, but the consumer may run on another stream than the producer (batches in flight on lanes)
+                done = torch.cuda.Event()
+                done.record(torch.cuda.current_stream(self.device))
+                return u8, done
             return u8
         if self.bufs[k] is None or self.bufs[k].shape[0] != self.world * u8.shape[0]:
             self.bufs[k] = torch.empty(self.world * u8.shape[0], *u8.shape[1:], dtype=u8.dtype, device=u8.device)
@@ -131,11 +135,34 @@ def run(args, model, vae, generator, rank, world, device, to_uint8, save=None, l
             stats.update(feats)
         stats.all_reduce()
         return {"total": total, "iters": iters, "written": written, "gather_seconds": 0.0, "fid_stats": stats}
+    # Batches in flight per GPU: the batches of a sampling job are independent (reference :128-146), so consecutive batches go to alternating HIP streams
+    # ("lanes": the same weights, own scratch and captured solver graphs -- solvers.concurrency_twin) and overlap on the chip; results are bit-identical to one
+    # lane (tests/test_gpu_cosched.py).  Noise is still drawn in batch order from the one generator, file indices and the gather order do not change.
+    n_lanes = int(getattr(args, "in_flight", 0) or 0) or (2 if torch.device(device).type == "cuda" else 1)
+    lanes = [(model, vae, None)]
+    if n_lanes > 1 and torch.device(device).type == "cuda":
+        from .solvers import concurrency_twin
+
+        cur = torch.cuda.current_stream(device)
+        lanes = []
+        for k in range(n_lanes):
+            st = torch.cuda.Stream(device)
+            st.wait_stream(cur)  # weights were loaded / packed on the launching stream
+            lanes.append((model if k == 0 else concurrency_twin(model), vae if k == 0 or vae is None else concurrency_twin(vae), st))
     for i in range(iters):
-        img = run_sampling(model, vae, args, args.batch_size, generator, device)
-        sink(pipe.submit(to_uint8(img)), i - 1)
+        mdl, va, st = lanes[i % len(lanes)]
+        if st is None:
+            img = run_sampling(mdl, va, args, args.batch_size, generator, device)
+            sink(pipe.submit(to_uint8(img)), i - 1)
+        else:
+            with torch.cuda.stream(st):
+                img = run_sampling(mdl, va, args, args.batch_size, generator, device)
+                sink(pipe.submit(to_uint8(img)), i - 1)  # the gather's side stream waits for THIS lane's stream
     sink(pipe.flush(), iters - 1)
-    return {"total": total, "iters": iters, "written": written, "gather_seconds": pipe.gather_seconds}
+    if lanes[0][2] is not None:
+        for _, _, st in lanes:
+            torch.cuda.current_stream(device).wait_stream(st)
+    return {"total": total, "iters": iters, "written": written, "gather_seconds": pipe.gather_seconds, "lanes": len(lanes)}
 
 
 def main(argv=None, hooks=None):
