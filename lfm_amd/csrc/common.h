@@ -98,18 +98,16 @@ __device__ __forceinline__ f32x2_t gelu_tanh_pk(f32x2_t x) {
   return x * r;
 }
 
-// a * b + c as ONE plain v_fma_f32 per element (inline asm: the compiler cannot re-pack it).  The row-affine epilogues of the folded LayerNorm path
-// (gemm_kernel.h: a[m] * acc + (b[m] * u[n] + v[n]) with (a, b) in a register pair) are written with it INSTEAD of the vector expression, for which the
+// a * b + c as ONE plain v_fma_f32 per element.  The row-affine epilogues of the folded LayerNorm path (gemm_kernel.h: a[m] * acc + (b[m] * u[n] + v[n])
+// with (a, b) in a register pair) are written element by element with it INSTEAD of the vector expression `ab.x * acc + (ab.y * u + v)`, for which the
 // compiler selects v_pk_fma_f32 with op_sel:[0,1,0] -- the LOW half of the packed operation takes src1 from the HIGH register of the pair.  On MI355X
 // that form sporadically evaluates with the operand read as 0.0 in lanes 48-63 when a foreign wave shares the SIMD (two HIP streams in flight): the
 // product term b * u vanished from ~500 elements per affected fc1 launch, 1-2 fp16 ulp in H (profiles/r05_cosched_root_cause.txt:
 // operand dump of the epilogue solo vs co-scheduled; 6 of 11-19 co-scheduled evaluations differ with the packed form in four builds, 0 of 24 and
-// 0 of the stress suite with this one).  tests/test_host_logic.py::test_no_packed_fp32_op_sel keeps every op_sel'd packed-fp32 form out of the library.
-__device__ __forceinline__ float fma_v(float a, float b, float c) {
-  float r;
-  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
+// 0 of the stress suite with scalar FMAs).  Scalar code stays scalar because the library is built with -fno-slp-vectorize (lfm_amd/_build.py);
+// tests/test_host_logic.py::test_no_packed_fp32_op_sel disassembles the built code objects and keeps every op_sel'd packed-fp32 form out of the library.
+// (Plain C, not inline asm: sixteen asm statements per pass pushed the one-wave-per-SIMD QKV kernel's accumulator view into scratch memory.)
+__device__ __forceinline__ float fma_v(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 // a * acc + (b * u + v), four columns of one row
 __device__ __forceinline__ f32x4 row_affine4(float a, float b, f32x4 acc, f32x4 u, f32x4 v) {
   return (f32x4){fma_v(a, acc.x, fma_v(b, u.x, v.x)), fma_v(a, acc.y, fma_v(b, u.y, v.y)), fma_v(a, acc.z, fma_v(b, u.z, v.z)), fma_v(a, acc.w, fma_v(b, u.w, v.w))};

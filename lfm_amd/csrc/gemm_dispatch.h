@@ -52,3 +52,14 @@ static inline int launch_gemm_auto(const ASrc& asrc, const half_t* W, long ldw, 
     return launch_gemm256h_tn(asrc, W, ldw, M, N, K, epi, stream, batch, bsA, bsW, bsC);
   return launch_gemm_tn(asrc, W, ldw, M, N, K, epi, stream, batch, bsA, bsW, bsC);
 }
+
+// slices of a deep small-map problem on the 256x256 kernel (declared in gemm_kernel.h, which the 256x256 kernels include): slice bz = K range
+// [bz ks, (bz + 1) ks) through the batch index, fp32 partial tile into slab[bz].  Returns 1 when the A source cannot take the kernel.
+template <class ASrc, class Epi>
+static inline int launch_gemm_splitk256(const ASrc& asrc, const half_t* W, long ldw, int M, int N, int ks, const EpiSlabF32& e, hipStream_t stream, int S) {
+  if ((long)N * ldw >= (1L << 31)) return 1;
+  if constexpr (asrc_has_buffer<ASrc>::value) {
+    if (!asrc_fits_buffer(asrc, 0)) return 1;
+  }
+  return launch_gemm256h_tn(asrc, W, ldw, M, N, ks, e, stream, S, ks, ks, 0);
+}

@@ -822,10 +822,40 @@ static inline int splitk_slices(int M, int N, int K, size_t slab_bytes, int max_
 // returns LFM_OK after launching both kernels, or 1 if split-K does not apply (the caller then takes the ordinary path).
 // Slices are addressed through the batch index: asrc.init(bz, ks) makes slice bz start at k = bz * ks (row-major A advances its
 // pointer; an implicit-GEMM convolution source starts its tap / channel walk there), W advances by ks columns.
+// Round 5: slices of DEEP small-map problems (the UNets' 8x8 / 16x16-map 3x3 convolutions: M = 2048 .. 8192 pixel rows, K = 9 Cin = 4608 .. 18432) on the
+// 256x256 eight-wave kernel instead of the 128x128 one: its main loop runs at ~1.3 PFLOP/s where the 128x128 loop reaches 0.45-0.75
+// (profiles/r04_conv_small_maps_probe.txt), and a slice that is >= 24 K-tiles deep amortises its longer prologue / epilogue.  S = the largest divisor
+// of the K-tile count that keeps tiles x S <= 256 workgroups (one per CU) with slices >= `min_tiles_k` K-tiles.  0 = does not apply.
+int lfm_gemm_debug_flags();
+static inline int splitk256_slices(int M, int N, int K, size_t slab_bytes, int min_tiles_k = 24) {
+  if (M < 2048 || N < 256 || (N % 256) != 0 || (K % 64) != 0 || (lfm_gemm_debug_flags() & 268435456)) return 0;  // flag 268435456: the 128x128 slices (A/B)
+  const long tiles = (long)cdiv(M, 256) * (N / 256);
+  if (tiles > 128) return 0;
+  const int kt = K / 64;
+  int best = 0;
+  for (int sl = 2; sl <= 16; ++sl)
+    if (kt % sl == 0 && tiles * sl <= 256 && kt / sl >= min_tiles_k && (size_t)sl * M * N * 4 <= slab_bytes) best = sl;
+  return best;
+}
+template <class ASrc, class Epi>
+static inline int launch_gemm_splitk256(const ASrc& asrc, const half_t* W, long ldw, int M, int N, int ks, const EpiSlabF32& e, hipStream_t stream, int S);
+
 template <class ASrc, class Epi>
 static inline int launch_gemm_splitk_src(const ASrc& asrc, const half_t* W, long ldw, int M, int N, int K, const Epi& epi, float* slab,
                                          size_t slab_bytes, hipStream_t stream, int max_tiles = 64, int max_wg = 256) {
   if (!slab || lfm_gemm_selected_v1_ok() == 0) return 1;
+  if (const int S2 = splitk256_slices(M, N, K, slab_bytes)) {
+    const int ks = K / S2;
+    const long stride = (long)M * N;
+    const int rc = launch_gemm_splitk256<ASrc, Epi>(asrc, W, ldw, M, N, ks, EpiSlabF32{slab, (long)N, stride}, stream, S2);
+    if (rc != 1) {
+      if (rc) return rc;
+      const long work = (long)M * (N >> 2);
+      hipLaunchKernelGGL((splitk_finish_kernel<Epi>), dim3((unsigned)cdiv(work, 256)), dim3(256), 0, stream, slab, S2, stride, M, N, epi);
+      LFM_CHECK_LAUNCH();
+      return LFM_OK;
+    }
+  }
   const int S = splitk_slices(M, N, K, slab_bytes, max_tiles, max_wg);
   if (S < 2) return 1;
   const int ks = K / S;

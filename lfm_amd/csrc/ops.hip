@@ -130,9 +130,11 @@ extern "C" size_t lfm_conv3x3_workspace_bytes(int N, int H, int W, int Cin, int 
   const long M = (long)N * H * W;
   if (M <= 0 || Cout <= 0 || Cin <= 0) return 0;
   const long tiles = (long)cdiv(M, 128) * cdiv(Cout, 128);
-  if (tiles > CONV_SPLITK_MAX_TILES) return 0;
+  const int s256 = M < (1L << 30) ? splitk256_slices((int)M, Cout, 9 * Cin, (size_t)-1) : 0;  // slices on the 256x256 kernel (gemm_kernel.h), if the shape takes it
   int s = 1;
-  while (tiles * (s * 2) <= CONV_SPLITK_MAX_WG && (9L * Cin) / (s * 2) >= 128 && ((9L * Cin) / (s * 2)) % 64 == 0) s *= 2;
+  if (tiles <= CONV_SPLITK_MAX_TILES)
+    while (tiles * (s * 2) <= CONV_SPLITK_MAX_WG && (9L * Cin) / (s * 2) >= 128 && ((9L * Cin) / (s * 2)) % 64 == 0) s *= 2;
+  if (s256 > s) s = s256;
   return s < 2 ? 0 : (size_t)s * M * Cout * 4;
 }
 
