@@ -67,9 +67,9 @@ def parse():
                         "random field stiff enough for dopri5 at 1e-5 to take >= 15 steps (92 NFE) -- the solver-loop stress variant of profiles/r03_config3_*")
     p.add_argument("--in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4],
                    help="batches in flight per GPU: 2 = consecutive steps alternate between two HIP streams with their own scratch (same weights, bit-identical "
-                        "per-batch results: tests/test_gpu_cosched.py); 0 = the configuration's default -- 2 for the fixed-grid configurations 2, 5, 6 (a sampling "
+                        "per-batch results: tests/test_gpu_cosched.py); 0 = the configuration's default -- 2 for the fixed-grid configurations 2, 4, 5, 6 (a sampling "
                         "job's batches are independent, test_flow_latent_ddp.py:128-146; while one lane's workgroups sit in their HBM-bound epilogues or run a "
-                        "small-map kernel that cannot fill the chip, the other lane's kernels use it), 1 for configs 3 / 4.  Rounds 1-4 reported one batch in "
+                        "small-map kernel that cannot fill the chip, the other lane's kernels use it), 1 for config 3 (dopri5 reads a value back per step).  Rounds 1-4 reported one batch in "
                         "flight: --in-flight 1 reproduces that line")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
@@ -232,10 +232,15 @@ def build_workload(a, dev, rank):
         else:
             from lfm_amd.sampler.karras_sample import karras_sample
 
-            def solve(x):
-                xx = torch.cat([x, x], 0)
-                return karras_sample(model, xx, steps=50, model_kwargs=dict(y=y, cfg_scale=1.5), device=dev, clip_denoised=False, sigma_min=1e-5,
-                                     sigma_max=1.0, s_tmin=0.0, s_tmax=1.0, s_churn=0.0, sampler="heun")[:B]
+            def lane_solver(mod):  # the fused Karras solver caches its buffers / graphs on the module object: a twin gets its own
+                def run(x):
+                    xx = torch.cat([x, x], 0)
+                    return karras_sample(mod, xx, steps=50, model_kwargs=dict(y=y, cfg_scale=1.5), device=dev, clip_denoised=False, sigma_min=1e-5,
+                                         sigma_max=1.0, s_tmin=0.0, s_tmax=1.0, s_churn=0.0, sampler="heun")[:B]
+
+                return run
+
+            solve = lane_solver(model)
 
             f_model = 88 * per_eval
             extra["nfe"] = 88
@@ -506,7 +511,7 @@ def main():
     if in_flight > 1:
         # two batches in flight: consecutive steps go to two HIP streams, each with its own solver buffers / captured graphs / workspaces on the SAME weights
         if w["lane_solver"] is None:
-            raise SystemExit("--in-flight 2 is built for the fixed-grid configurations (2, 5, 6)")
+            raise SystemExit("--in-flight 2 is built for the fixed-grid configurations (2, 4, 5, 6)")
         from lfm_amd.solvers import concurrency_twin
 
         lanes = [(solve, vae, x_dev, torch.cuda.Stream(dev))]

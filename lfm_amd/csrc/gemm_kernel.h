@@ -828,7 +828,7 @@ static inline int splitk_slices(int M, int N, int K, size_t slab_bytes, int max_
 // of the K-tile count that keeps tiles x S <= 256 workgroups (one per CU) with slices >= `min_tiles_k` K-tiles.  0 = does not apply.
 int lfm_gemm_debug_flags();
 static inline int splitk256_slices(int M, int N, int K, size_t slab_bytes, int min_tiles_k = 24) {
-  if (M < 2048 || N < 256 || (N % 256) != 0 || (K % 64) != 0 || (lfm_gemm_debug_flags() & 268435456)) return 0;  // flag 268435456: the 128x128 slices (A/B)
+  if (M < 2048 || N < 256 || (N % 256) != 0 || (K % 64) != 0 || (lfm_gemm_debug_flags() & 65536)) return 0;  // flag 65536: the 128x128 slices (A/B)
   const long tiles = (long)cdiv(M, 256) * (N / 256);
   if (tiles > 128) return 0;
   const int kt = K / 64;

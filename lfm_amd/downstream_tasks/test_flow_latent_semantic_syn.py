@@ -2,8 +2,9 @@
 
 Per batch (reference :130-140): one-hot label map -> ``SpatialRescaler`` (three bilinear x0.5 stages + a 1x1 channel mapper,
 models/encoder.py:90-112) -> 4-channel conditioning latent at the latent resolution, concatenated to the state (8 input channels of the
-origin-ADM UNet); integrate from noise; decode.  The rescaler is a few hundred kFLOP per image and stays torch ops on the GPU (plumbing);
-the UNet velocity field and the VAE decode run on the HIP path."""
+origin-ADM UNet); integrate from noise; decode.  The rescaler is a few hundred kFLOP per image: its bilinear resampling stays a torch elementwise op
+(data preparation), its 1x1 channel mapper runs on the library's MFMA GEMM (``lfm_gemm_f16``, fp16 hi + lo split operands: the fp32 product to 2^-21) --
+no vendor BLAS / MIOpen call on the product path; the UNet velocity field and the VAE decode run on the HIP path."""
 from functools import partial
 
 import torch
@@ -29,7 +30,30 @@ class SpatialRescaler(nn.Module):
     def forward(self, x):
         for _ in range(self.n_stages):
             x = self.interpolator(x, scale_factor=self.multiplier)
-        return self.channel_mapper(x) if self.remap_output else x
+        if not self.remap_output:
+            return x
+        return self._map_channels_hip(x) if x.is_cuda else self.channel_mapper(x)  # (CPU tensors: the oracle side of the tests)
+
+    def _map_channels_hip(self, x):
+        """The 1x1 ``channel_mapper`` convolution as C[pixels, Cout] = X[pixels, Cin] W^T on lfm_gemm_f16 (fp32 accumulate, fp32 output).  Activation and
+        weight are split into fp16 hi + lo parts and three products are summed (hi hi + lo hi + hi lo; the dropped lo lo term is 2^-22 relative): the
+        fp32 convolution of the reference to rounding, like the library's own input / output layers."""
+        from .. import hip
+
+        N, Cin, h, w = x.shape
+        Cout = self.channel_mapper.out_channels
+        K, Np = -(-Cin // 64) * 64, -(-Cout // 4) * 4  # the GEMM kernel's K-tile depth / 4-column granularity
+        a32 = torch.zeros(N * h * w, K, device=x.device, dtype=torch.float32)
+        a32[:, :Cin] = x.permute(0, 2, 3, 1).reshape(-1, Cin)
+        w32 = torch.zeros(Np, K, device=x.device, dtype=torch.float32)
+        w32[:Cout, :Cin] = self.channel_mapper.weight.detach().reshape(Cout, Cin).to(x.device, torch.float32)
+        a_hi, w_hi = a32.half(), w32.half()
+        a_lo, w_lo = (a32 - a_hi.float()).half(), (w32 - w_hi.float()).half()
+        bias = torch.zeros(Np, device=x.device)
+        if self.channel_mapper.bias is not None:
+            bias[:Cout] = self.channel_mapper.bias.detach().to(x.device, torch.float32)
+        out = hip.gemm_f16(a_hi, w_hi, bias, epilogue=2) + hip.gemm_f16(a_lo, w_hi, None, epilogue=2) + hip.gemm_f16(a_hi, w_lo, None, epilogue=2)
+        return out[:, :Cout].reshape(N, h, w, Cout).permute(0, 3, 1, 2).contiguous()
 
     def encode(self, x):
         return self(x)

@@ -1,5 +1,5 @@
 """Split-K slices of the UNets' deep small-map 3x3 convolutions on the 256x256 kernel (round 5, gemm_kernel.h: splitk256_slices) against the 128x128 slices
-(flag 268435456), through lfm_conv3x3_f16_ws with the workspace the models pass.   Usage: python tools/splitk256_probe.py [reps]"""
+(flag 65536), through lfm_conv3x3_f16_ws with the workspace the models pass.   Usage: python tools/splitk256_probe.py [reps]"""
 import os
 import sys
 
@@ -22,7 +22,7 @@ for N, H, W, Cin, Cout in SHAPES:
     ws = torch.empty(max(wsb, 16), device=dev, dtype=torch.uint8)
     flop = 2.0 * N * H * W * Cout * 9 * Cin
     res, outs = {}, {}
-    for name, flags in (("256x256 slices", 0), ("128x128 slices", 268435456)):
+    for name, flags in (("256x256 slices", 0), ("128x128 slices", 65536)):
         out = torch.empty(N * H * W, Cout, device=dev, dtype=torch.float16)
         hip.gemm_select(flags << 4)
 
