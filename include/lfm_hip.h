@@ -168,6 +168,9 @@ int lfm_profile_blocks_read(float* host_ms_out, int max_n);
 /* key 2 (LFM_OPT_GEMM_V6), value 0 / 1: the chip-filling row-major GEMMs (the four linears of a DiT block) on the one-wave-per-SIMD 256x256 kernel
  * (csrc/gemm256w_kernel.h) instead of the eight-wave one.  Same accumulation order per output element: bit-identical results. */
 #define LFM_OPT_GEMM_V6 2
+/* key 4 (LFM_OPT_SKINNY_GEMM), value 0 / 1, default 1: evaluations of ONE image of <= 256 tokens (--measure_time, test_flow_latent.py:223-246) run the four
+ * linears of a DiTBlock on the all-rows x 16-columns kernel (csrc/gemm_skinny_kernel.h); 0 = the split-K 128x128 path (A/B and parity tests). */
+#define LFM_OPT_SKINNY_GEMM 4
 int lfm_set_option(int key, int value);
 /* The settings lfm_dit_forward would run `call` with if it were enqueued by the calling thread now (per-call fields over the library defaults):
  * *gemm_select_out = kernel | flags << 4, *fold_ln_out = 0 / 1.  No launch; usable without a GPU. */

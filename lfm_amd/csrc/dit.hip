@@ -2,6 +2,7 @@
 // Reference behaviour: /root/reference/models/DiT.py (cited per kernel).
 #include "../../include/lfm_hip.h"
 #include "gemm_dispatch.h"
+#include "gemm_skinny_kernel.h"
 
 // Library-wide switches = process-wide DEFAULTS (lfm_gemm_select, lfm_set_option); a call that carries its own values (lfm_dit_call.fold_ln /
 // .gemm_select, ABI 4) overrides them in THREAD-LOCAL state for the duration of lfm_dit_forward: every launcher reads the effective value on the
@@ -27,6 +28,7 @@ int lfm_gemm_prefers_v4(int M, int N, int K) {
 }
 static int g_opt_v6 = 0;
 int lfm_gemm_v6_default() { return g_opt_v6; }
+static int g_opt_skinny = 1;  // LFM_OPT_SKINNY_GEMM: the all-rows x 16-columns kernel for the batch-1 DiT linears (gemm_skinny_kernel.h)
 static int g_stagger = 0;
 int lfm_stagger_ticks() { return g_stagger; }
 static inline bool gemm_select_valid(int which) {
@@ -74,6 +76,10 @@ extern "C" int lfm_set_option(int key, int value) {  // key 1 (LFM_OPT_FOLD_LN):
   }
   if (key == 2) {  // LFM_OPT_GEMM_V6: the one-wave-per-SIMD 256x256 kernel for the chip-filling row-major GEMMs
     g_opt_v6 = value != 0;
+    return LFM_OK;
+  }
+  if (key == 4) {  // LFM_OPT_SKINNY_GEMM: 0 = the split-K 128x128 path of rounds 2-4 for M <= 256 (A/B, parity)
+    g_opt_skinny = value != 0;
     return LFM_OK;
   }
 #ifdef LFM_MEASURE
@@ -1431,6 +1437,17 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
     }
   }
 #undef DIT_CHK
+  // Latency mode (one image of <= 256 tokens): the four linears of a block on the skinny kernel (gemm_skinny_kernel.h): qkv / fc1 with their epilogues in the
+  // kernel, proj / fc2 as K-slices (256 workgroups) into the slabs of the row-owning finish + LayerNorm kernel
+  auto sk_slices = [&](int N_, int K_) {  // K-slices so that column slices x slices ~ 256 workgroups; slabs must fit
+    int sl = 1;
+    while ((N_ / SK_BN) * (sl * 2) <= 256 && (K_ % (sl * 2 * SK_BK)) == 0 && K_ / (sl * 2) >= 2 * SK_BK && (size_t)(sl * 2) * M * N_ * 4 <= ws.slab_bytes) sl *= 2;
+    return sl;
+  };
+  const int sk_s_proj = sk_slices(D, D), sk_s_fc2 = sk_slices(D, H);
+  const bool skinny = !fold && g_opt_skinny && g_gemm_sel == 0 && M <= SK_ROWS && ws.slab && D <= 1024 * SPLITK_LN_MAXJ && (D % 4) == 0 &&
+                      gemm_skinny_ok(ws.A, D, w->qkv_w, D, M, 3 * D, D, 1) && gemm_skinny_ok(ws.A, D, w->fc1_w, D, M, H, D, 1) &&
+                      gemm_skinny_ok(ws.A, D, w->proj_w, D, M, D, D, sk_s_proj) && gemm_skinny_ok(ws.QKVH, H, w->fc2_w, H, M, D, H, sk_s_fc2);
   bool a_ready = false;  // latency mode: the previous split-K finish already wrote this LayerNorm's output
   for (int i = 0; i < (fold ? 0 : s->depth); ++i) {
     const float* mod = ws.mod + (long)i * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
@@ -1440,15 +1457,25 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
     }
     a_ready = false;
     const EpiQKV e_qkv = EpiQKV::make(Qb, Kb, Vb, w->qkv_b + (size_t)i * 3 * D, D, D / s->heads, T);
-    rc = launch_gemm_splitk(ws.A, D, (const half_t*)w->qkv_w + (size_t)i * 3 * D * D, D, M, 3 * D, D, e_qkv, ws.slab, ws.slab_bytes, st);
-    if (rc == 1) rc = launch_gemm_auto(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->qkv_w + (size_t)i * 3 * D * D, D, M, 3 * D, D, e_qkv, st);
+    if (skinny) rc = launch_gemm_skinny(ws.A, D, (const half_t*)w->qkv_w + (size_t)i * 3 * D * D, D, M, 3 * D, D, e_qkv, 1, st);
+    else {
+      rc = launch_gemm_splitk(ws.A, D, (const half_t*)w->qkv_w + (size_t)i * 3 * D * D, D, M, 3 * D, D, e_qkv, ws.slab, ws.slab_bytes, st);
+      if (rc == 1) rc = launch_gemm_auto(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->qkv_w + (size_t)i * 3 * D * D, D, M, 3 * D, D, e_qkv, st);
+    }
     if (rc) return rc;
     rc = attention_launch(Qb, Kb, Vb, ws.A, B, s->heads, D / s->heads, T, st);
     if (rc) return rc;
     const EpiGateResidF32 e_proj{ws.X, D, w->proj_b + (size_t)i * D, mod + 2 * D, mstride, T};
     // small M: split-K whose finish kernel is also the LayerNorm-modulate in front of fc1 (its input ws.A is consumed by the slab GEMM before the finish writes it)
-    rc = launch_gemm_splitk_resid_ln(ws.A, D, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D, e_proj, ws.A, mod + 3 * D, mod + 4 * D, mstride, ws.slab,
-                                     ws.slab_bytes, st);
+    if (skinny) {  // K-slices of the skinny kernel into slabs, then the row-owning finish that is also the LayerNorm-modulate in front of fc1
+      rc = launch_gemm_skinny(ws.A, D, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D, EpiSlabF32{ws.slab, (long)D, (long)M * D}, sk_s_proj, st);
+      if (rc) return rc;
+      hipLaunchKernelGGL(splitk_finish_resid_ln_kernel, dim3(M), dim3(256), 0, st, ws.slab, sk_s_proj, (long)M * D, D, e_proj.X, e_proj.ldx, e_proj.bias, e_proj.gate,
+                         e_proj.gate_stride, e_proj.tokens, ws.A, mod + 3 * D, mod + 4 * D, mstride);
+      LFM_CHECK_LAUNCH();
+    } else
+      rc = launch_gemm_splitk_resid_ln(ws.A, D, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D, e_proj, ws.A, mod + 3 * D, mod + 4 * D, mstride, ws.slab,
+                                       ws.slab_bytes, st);
     if (rc == 1) {
       rc = launch_gemm_auto(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D, e_proj, st);
       if (rc) return rc;
@@ -1458,14 +1485,24 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
     const bool prof = prof_ok && g_prof_mode == 1 && g_prof_count < LFM_PROF_MAX;
     if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_count], st);
     const EpiBiasGeluF16 e_fc1{ws.QKVH, H, w->fc1_b + (size_t)i * H};
-    rc = launch_gemm_splitk(ws.A, D, (const half_t*)w->fc1_w + (size_t)i * H * D, D, M, H, D, e_fc1, ws.slab, ws.slab_bytes, st);
-    if (rc == 1) rc = launch_gemm_auto(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->fc1_w + (size_t)i * H * D, D, M, H, D, e_fc1, st);
+    if (skinny) rc = launch_gemm_skinny(ws.A, D, (const half_t*)w->fc1_w + (size_t)i * H * D, D, M, H, D, e_fc1, 1, st);
+    else {
+      rc = launch_gemm_splitk(ws.A, D, (const half_t*)w->fc1_w + (size_t)i * H * D, D, M, H, D, e_fc1, ws.slab, ws.slab_bytes, st);
+      if (rc == 1) rc = launch_gemm_auto(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->fc1_w + (size_t)i * H * D, D, M, H, D, e_fc1, st);
+    }
     if (rc) return rc;
     if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_count++ + 1], st);
     const EpiGateResidF32 e_fc2{ws.X, D, w->fc2_b + (size_t)i * D, mod + 5 * D, mstride, T};
     const bool more = i + 1 < s->depth;  // ... and the one in front of the NEXT block's qkv (its shift_msa / scale_msa)
-    rc = launch_gemm_splitk_resid_ln(ws.QKVH, H, (const half_t*)w->fc2_w + (size_t)i * D * H, H, M, D, H, e_fc2, more ? ws.A : (half_t*)nullptr, mod + 6 * D, mod + 7 * D,
-                                     mstride, ws.slab, ws.slab_bytes, st);
+    if (skinny) {
+      rc = launch_gemm_skinny(ws.QKVH, H, (const half_t*)w->fc2_w + (size_t)i * D * H, H, M, D, H, EpiSlabF32{ws.slab, (long)D, (long)M * D}, sk_s_fc2, st);
+      if (rc) return rc;
+      hipLaunchKernelGGL(splitk_finish_resid_ln_kernel, dim3(M), dim3(256), 0, st, ws.slab, sk_s_fc2, (long)M * D, D, e_fc2.X, e_fc2.ldx, e_fc2.bias, e_fc2.gate,
+                         e_fc2.gate_stride, e_fc2.tokens, more ? ws.A : (half_t*)nullptr, mod + 6 * D, mod + 7 * D, mstride);
+      LFM_CHECK_LAUNCH();
+    } else
+      rc = launch_gemm_splitk_resid_ln(ws.QKVH, H, (const half_t*)w->fc2_w + (size_t)i * D * H, H, M, D, H, e_fc2, more ? ws.A : (half_t*)nullptr, mod + 6 * D, mod + 7 * D,
+                                       mstride, ws.slab, ws.slab_bytes, st);
     if (rc == LFM_OK) a_ready = more;
     if (rc == 1) rc = launch_gemm_auto(ASrcRowMajor{ws.QKVH, H, M, 0}, (const half_t*)w->fc2_w + (size_t)i * D * H, H, M, D, H, e_fc2, st);
     if (rc) return rc;

@@ -338,6 +338,44 @@ def test_dit_matches_oracle_fullsize(dev, name, batch, kw):
 
 
 @pytest.mark.parametrize("name,batch,kw", [
+    ("DiT-L/2", 1, dict(num_classes=1, label_dropout=0.0)),      # the reference's --measure_time configuration (test_flow_latent.py:223-246)
+    ("DiT-S/2", 1, dict(num_classes=10, label_dropout=0.1)),     # 384 wide: 24 / 72 / 96 column slices, two K-slices for proj / fc2
+    ("DiT-XL/2", 1, dict(num_classes=1000, label_dropout=0.1)),  # 1152 wide, head_dim 72, two column groups per thread in the finish
+    ("DiT-B/4", 3, dict(num_classes=1, label_dropout=0.0)),      # three images of 64 tokens: 192 rows (ragged against the kernel's 256), patch-4 embedding
+])
+def test_skinny_latency_kernel_vs_splitk_path_and_oracle(dev, name, batch, kw):
+    """Evaluations of <= 256 token rows run their four block linears on the all-rows x 16-columns kernel (csrc/gemm_skinny_kernel.h, default): the same
+    forward as the split-K 128x128 path of rounds 2-4 (lfm_set_option(LFM_OPT_SKINNY_GEMM, 0)) up to the fp32 summation order, bit-repeatable, and inside
+    the per-forward budget against the CPU oracle."""
+    from lfm_amd import hip
+    from lfm_amd.models import DiT_models
+
+    cfg = dit_ref.DiTCfg.named(name, **kw)
+    sd = dit_ref.make_dit_state(cfg, seed=3)
+    m = DiT_models[name](img_resolution=32, in_channels=4, **kw)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).eval()
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(batch, 4, 32, 32, generator=g)
+    y = torch.randint(0, kw["num_classes"], (batch,), generator=g) if kw["num_classes"] > 1 else None
+    t = torch.tensor(0.37)
+    xd, td, yd = x.to(dev), t.to(dev), (y.to(dev) if y is not None else None)
+    a = m(td, xd, yd).clone()
+    b = m(td, xd, yd).clone()
+    hip.set_option(hip.OPT_SKINNY_GEMM, 0)
+    try:
+        old = m(td, xd, yd).clone()
+    finally:
+        hip.set_option(hip.OPT_SKINNY_GEMM, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    assert not torch.equal(a, old), "the skinny kernel did not run (preconditions?)"
+    assert rel_l2(a, old) < 2e-4  # same fp16 operands, fp32 accumulation in another order
+    ref = dit_ref.dit_forward(sd, cfg, t, x, y)
+    assert rel_l2(a, ref) < 2e-3 and rel_l2(old, ref) < 2e-3
+
+
+@pytest.mark.parametrize("name,batch,kw", [
     ("DiT-S/2", 3, dict(num_classes=10, label_dropout=0.1)),     # 384 wide: the 128x128 GEMM tiles
     ("DiT-L/2", 2, dict(num_classes=1, label_dropout=0.0)),      # 1024 wide: the 256x256 tiles and the folded LayerNorm-modulate over 1024-token images
     ("DiT-XL/2", 1, dict(num_classes=1000, label_dropout=0.1)),  # head_dim 72
