@@ -835,7 +835,9 @@ static inline int splitk256_slices(int M, int N, int K, size_t slab_bytes, int m
   int best = 0;
   for (int sl = 2; sl <= 16; ++sl)
     if (kt % sl == 0 && tiles * sl <= 256 && kt / sl >= min_tiles_k && (size_t)sl * M * N * 4 <= slab_bytes) best = sl;
-  return best;
+  // at least half the CUs busy, or the many small 128x128 slices win (tools/splitk256_probe.py: 512 -> 512 channels at 8x8 x 32 images = 16 tiles x 3
+  // slices = 48 workgroups: 47.8 us against 27.0 us; 768 -> 768 at 8x8 x 64 images = 144 workgroups: 66.6 against 79.1 us)
+  return tiles * best >= 128 ? best : 0;
 }
 template <class ASrc, class Epi>
 static inline int launch_gemm_splitk256(const ASrc& asrc, const half_t* W, long ldw, int M, int N, int ks, const EpiSlabF32& e, hipStream_t stream, int S);

@@ -9,8 +9,12 @@
 //     workgroup; A (256 x K fp16, 0.5 MB at K = 1024) comes out of the L2 -- 256 workgroups x 0.5 MB = 128 MB of L2 traffic per GEMM, ~4.5 us at the
 //     48 B/clk/CU that eight waves of buffer-addressed LDS-DMA sustain (tools/ubench/ldsdma_rate.hip);
 //   * eight waves: all of them stage (thread tid moves 16-byte chunk tid & 7 of rows (tid >> 3) + 64 j, j = 0..3, of a 64-deep K-tile: 32 KiB of A
-//     plus 2 KiB of W per stage, four stages = 136 KiB of LDS, three K-tiles in flight behind counted vmcnt waits, ONE barrier per K-tile), wave w
-//     multiplies M-tiles 2 w, 2 w + 1 (v_mfma_f32_16x16x32_f16, W as the A operand: a lane owns four consecutive n of one row);
+//     per stage, four stages, three K-tiles in flight behind counted vmcnt waits, ONE barrier per K-tile), wave w multiplies M-tiles 2 w, 2 w + 1
+//     (v_mfma_f32_16x16x32_f16, W as the A operand: a lane owns four consecutive n of one row);
+//   * WPRE (K-slice <= 1024): the workgroup's WHOLE W slice (16 x K-slice, <= 32 KiB) is requested up front, before the first A tile.  W comes from
+//     HBM (first touch), A from the L2: with W staged tile by tile behind a three-tile lookahead the kernel was an HBM-LATENCY chain (first build:
+//     12.0 us per K = 1024 GEMM = 20 B/clk/CU of A streaming); requested at once the slice costs one HBM round trip.  4 x 32 KiB + 32 KiB = the CU's
+//     160 KiB of LDS.  Without WPRE (DiT-XL: K = 1152) W travels with its A tile: 2 KiB per stage;
 //   * LDS image as every 128-byte-row kernel here: chunk c of row r at c ^ ((r >> 1) & 7), swizzle on the DMA source and on the fragment read;
 //   * epilogue straight from the accumulators through the shared Epi interface (EpiQKV / EpiBiasGeluF16 in-kernel: no slab, no finish launch);
 //   * grid.y > 1 slices K (proj / fc2: 64 column slices x 4 K-slices = 256 workgroups) into fp32 slabs (EpiSlabF32) for the row-owning finish kernel
@@ -30,10 +34,15 @@
 
 typedef float sk_f32x4 __attribute__((ext_vector_type(4)));
 
-template <class Epi>
+#define SK_WPRE_MAX_KS 1024
+#define SK_LDS_BYTES_WPRE (SK_STAGES * SK_A_BYTES + SK_BN * SK_WPRE_MAX_KS * 2)
+
+template <class Epi, bool WPRE>
 __global__ __launch_bounds__(512) void gemm_skinny_kernel(const half_t* __restrict__ A, long lda, const half_t* __restrict__ W, long ldw, int M, int N, int Ks,
                                                           Epi epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int STAGE = WPRE ? SK_A_BYTES : SK_STAGE_BYTES;  // bytes per ring stage
+  constexpr int WBASE = WPRE ? SK_STAGES * SK_A_BYTES : SK_A_BYTES;  // WPRE: one region behind the ring, tile kt at + 2048 kt; else inside the stage
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n0 = blockIdx.x * SK_BN, bz = blockIdx.y;
   epi_batch(epi, bz, 0, 0);
@@ -48,15 +57,25 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(const half_t* __restri
     const int r = (tid >> 3) + 64 * j;
     avoff[j] = ((unsigned)(r < M ? r : M - 1) * (unsigned)lda + cswz) * 2u;
   }
-  const int wr = n0 + (tid >> 3);  // waves 0, 1 stage the 16 W rows (tid < 128)
-  const unsigned wvoff = ((unsigned)(wr < N ? wr : N - 1) * (unsigned)ldw + cswz) * 2u;
   const int nk = Ks / SK_BK;
+  if constexpr (WPRE) {
+    // the whole W slice first: 2 nk DMAs of 1 KiB (8 rows x 128 B) dealt round-robin to the eight waves -- DMA d = 2 kt + h moves rows 8 h .. 8 h + 7 of
+    // K-tile kt; d = wave (mod 8), so h = wave & 1 is fixed per wave.  Issued before every A tile: loads return in order, so the first counted wait
+    // below already implies them (the per-wave counts need not be equal).
+    const int h = wave & 1, wr = n0 + 8 * h + (lane >> 3);
+    const unsigned wv = ((unsigned)(wr < N ? wr : N - 1) * (unsigned)ldw + (unsigned)(((lane & 7) ^ ((4 * h + (lane >> 4)) & 7)) * 8)) * 2u;
+    for (int d = wave; d < 2 * nk; d += 8) glds16_buf(rsw, wv, (kbase + (unsigned)(d >> 1) * SK_BK) * 2u, smem + WBASE + d * 1024);
+  }
+  const int wr_t = n0 + (tid >> 3);  // (!WPRE) waves 0, 1 stage the 16 W rows of a tile (tid < 128)
+  const unsigned wvoff = ((unsigned)(wr_t < N ? wr_t : N - 1) * (unsigned)ldw + cswz) * 2u;
   auto issue = [&](int kt) {
-    char* st = smem + (kt % SK_STAGES) * SK_STAGE_BYTES;
+    char* st = smem + (kt % SK_STAGES) * STAGE;
     const unsigned soff = (kbase + (unsigned)kt * SK_BK) * 2u;
 #pragma unroll
     for (int j = 0; j < 4; ++j) glds16_buf(rsa, avoff[j], soff, st + j * 8192 + wave * 1024);
-    if (wave < 2) glds16_buf(rsw, wvoff, soff, st + SK_A_BYTES + wave * 1024);
+    if constexpr (!WPRE) {
+      if (wave < 2) glds16_buf(rsw, wvoff, soff, st + SK_A_BYTES + wave * 1024);
+    }
   };
   // ---- fragment read addresses: lane (r = lane & 15, q = lane >> 4) reads logical chunk 4 ks + q of row base + r
   const int rkey = ((lane & 15) >> 1) & 7, q4 = lane >> 4;
@@ -65,15 +84,15 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(const half_t* __restri
   for (int ks = 0; ks < 2; ++ks) {
     const int ch = ((ks * 4 + q4) ^ rkey) << 4;
     fa[ks] = (32 * wave + (lane & 15)) * 128 + ch;  // + 2048 for the wave's second M-tile
-    fw[ks] = SK_A_BYTES + (lane & 15) * 128 + ch;
+    fw[ks] = WBASE + (lane & 15) * 128 + ch;
   }
   sk_f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #define SK_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
   for (int t = 0; t < 3 && t < nk; ++t) issue(t);
   for (int t = 0; t < nk; ++t) {
-    // K-tile t has landed: this thread's DMAs of the (at most two) later tiles may still be in flight -- 5 per tile for the W-staging waves, 4 for the others
+    // K-tile t has landed: this thread's DMAs of the (at most two) later tiles may still be in flight -- 4 per tile (5 for the W-staging waves of !WPRE)
     const int later = nk - 1 - t < 2 ? nk - 1 - t : 2;
-    if (wave < 2) {
+    if (!WPRE && wave < 2) {
       if (later == 2) SK_VMCNT(10);
       else if (later == 1) SK_VMCNT(5);
       else SK_VMCNT(0);
@@ -86,11 +105,11 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(const half_t* __restri
     __builtin_amdgcn_s_barrier();  // everyone's share of tile t is in the LDS, and everyone has finished reading tile t - 1 (its stage is free)
     asm volatile("" ::: "memory");
     if (t + 3 < nk) issue(t + 3);
-    const int sb = (t % SK_STAGES) * SK_STAGE_BYTES;
+    const int sb = (t % SK_STAGES) * STAGE, wb = WPRE ? t * 2048 : sb;
     half8_t af[2][2], wf[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      asm volatile("ds_read_b128 %0, %1" : "=v"(wf[ks]) : "v"(fw[ks] + sb) : "memory");
+      asm volatile("ds_read_b128 %0, %1" : "=v"(wf[ks]) : "v"(fw[ks] + wb) : "memory");
       asm volatile("ds_read_b128 %0, %1" : "=v"(af[0][ks]) : "v"(fa[ks] + sb) : "memory");
       asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(af[1][ks]) : "v"(fa[ks] + sb) : "memory");
     }
@@ -123,14 +142,24 @@ static inline bool gemm_skinny_ok(const void* A, long lda, const void* W, long l
 template <class Epi>
 static inline int launch_gemm_skinny(const half_t* A, long lda, const half_t* W, long ldw, int M, int N, int K, const Epi& epi, int S, hipStream_t stream) {
   if (!gemm_skinny_ok(A, lda, W, ldw, M, N, K, S)) return LFM_ERR_SHAPE;
-  static unsigned long long attr_set = 0;  // one bit per device: the attribute is per (function, device)
+  static unsigned long long attr_set = 0, wpre_bad = 0;  // one bit per device: the attribute is per (function, device)
   int devid = 0;
   (void)hipGetDevice(&devid);
-  if (!((attr_set >> (devid & 63)) & 1)) {
-    if (hipFuncSetAttribute((const void*)gemm_skinny_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES) != hipSuccess) return LFM_ERR_LAUNCH;
-    attr_set |= 1ull << (devid & 63);
+  const unsigned long long bit = 1ull << (devid & 63);
+  if (!(attr_set & bit)) {
+    if (hipFuncSetAttribute((const void*)gemm_skinny_kernel<Epi, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES) != hipSuccess) return LFM_ERR_LAUNCH;
+    // the W-prefetch variant takes the CU's whole 160 KiB: where the runtime refuses that much for one workgroup, the tile-by-tile variant serves every shape
+    if (hipFuncSetAttribute((const void*)gemm_skinny_kernel<Epi, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES_WPRE) != hipSuccess) {
+      (void)hipGetLastError();
+      wpre_bad |= bit;
+    }
+    attr_set |= bit;
   }
-  hipLaunchKernelGGL((gemm_skinny_kernel<Epi>), dim3(N / SK_BN, S), dim3(512), SK_LDS_BYTES, stream, A, lda, W, ldw, M, N, K / S, epi);
+  const int Ks = K / S;
+  if (Ks <= SK_WPRE_MAX_KS && !(wpre_bad & bit))
+    hipLaunchKernelGGL((gemm_skinny_kernel<Epi, true>), dim3(N / SK_BN, S), dim3(512), SK_LDS_BYTES_WPRE, stream, A, lda, W, ldw, M, N, Ks, epi);
+  else
+    hipLaunchKernelGGL((gemm_skinny_kernel<Epi, false>), dim3(N / SK_BN, S), dim3(512), SK_LDS_BYTES, stream, A, lda, W, ldw, M, N, Ks, epi);
   LFM_CHECK_LAUNCH();
   return LFM_OK;
 }
