@@ -58,6 +58,11 @@ def build(force=False, verbose=False):
         lock = open(os.path.join(LIBDIR, ".build.lock"), "w")
     except PermissionError:  # a read-only install: nothing can be (re)built here anyway
         if os.path.exists(LIB):
+            if not (os.path.exists(STAMP) and open(STAMP).read() == dig):
+                import warnings
+
+                warnings.warn(f"{LIB} was built from other sources than the ones next to it (stamp mismatch) and this install is read-only: using it as "
+                              "shipped; hip.lib() still refuses a library of another ABI version")
             return LIB
         raise
     with lock:

@@ -462,26 +462,32 @@ static int attention_launch(const half_t* Q, const half_t* K, const half_t* Vt, 
     LFM_CHECK_LAUNCH();
     return LFM_OK;
   }
+  // the dynamic-LDS attribute is per (function, device): one bit per device and instantiation
+  int devid = 0;
+  (void)hipGetDevice(&devid);
+  const unsigned long long dbit = 1ull << (devid & 63);
 #define ATT_CASE(TT, JQ, HD)                                                                                                             \
   {                                                                                                                                     \
-    static bool set = false;                                                                                                            \
-    if (!set) {                                                                                                                         \
+    static unsigned long long set = 0;                                                                                                  \
+    if (!(set & dbit)) {                                                                                                                \
       (void)hipFuncSetAttribute((const void*)dit_attention_kernel<TT, JQ, HD>, hipFuncAttributeMaxDynamicSharedMemorySize, TT * HD * 4); \
-      set = true;                                                                                                                       \
+      set |= dbit;                                                                                                                      \
     }                                                                                                                                   \
     hipLaunchKernelGGL((dit_attention_kernel<TT, JQ, HD>), grid, dim3((TT / (32 * JQ)) * 64), lds, st, Q, K, Vt, O, D, heads, sl2, lfm_stagger_ticks()); \
   }
   if (T == 1024) {  // four key chunks of 256 through the LDS, one workgroup per 256 queries
-    static bool set = false;
     const dim3 grid4(heads, batch, 4);
     if (hd == 64) {
-      if (!set) (void)hipFuncSetAttribute((const void*)dit_attention_kernel<256, 1, 64, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 64 * 4);
+      static unsigned long long set = 0;
+      if (!(set & dbit)) (void)hipFuncSetAttribute((const void*)dit_attention_kernel<256, 1, 64, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 64 * 4);
+      set |= dbit;
       hipLaunchKernelGGL((dit_attention_kernel<256, 1, 64, 0, 4>), grid4, dim3(512), (size_t)256 * 64 * 4, st, Q, K, Vt, O, D, heads, sl2, lfm_stagger_ticks());
     } else {
-      if (!set) (void)hipFuncSetAttribute((const void*)dit_attention_kernel<256, 1, 72, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 72 * 4);
+      static unsigned long long set = 0;  // its own flag: the hd-72 kernel needs 72 KiB, above the 64-KiB default, whatever the hd-64 one did before
+      if (!(set & dbit)) (void)hipFuncSetAttribute((const void*)dit_attention_kernel<256, 1, 72, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 72 * 4);
+      set |= dbit;
       hipLaunchKernelGGL((dit_attention_kernel<256, 1, 72, 0, 4>), grid4, dim3(512), (size_t)256 * 72 * 4, st, Q, K, Vt, O, D, heads, sl2, lfm_stagger_ticks());
     }
-    set = true;
     LFM_CHECK_LAUNCH();
     return LFM_OK;
   }

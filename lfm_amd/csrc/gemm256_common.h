@@ -205,7 +205,7 @@ __device__ __forceinline__ void g256_epilogue(f32x16 (&acc)[4][2], char* smem, E
             if (m + 11 < M) epi.store_t8(nb + ps * 8, m, lo[ps], hi[ps], bt[ps]);
             else {
               if (m + 3 < M) epi.store_t(nb + ps * 8, m, lo[ps], bt[ps]);
-              if (m + 11 < M) epi.store_t(nb + ps * 8, m + 8, hi[ps], bt[ps]);
+              // (the hi half -- tokens m + 8 .. m + 11 -- lies beyond M here; wide_t_ok() implies M % 16 == 0)
             }
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -359,7 +359,7 @@ __device__ __forceinline__ void g256h_epilogue_body(f32x4_t (&acc)[8][4], char* 
               if (m + 11 < M) epi.store_t8(n, m, lo, hi, b);
               else {
                 if (m + 3 < M) epi.store_t(n, m, lo, b);
-                if (m + 11 < M) epi.store_t(n, m + 8, hi, b);
+                // (the hi half -- tokens m + 8 .. m + 11 -- lies beyond M here; wide_t_ok() implies M % 16 == 0, so this branch only trims whole tails)
               }
             }
           } else {

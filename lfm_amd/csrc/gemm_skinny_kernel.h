@@ -8,14 +8,14 @@
 //   * a workgroup owns ALL 256 rows x 16 output columns (x one K-slice): its W slice (16 x K) is streamed from HBM exactly once by exactly one
 //     workgroup; A (256 x K fp16, 0.5 MB at K = 1024) comes out of the L2 -- 256 workgroups x 0.5 MB = 128 MB of L2 traffic per GEMM, ~4.5 us at the
 //     48 B/clk/CU that eight waves of buffer-addressed LDS-DMA sustain (tools/ubench/ldsdma_rate.hip);
-//   * eight waves; wave w multiplies M-tiles 2 w, 2 w + 1 (v_mfma_f32_16x16x32_f16, W as the A operand: a lane owns four consecutive n of one row) and
-//     streams ITS OWN 32 rows of A straight into registers in the fragment layout -- no wave shares A rows with another, so the LDS is not needed for A,
-//     and the register file holds far more in flight: DEPTH = 8 K-tiles = 256 KiB per CU.  (Builds 1 and 2 of round 5 staged A through a 4 x 32 KiB LDS
-//     ring: 96 KiB in flight per CU against ~2 us of L2 latency = 21 B/clk/CU, 12.0 / 10.7 us per K = 1024 GEMM; profiles/r05_latency_mode.txt.)  No
-//     barrier in the main loop: counted vmcnt waits per K-tile, slots refilled right after the MFMAs that read them;
-//   * the workgroup's WHOLE W slice (16 x K-slice, 32 KiB at K = 1024) is requested up front by LDS-DMA, before the first A tile: W is the operand that
-//     comes from HBM (first touch); requested at once it costs one HBM round trip instead of one per lookahead window.  One barrier after it landed;
-//     W fragments are read from the LDS one K-tile ahead (chunk c of row r at c ^ ((r >> 1) & 7), swizzle on the DMA source and on the read);
+//   * eight waves: all of them stage (thread tid moves 16-byte chunk tid & 7 of rows (tid >> 3) + 64 j, j = 0..3, of a 64-deep K-tile: 32 KiB of A
+//     per stage, four stages, three K-tiles in flight behind counted vmcnt waits, ONE barrier per K-tile), wave w multiplies M-tiles 2 w, 2 w + 1
+//     (v_mfma_f32_16x16x32_f16, W as the A operand: a lane owns four consecutive n of one row);
+//   * WPRE (K-slice <= 1024): the workgroup's WHOLE W slice (16 x K-slice, <= 32 KiB) is requested up front, before the first A tile.  W comes from
+//     HBM (first touch), A from the L2: with W staged tile by tile behind a three-tile lookahead the kernel was an HBM-LATENCY chain (first build:
+//     12.0 us per K = 1024 GEMM = 20 B/clk/CU of A streaming); requested at once the slice costs one HBM round trip.  4 x 32 KiB + 32 KiB = the CU's
+//     160 KiB of LDS.  Without WPRE (DiT-XL: K = 1152) W travels with its A tile: 2 KiB per stage;
+//   * LDS image as every 128-byte-row kernel here: chunk c of row r at c ^ ((r >> 1) & 7), swizzle on the DMA source and on the fragment read;
 //   * epilogue straight from the accumulators through the shared Epi interface (EpiQKV / EpiBiasGeluF16 in-kernel: no slab, no finish launch);
 //   * grid.y > 1 slices K (proj / fc2: 64 column slices x 4 K-slices = 256 workgroups) into fp32 slabs (EpiSlabF32) for the row-owning finish kernel
 //     that is also the next LayerNorm-modulate (splitk_finish_resid_ln_kernel) -- deterministic, fixed summation order.
@@ -26,119 +26,102 @@
 #define SK_BK 64
 #define SK_ROWS 256
 #define SK_BN 16
-#define SK_MAX_KS 4096  // W slice of a workgroup: 16 x Ks fp16 <= 128 KiB of LDS
+#define SK_STAGES 4
+#define SK_A_BYTES (SK_ROWS * SK_BK * 2)
+#define SK_W_BYTES (SK_BN * SK_BK * 2)
+#define SK_STAGE_BYTES (SK_A_BYTES + SK_W_BYTES)
+#define SK_LDS_BYTES (SK_STAGES * SK_STAGE_BYTES)
 
 typedef float sk_f32x4 __attribute__((ext_vector_type(4)));
-template <int V>
-struct sk_ic {
-  static constexpr int value = V;
-};
-template <class F, int... I>
-__device__ __forceinline__ void sk_for_impl(F&& f, std::integer_sequence<int, I...>) {
-  (f(sk_ic<I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void sk_for(F&& f) {
-  sk_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-// s_waitcnt vmcnt(4 n): at most n later K-tiles (four loads each) of this lane still in flight
-__device__ __forceinline__ void sk_wait_tiles(int n) {
-  switch (n) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
-    case 6: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
-    case 7: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
-  }
-}
 
-template <class Epi, int DEPTH>
+#define SK_WPRE_MAX_KS 1024
+#define SK_LDS_BYTES_WPRE (SK_STAGES * SK_A_BYTES + SK_BN * SK_WPRE_MAX_KS * 2)
+
+template <class Epi, bool WPRE>
 __global__ __launch_bounds__(512) void gemm_skinny_kernel(const half_t* __restrict__ A, long lda, const half_t* __restrict__ W, long ldw, int M, int N, int Ks,
                                                           Epi epi) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // the W slice: K-tile kt at 2048 kt, 16 rows x 128 B, chunk c of row r at c ^ ((r >> 1) & 7)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int STAGE = WPRE ? SK_A_BYTES : SK_STAGE_BYTES;  // bytes per ring stage
+  constexpr int WBASE = WPRE ? SK_STAGES * SK_A_BYTES : SK_A_BYTES;  // WPRE: one region behind the ring, tile kt at + 2048 kt; else inside the stage
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n0 = blockIdx.x * SK_BN, bz = blockIdx.y;
   epi_batch(epi, bz, 0, 0);
   const unsigned kbase = (unsigned)bz * (unsigned)Ks;
+  // ---- DMA sources (buffer resources over the operands: unsigned 32-bit byte offsets)
+  const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, -1, 0x00020000);
+  const unsigned cswz = (unsigned)(((tid & 7) ^ ((tid >> 4) & 7)) * 8);  // source chunk of the physical slot this thread fills (key (row >> 1) & 7)
+  unsigned avoff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = (tid >> 3) + 64 * j;
+    avoff[j] = ((unsigned)(r < M ? r : M - 1) * (unsigned)lda + cswz) * 2u;
+  }
   const int nk = Ks / SK_BK;
-  // ---- the whole W slice first: 2 nk LDS-DMAs of 1 KiB (8 rows x 128 B) dealt round-robin to the eight waves -- DMA d = 2 kt + h moves rows 8 h .. 8 h + 7
-  // of K-tile kt; d = wave (mod 8), so h = wave & 1 is fixed per wave.  W is the operand that comes from HBM: requested at once it costs one round trip.
-  {
-    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, -1, 0x00020000);
+  if constexpr (WPRE) {
+    // the whole W slice first: 2 nk DMAs of 1 KiB (8 rows x 128 B) dealt round-robin to the eight waves -- DMA d = 2 kt + h moves rows 8 h .. 8 h + 7 of
+    // K-tile kt; d = wave (mod 8), so h = wave & 1 is fixed per wave.  Issued before every A tile: loads return in order, so the first counted wait
+    // below already implies them (the per-wave counts need not be equal).
     const int h = wave & 1, wr = n0 + 8 * h + (lane >> 3);
     const unsigned wv = ((unsigned)(wr < N ? wr : N - 1) * (unsigned)ldw + (unsigned)(((lane & 7) ^ ((4 * h + (lane >> 4)) & 7)) * 8)) * 2u;
-    for (int d = wave; d < 2 * nk; d += 8) glds16_buf(rsw, wv, (kbase + (unsigned)(d >> 1) * SK_BK) * 2u, smem + d * 1024);
+    for (int d = wave; d < 2 * nk; d += 8) glds16_buf(rsw, wv, (kbase + (unsigned)(d >> 1) * SK_BK) * 2u, smem + WBASE + d * 1024);
   }
-  // ---- A: every wave streams ITS OWN 32 rows straight into registers in the MFMA fragment layout (no wave shares A rows, so the LDS would only be a
-  // detour -- and a capacity limit: with a 4 x 32 KiB LDS ring the kernel sat at 96 KiB in flight per CU = 21 B/clk of L2 latency x bandwidth).  Lane
-  // (r = lane & 15, q = lane >> 4) of M-tile i loads the 16 bytes A[32 wave + 16 i + r][k0 + 32 ks + 8 q ..]; DEPTH K-tiles (DEPTH x 32 KiB per CU) in flight.
-  const int q4 = lane >> 4;
-  unsigned aoff[2][2];
+  const int wr_t = n0 + (tid >> 3);  // (!WPRE) waves 0, 1 stage the 16 W rows of a tile (tid < 128)
+  const unsigned wvoff = ((unsigned)(wr_t < N ? wr_t : N - 1) * (unsigned)ldw + cswz) * 2u;
+  auto issue = [&](int kt) {
+    char* st = smem + (kt % SK_STAGES) * STAGE;
+    const unsigned soff = (kbase + (unsigned)kt * SK_BK) * 2u;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = 32 * wave + 16 * i + (lane & 15);
+    for (int j = 0; j < 4; ++j) glds16_buf(rsa, avoff[j], soff, st + j * 8192 + wave * 1024);
+    if constexpr (!WPRE) {
+      if (wave < 2) glds16_buf(rsw, wvoff, soff, st + SK_A_BYTES + wave * 1024);
+    }
+  };
+  // ---- fragment read addresses: lane (r = lane & 15, q = lane >> 4) reads logical chunk 4 ks + q of row base + r
+  const int rkey = ((lane & 15) >> 1) & 7, q4 = lane >> 4;
+  int fa[2], fw[2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) aoff[i][ks] = ((unsigned)(r < M ? r : M - 1) * (unsigned)lda + (unsigned)(ks * 32 + q4 * 8)) * 2u;
+  for (int ks = 0; ks < 2; ++ks) {
+    const int ch = ((ks * 4 + q4) ^ rkey) << 4;
+    fa[ks] = (32 * wave + (lane & 15)) * 128 + ch;  // + 2048 for the wave's second M-tile
+    fw[ks] = WBASE + (lane & 15) * 128 + ch;
   }
-  half8_t af[DEPTH][2][2];
-  // (inline asm operands must be lambda PARAMETERS, not captures)
-  auto gload = [](half8_t& dst, unsigned off, const char* base) { asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory"); };
-  auto lread = [](half8_t& dst, int addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory"); };
-  auto load_tile = [&](auto SC, int kt) {
-    constexpr int S = decltype(SC)::value;
-    const char* base = (const char*)A + ((size_t)kbase + (size_t)kt * SK_BK) * 2;  // wave-uniform: an SGPR pair
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) gload(af[S][i][ks], aoff[i][ks], base);
-  };
-  sk_for<DEPTH>([&](auto SC) {
-    if (decltype(SC)::value < nk) load_tile(SC, decltype(SC)::value);
-  });
-  // my share of W has landed once at most the A loads issued after it are outstanding; behind the barrier so has everyone's
-  sk_wait_tiles(nk < DEPTH ? nk : DEPTH);
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  // W fragment reads: lane (r, q) reads logical chunk 4 ks + q of row r of K-tile t; double-buffered one tile ahead
-  const int rkey = ((lane & 15) >> 1) & 7;
-  int fw[2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) fw[ks] = (lane & 15) * 128 + (((ks * 4 + q4) ^ rkey) << 4);
-  half8_t wf[2][2];
-  auto read_w = [&](auto BC, int t) {
-    constexpr int B = decltype(BC)::value;
-    lread(wf[B][0], fw[0] + t * 2048);
-    lread(wf[B][1], fw[1] + t * 2048);
-  };
   sk_f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-  read_w(sk_ic<0>{}, 0);
-  for (int t0 = 0; t0 < nk; t0 += DEPTH) {
-    sk_for<DEPTH>([&](auto SC) {
-      constexpr int S = decltype(SC)::value, B = S & 1;
-      const int t = t0 + S;
-      if (t < nk) {
-        const int later = nk - 1 - t < DEPTH - 1 ? nk - 1 - t : DEPTH - 1;
-        sk_wait_tiles(later);                               // A fragments of tile t
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // W fragments of tile t (requested a tile ago)
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < nk) read_w(sk_ic<(B ^ 1)>{}, t + 1);
-        __builtin_amdgcn_sched_barrier(0);
+#define SK_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+  for (int t = 0; t < 3 && t < nk; ++t) issue(t);
+  for (int t = 0; t < nk; ++t) {
+    // K-tile t has landed: this thread's DMAs of the (at most two) later tiles may still be in flight -- 4 per tile (5 for the W-staging waves of !WPRE)
+    const int later = nk - 1 - t < 2 ? nk - 1 - t : 2;
+    if (!WPRE && wave < 2) {
+      if (later == 2) SK_VMCNT(10);
+      else if (later == 1) SK_VMCNT(5);
+      else SK_VMCNT(0);
+    } else {
+      if (later == 2) SK_VMCNT(8);
+      else if (later == 1) SK_VMCNT(4);
+      else SK_VMCNT(0);
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // everyone's share of tile t is in the LDS, and everyone has finished reading tile t - 1 (its stage is free)
+    asm volatile("" ::: "memory");
+    if (t + 3 < nk) issue(t + 3);
+    const int sb = (t % SK_STAGES) * STAGE, wb = WPRE ? t * 2048 : sb;
+    half8_t af[2][2], wf[2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[B][ks], af[S][0][ks], acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[B][ks], af[S][1][ks], acc[1], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + DEPTH < nk) load_tile(SC, t + DEPTH);  // refill the slot the MFMAs above have read
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    });
+    for (int ks = 0; ks < 2; ++ks) {
+      asm volatile("ds_read_b128 %0, %1" : "=v"(wf[ks]) : "v"(fw[ks] + wb) : "memory");
+      asm volatile("ds_read_b128 %0, %1" : "=v"(af[0][ks]) : "v"(fa[ks] + sb) : "memory");
+      asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(af[1][ks]) : "v"(fa[ks] + sb) : "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks], af[0][ks], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks], af[1][ks], acc[1], 0, 0, 0);
+    }
   }
+#undef SK_VMCNT
   // ---- epilogue: lane l owns C[m = 16 (2 wave + i) + (l & 15)][n0 + 4 (l >> 4) .. + 3]
   const int n = n0 + 4 * q4;
 #pragma unroll
@@ -152,26 +135,31 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(const half_t* __restri
 }
 
 static inline bool gemm_skinny_ok(const void* A, long lda, const void* W, long ldw, int M, int N, int K, int S) {
-  return M > 0 && M <= SK_ROWS && N > 0 && (N % SK_BN) == 0 && S >= 1 && (K % (S * SK_BK)) == 0 && K / S <= SK_MAX_KS && (lda % 8) == 0 && (ldw % 8) == 0 &&
+  return M > 0 && M <= SK_ROWS && N > 0 && (N % SK_BN) == 0 && S >= 1 && (K % (S * SK_BK)) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 &&
          !(((uintptr_t)A | (uintptr_t)W) & 15) && (long)M * lda < (1L << 30) && (long)N * ldw < (1L << 30);
 }
 // S K-slices: slice bz covers k in [bz K / S, (bz + 1) K / S); with S > 1 the epilogue must be slab-addressed by the slice (EpiSlabF32)
 template <class Epi>
 static inline int launch_gemm_skinny(const half_t* A, long lda, const half_t* W, long ldw, int M, int N, int K, const Epi& epi, int S, hipStream_t stream) {
   if (!gemm_skinny_ok(A, lda, W, ldw, M, N, K, S)) return LFM_ERR_SHAPE;
-  static unsigned long long attr_set = 0;  // one bit per device: the attribute is per (function, device)
+  static unsigned long long attr_set = 0, wpre_bad = 0;  // one bit per device: the attribute is per (function, device)
   int devid = 0;
   (void)hipGetDevice(&devid);
   const unsigned long long bit = 1ull << (devid & 63);
   if (!(attr_set & bit)) {
-    if (hipFuncSetAttribute((const void*)gemm_skinny_kernel<Epi, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_BN * SK_MAX_KS * 2) != hipSuccess ||
-        hipFuncSetAttribute((const void*)gemm_skinny_kernel<Epi, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_BN * SK_MAX_KS * 2) != hipSuccess)
-      return LFM_ERR_LAUNCH;
+    if (hipFuncSetAttribute((const void*)gemm_skinny_kernel<Epi, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES) != hipSuccess) return LFM_ERR_LAUNCH;
+    // the W-prefetch variant takes the CU's whole 160 KiB: where the runtime refuses that much for one workgroup, the tile-by-tile variant serves every shape
+    if (hipFuncSetAttribute((const void*)gemm_skinny_kernel<Epi, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES_WPRE) != hipSuccess) {
+      (void)hipGetLastError();
+      wpre_bad |= bit;
+    }
     attr_set |= bit;
   }
-  const int Ks = K / S, lds = SK_BN * Ks * 2;
-  if (Ks / SK_BK >= 8) hipLaunchKernelGGL((gemm_skinny_kernel<Epi, 8>), dim3(N / SK_BN, S), dim3(512), lds, stream, A, lda, W, ldw, M, N, Ks, epi);
-  else hipLaunchKernelGGL((gemm_skinny_kernel<Epi, 4>), dim3(N / SK_BN, S), dim3(512), lds, stream, A, lda, W, ldw, M, N, Ks, epi);
+  const int Ks = K / S;
+  if (Ks <= SK_WPRE_MAX_KS && !(wpre_bad & bit))
+    hipLaunchKernelGGL((gemm_skinny_kernel<Epi, true>), dim3(N / SK_BN, S), dim3(512), SK_LDS_BYTES_WPRE, stream, A, lda, W, ldw, M, N, Ks, epi);
+  else
+    hipLaunchKernelGGL((gemm_skinny_kernel<Epi, false>), dim3(N / SK_BN, S), dim3(512), SK_LDS_BYTES, stream, A, lda, W, ldw, M, N, Ks, epi);
   LFM_CHECK_LAUNCH();
   return LFM_OK;
 }
