@@ -369,8 +369,11 @@ def test_conv_split_k_plan_for_the_small_maps():
     L = hip.lib()
     ws = lambda n, h, cin, cout: L.lfm_conv3x3_workspace_bytes(n, h, h, cin, cout)
     assert ws(32, 64, 256, 256) == 0 and ws(32, 32, 512, 512) == 0          # 2048 / 1024 tiles: no split
-    assert ws(32, 16, 512, 512) == 2 * 8192 * 512 * 4                        # 256 tiles -> two slices
-    assert ws(32, 16, 1024, 512) == 2 * 8192 * 512 * 4
+    # round 5: deep problems with >= 2048 rows whose 256x256 tiles x slices keep at least half the CUs busy slice on the 256x256 kernel (gemm_kernel.h:
+    # splitk256_slices: the largest divisor of the K-tile count with slices >= 24 K-tiles and at most 256 workgroups); the workspace covers the larger plan
+    assert ws(32, 16, 512, 512) == 3 * 8192 * 512 * 4                        # 64 tiles of 256x256 x 3 slices of 24 K-tiles (128x128 plan: two slices)
+    assert ws(32, 16, 1024, 512) == 4 * 8192 * 512 * 4                       # 64 tiles x 4 slices of 36 K-tiles
+    assert ws(64, 8, 768, 768) == 4 * 4096 * 768 * 4                         # EDM ffhq_adm 8x8 maps at batch 64: 48 tiles x 4 slices of 27 K-tiles
     assert ws(32, 8, 512, 512) == 8 * 2048 * 512 * 4                         # 64 tiles -> eight slices of K / 8 = 576
     assert ws(32, 4, 1024, 1024) == 16 * 512 * 1024 * 4                      # 32 tiles -> sixteen slices of 576
     assert ws(2, 8, 64, 128) == 0                                            # K = 576: a half (288) is not a multiple of the 64-deep K-tile
