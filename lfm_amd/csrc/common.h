@@ -108,9 +108,22 @@ __device__ __forceinline__ f32x2_t gelu_tanh_pk(f32x2_t x) {
 // tests/test_host_logic.py::test_no_packed_fp32_op_sel disassembles the built code objects and keeps every op_sel'd packed-fp32 form out of the library.
 // (Plain C, not inline asm: sixteen asm statements per pass pushed the one-wave-per-SIMD QKV kernel's accumulator view into scratch memory.)
 __device__ __forceinline__ float fma_v(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-// a * acc + (b * u + v), four columns of one row
+// a * acc + (b * u + v), four columns of one row.  Packed again, but only in the SAFE form: a and b are first pinned into registers of their own (the empty
+// asm), so that the compiler broadcasts each as the LOW register of a pair -- v_pk_fma_f32 .. op_sel_hi:[0,1,1], both halves read the low register -- and
+// never reaches into the high register of the (a, b) pair for the low half (op_sel:[1,..]).  In round 4's events the op_sel_hi-broadcast FMA of the same
+// chain (a * acc + t) never produced a wrong half; only the op_sel one did.  One v_mov + eight packed FMAs per eight outputs (sixteen scalar FMAs cost the
+// VALU-bound fc1 / qkv epilogues ~2 us per launch).  LFM_EXP_AFFINE_SCALAR: the all-scalar form (A/B).
 __device__ __forceinline__ f32x4 row_affine4(float a, float b, f32x4 acc, f32x4 u, f32x4 v) {
+#ifdef LFM_EXP_AFFINE_SCALAR
   return (f32x4){fma_v(a, acc.x, fma_v(b, u.x, v.x)), fma_v(a, acc.y, fma_v(b, u.y, v.y)), fma_v(a, acc.z, fma_v(b, u.z, v.z)), fma_v(a, acc.w, fma_v(b, u.w, v.w))};
+#else
+  asm("" : "+v"(a));
+  asm("" : "+v"(b));
+  const f32x2 aa = {a, a}, bb = {b, b};
+  const f32x2 t0 = __builtin_elementwise_fma(bb, (f32x2){u.x, u.y}, (f32x2){v.x, v.y}), t1 = __builtin_elementwise_fma(bb, (f32x2){u.z, u.w}, (f32x2){v.z, v.w});
+  const f32x2 x0 = __builtin_elementwise_fma(aa, (f32x2){acc.x, acc.y}, t0), x1 = __builtin_elementwise_fma(aa, (f32x2){acc.z, acc.w}, t1);
+  return (f32x4){x0.x, x0.y, x1.x, x1.y};
+#endif
 }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
