@@ -68,8 +68,13 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(const half_t* __restri
   }
   const int wr_t = n0 + (tid >> 3);  // (!WPRE) waves 0, 1 stage the 16 W rows of a tile (tid < 128)
   const unsigned wvoff = ((unsigned)(wr_t < N ? wr_t : N - 1) * (unsigned)ldw + cswz) * 2u;
-  auto issue = [&](int kt) {
-    char* st = smem + (kt % SK_STAGES) * STAGE;
+  // K-tile ORDER rotated per workgroup (step t handles K-tile (t + rot) mod nk): all 256 workgroups of a launch read the same 0.5 MB of A, and in lockstep
+  // they would all ask the L2 for the same addresses -- the same channels -- at the same time
+  const int rot = (int)(blockIdx.x % (unsigned)nk);
+  auto tile_of = [&](int t) { return t + rot < nk ? t + rot : t + rot - nk; };
+  auto issue = [&](int t) {
+    const int kt = tile_of(t);
+    char* st = smem + (t % SK_STAGES) * STAGE;
     const unsigned soff = (kbase + (unsigned)kt * SK_BK) * 2u;
 #pragma unroll
     for (int j = 0; j < 4; ++j) glds16_buf(rsa, avoff[j], soff, st + j * 8192 + wave * 1024);
@@ -105,7 +110,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(const half_t* __restri
     __builtin_amdgcn_s_barrier();  // everyone's share of tile t is in the LDS, and everyone has finished reading tile t - 1 (its stage is free)
     asm volatile("" ::: "memory");
     if (t + 3 < nk) issue(t + 3);
-    const int sb = (t % SK_STAGES) * STAGE, wb = WPRE ? t * 2048 : sb;
+    const int sb = (t % SK_STAGES) * STAGE, wb = WPRE ? tile_of(t) * 2048 : sb;
     half8_t af[2][2], wf[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
