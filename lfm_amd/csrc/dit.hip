@@ -28,8 +28,6 @@ int lfm_gemm_prefers_v4(int M, int N, int K) {
 }
 static int g_opt_v6 = 0;
 int lfm_gemm_v6_default() { return g_opt_v6; }
-static int g_skinny_narrow = 0;
-int lfm_skinny_narrow() { return g_skinny_narrow; }
 static int g_opt_skinny = 1;  // LFM_OPT_SKINNY_GEMM: the all-rows x 16-columns kernel for the batch-1 DiT linears (gemm_skinny_kernel.h)
 static int g_stagger = 0;
 int lfm_stagger_ticks() { return g_stagger; }
@@ -80,9 +78,8 @@ extern "C" int lfm_set_option(int key, int value) {  // key 1 (LFM_OPT_FOLD_LN):
     g_opt_v6 = value != 0;
     return LFM_OK;
   }
-  if (key == 4) {  // LFM_OPT_SKINNY_GEMM: 0 = the split-K 128x128 path of rounds 2-4 for M <= 256 (A/B, parity); 2 = skinny with 16-column slices everywhere (A/B)
+  if (key == 4) {  // LFM_OPT_SKINNY_GEMM: 0 = the split-K 128x128 path of rounds 2-4 for M <= 256 (A/B, parity)
     g_opt_skinny = value != 0;
-    g_skinny_narrow = value == 2;
     return LFM_OK;
   }
 #ifdef LFM_MEASURE

@@ -23,31 +23,31 @@
 #pragma once
 #include "gemm_kernel.h"
 
+#ifndef SK_ROTATE
+#define SK_ROTATE 1
+#endif
 #define SK_BK 64
 #define SK_ROWS 256
 #define SK_BN 16
 #define SK_STAGES 4
 #define SK_A_BYTES (SK_ROWS * SK_BK * 2)
-#define SK_BN_WIDE 32  // column-slice width of the launches that keep W in the ring (qkv, fc1: see launch_gemm_skinny)
-#define SK_LDS_BYTES(BN) (SK_STAGES * (SK_A_BYTES + (BN) * SK_BK * 2))
+#define SK_W_BYTES (SK_BN * SK_BK * 2)
+#define SK_STAGE_BYTES (SK_A_BYTES + SK_W_BYTES)
+#define SK_LDS_BYTES (SK_STAGES * SK_STAGE_BYTES)
 
 typedef float sk_f32x4 __attribute__((ext_vector_type(4)));
-int lfm_skinny_narrow();  // 1: 16-column slices everywhere (lfm_set_option LFM_OPT_SKINNY_GEMM value 2: A/B)
 
 #define SK_WPRE_MAX_KS 1024
 #define SK_LDS_BYTES_WPRE (SK_STAGES * SK_A_BYTES + SK_BN * SK_WPRE_MAX_KS * 2)
 
-template <class Epi, int BN, bool WPRE>
+template <class Epi, bool WPRE>
 __global__ __launch_bounds__(512) void gemm_skinny_kernel(const half_t* __restrict__ A, long lda, const half_t* __restrict__ W, long ldw, int M, int N, int Ks,
                                                           Epi epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  static_assert((BN == 16 || BN == 32) && (!WPRE || BN == 16), "W prefetch: 16 columns (32 KiB); 32 columns travel with their A tile");
-  constexpr int NJ = BN / 16;                // 16-column MFMA tiles per workgroup
-  constexpr int WT = BN * SK_BK * 2;         // bytes of a W K-tile
-  constexpr int STAGE = WPRE ? SK_A_BYTES : SK_A_BYTES + WT;  // bytes per ring stage
+  constexpr int STAGE = WPRE ? SK_A_BYTES : SK_STAGE_BYTES;  // bytes per ring stage
   constexpr int WBASE = WPRE ? SK_STAGES * SK_A_BYTES : SK_A_BYTES;  // WPRE: one region behind the ring, tile kt at + 2048 kt; else inside the stage
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n0 = blockIdx.x * BN, bz = blockIdx.y;
+  const int n0 = blockIdx.x * SK_BN, bz = blockIdx.y;
   epi_batch(epi, bz, 0, 0);
   const unsigned kbase = (unsigned)bz * (unsigned)Ks;
   // ---- DMA sources (buffer resources over the operands: unsigned 32-bit byte offsets)
@@ -69,11 +69,11 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(const half_t* __restri
     const unsigned wv = ((unsigned)(wr < N ? wr : N - 1) * (unsigned)ldw + (unsigned)(((lane & 7) ^ ((4 * h + (lane >> 4)) & 7)) * 8)) * 2u;
     for (int d = wave; d < 2 * nk; d += 8) glds16_buf(rsw, wv, (kbase + (unsigned)(d >> 1) * SK_BK) * 2u, smem + WBASE + d * 1024);
   }
-  const int wr_t = n0 + (tid >> 3);  // (!WPRE) the first BN / 8 waves stage the BN W rows of a tile (tid < 8 BN)
+  const int wr_t = n0 + (tid >> 3);  // (!WPRE) waves 0, 1 stage the 16 W rows of a tile (tid < 128)
   const unsigned wvoff = ((unsigned)(wr_t < N ? wr_t : N - 1) * (unsigned)ldw + cswz) * 2u;
-  // K-tile ORDER rotated per workgroup (step t handles K-tile (t + rot) mod nk): all 256 workgroups of a launch read the same 0.5 MB of A, and in lockstep
-  // they would all ask the L2 for the same addresses -- the same channels -- at the same time
-  const int rot = (int)(blockIdx.x % (unsigned)nk);
+  // (experiment) K-tile ORDER rotated per workgroup: step t handles K-tile (t + rot) mod nk, rot = (workgroup / 8) mod nk.  Workgroup i runs on XCD i mod 8 and
+  // the 32 workgroups of an XCD stream the SAME rows of A: in lockstep every K-tile is a first touch of that XCD's L2 for all of them.
+  const int rot = SK_ROTATE ? (int)((blockIdx.x >> 3) % (unsigned)nk) : 0;
   auto tile_of = [&](int t) { return t + rot < nk ? t + rot : t + rot - nk; };
   auto issue = [&](int t) {
     const int kt = tile_of(t);
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(const half_t* __restri
 #pragma unroll
     for (int j = 0; j < 4; ++j) glds16_buf(rsa, avoff[j], soff, st + j * 8192 + wave * 1024);
     if constexpr (!WPRE) {
-      if (wave < BN / 8) glds16_buf(rsw, wvoff, soff, st + SK_A_BYTES + wave * 1024);
+      if (wave < 2) glds16_buf(rsw, wvoff, soff, st + SK_A_BYTES + wave * 1024);
     }
   };
   // ---- fragment read addresses: lane (r = lane & 15, q = lane >> 4) reads logical chunk 4 ks + q of row base + r
@@ -92,19 +92,15 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(const half_t* __restri
   for (int ks = 0; ks < 2; ++ks) {
     const int ch = ((ks * 4 + q4) ^ rkey) << 4;
     fa[ks] = (32 * wave + (lane & 15)) * 128 + ch;  // + 2048 for the wave's second M-tile
-    fw[ks] = WBASE + (lane & 15) * 128 + ch;  // + 2048 j for N-tile j
+    fw[ks] = WBASE + (lane & 15) * 128 + ch;
   }
-  sk_f32x4 acc[2][NJ];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) acc[i][j] = (sk_f32x4){0.f, 0.f, 0.f, 0.f};
+  sk_f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #define SK_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
   for (int t = 0; t < 3 && t < nk; ++t) issue(t);
   for (int t = 0; t < nk; ++t) {
     // K-tile t has landed: this thread's DMAs of the (at most two) later tiles may still be in flight -- 4 per tile (5 for the W-staging waves of !WPRE)
     const int later = nk - 1 - t < 2 ? nk - 1 - t : 2;
-    if (!WPRE && wave < BN / 8) {
+    if (!WPRE && wave < 2) {
       if (later == 2) SK_VMCNT(10);
       else if (later == 1) SK_VMCNT(5);
       else SK_VMCNT(0);
@@ -118,36 +114,30 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(const half_t* __restri
     asm volatile("" ::: "memory");
     if (t + 3 < nk) issue(t + 3);
     const int sb = (t % SK_STAGES) * STAGE, wb = WPRE ? tile_of(t) * 2048 : sb;
-    half8_t af[2][2], wf[NJ][2];
+    half8_t af[2][2], wf[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(wf[j][ks]) : "v"(fw[ks] + wb + j * 2048) : "memory");
+      asm volatile("ds_read_b128 %0, %1" : "=v"(wf[ks]) : "v"(fw[ks] + wb) : "memory");
       asm volatile("ds_read_b128 %0, %1" : "=v"(af[0][ks]) : "v"(fa[ks] + sb) : "memory");
       asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(af[1][ks]) : "v"(fa[ks] + sb) : "memory");
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j][ks], af[0][ks], acc[0][j], 0, 0, 0);
-        acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j][ks], af[1][ks], acc[1][j], 0, 0, 0);
-      }
+    for (int ks = 0; ks < 2; ++ks) {
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks], af[0][ks], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks], af[1][ks], acc[1], 0, 0, 0);
+    }
   }
 #undef SK_VMCNT
-  // ---- epilogue: lane l owns C[m = 16 (2 wave + i) + (l & 15)][n0 + 16 j + 4 (l >> 4) .. + 3]
+  // ---- epilogue: lane l owns C[m = 16 (2 wave + i) + (l & 15)][n0 + 4 (l >> 4) .. + 3]
+  const int n = n0 + 4 * q4;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int m = 32 * wave + 16 * i + (lane & 15);
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int n = n0 + 16 * j + 4 * q4;
-      if (m < M && n + 3 < N) {
-        const f32x4 v = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-        epi.store(m, n, v, epi.load(m, n));
-      }
+    if (m < M && n + 3 < N) {
+      const f32x4 v = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+      epi.store(m, n, v, epi.load(m, n));
     }
   }
 }
@@ -157,10 +147,6 @@ static inline bool gemm_skinny_ok(const void* A, long lda, const void* W, long l
          !(((uintptr_t)A | (uintptr_t)W) & 15) && (long)M * lda < (1L << 30) && (long)N * ldw < (1L << 30);
 }
 // S K-slices: slice bz covers k in [bz K / S, (bz + 1) K / S); with S > 1 the epilogue must be slab-addressed by the slice (EpiSlabF32)
-// Column-slice width: the L2s deliver ~12 TB/s to the 256 CUs together (256 workgroups x 0.5 MB in 10.7 us with 16-column slices: every width streams A at
-// that aggregate rate), so the time of a launch follows the TOTAL A traffic = column slices x K-slices x rows x K-slice.  S = 1 launches (qkv, fc1: epilogue in
-// the kernel) therefore take 32-column slices when that still gives >= 96 workgroups (half the traffic; W travels with its A tile: 4 KiB per stage); K-sliced
-// launches (proj, fc2) already move little A per workgroup and keep 16 columns with the whole-slice W prefetch.
 template <class Epi>
 static inline int launch_gemm_skinny(const half_t* A, long lda, const half_t* W, long ldw, int M, int N, int K, const Epi& epi, int S, hipStream_t stream) {
   if (!gemm_skinny_ok(A, lda, W, ldw, M, N, K, S)) return LFM_ERR_SHAPE;
@@ -169,23 +155,19 @@ static inline int launch_gemm_skinny(const half_t* A, long lda, const half_t* W,
   (void)hipGetDevice(&devid);
   const unsigned long long bit = 1ull << (devid & 63);
   if (!(attr_set & bit)) {
-    if (hipFuncSetAttribute((const void*)gemm_skinny_kernel<Epi, 16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES(16)) != hipSuccess ||
-        hipFuncSetAttribute((const void*)gemm_skinny_kernel<Epi, 32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES(32)) != hipSuccess)
-      return LFM_ERR_LAUNCH;
+    if (hipFuncSetAttribute((const void*)gemm_skinny_kernel<Epi, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES) != hipSuccess) return LFM_ERR_LAUNCH;
     // the W-prefetch variant takes the CU's whole 160 KiB: where the runtime refuses that much for one workgroup, the tile-by-tile variant serves every shape
-    if (hipFuncSetAttribute((const void*)gemm_skinny_kernel<Epi, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES_WPRE) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)gemm_skinny_kernel<Epi, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES_WPRE) != hipSuccess) {
       (void)hipGetLastError();
       wpre_bad |= bit;
     }
     attr_set |= bit;
   }
   const int Ks = K / S;
-  if (S == 1 && (N % 32) == 0 && N / 32 >= 96 && !lfm_skinny_narrow())
-    hipLaunchKernelGGL((gemm_skinny_kernel<Epi, 32, false>), dim3(N / 32, S), dim3(512), SK_LDS_BYTES(32), stream, A, lda, W, ldw, M, N, Ks, epi);
-  else if (Ks <= SK_WPRE_MAX_KS && !(wpre_bad & bit))
-    hipLaunchKernelGGL((gemm_skinny_kernel<Epi, 16, true>), dim3(N / SK_BN, S), dim3(512), SK_LDS_BYTES_WPRE, stream, A, lda, W, ldw, M, N, Ks, epi);
+  if (Ks <= SK_WPRE_MAX_KS && !(wpre_bad & bit))
+    hipLaunchKernelGGL((gemm_skinny_kernel<Epi, true>), dim3(N / SK_BN, S), dim3(512), SK_LDS_BYTES_WPRE, stream, A, lda, W, ldw, M, N, Ks, epi);
   else
-    hipLaunchKernelGGL((gemm_skinny_kernel<Epi, 16, false>), dim3(N / SK_BN, S), dim3(512), SK_LDS_BYTES(16), stream, A, lda, W, ldw, M, N, Ks, epi);
+    hipLaunchKernelGGL((gemm_skinny_kernel<Epi, false>), dim3(N / SK_BN, S), dim3(512), SK_LDS_BYTES, stream, A, lda, W, ldw, M, N, Ks, epi);
   LFM_CHECK_LAUNCH();
   return LFM_OK;
 }

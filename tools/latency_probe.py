@@ -5,7 +5,7 @@ from lfm_amd import hip
 from lfm_amd.models import DiT_models
 from lfm_amd.solvers import odeint, sample_torchdiffeq_euler_fused
 dev = torch.device("cuda:0")
-for name, flags, skinny in (("DiT-L/2", 0, 1), ("DiT-L/2", 0, 2), ("DiT-L/2", 0, 0), ("DiT-B/2", 0, 1), ("DiT-B/2", 0, 2), ("DiT-B/2", 0, 0)):
+for name, flags, skinny in (("DiT-L/2", 0, 1), ("DiT-L/2", 0, 0), ("DiT-B/2", 0, 1), ("DiT-B/2", 0, 0)):
     hip.gemm_select(flags << 4)  # flag 512: split-K off
     hip.set_option(hip.OPT_SKINNY_GEMM, skinny)  # 1 (default): the all-rows x 16-columns kernel of round 5; 0: the split-K 128x128 path of rounds 2-4
     m = DiT_models[name](img_resolution=32, in_channels=4, num_classes=1, label_dropout=0.0).to(dev).eval()
