@@ -24,7 +24,7 @@
 #include "gemm_kernel.h"
 
 #ifndef SK_ROTATE
-#define SK_ROTATE 1
+#define SK_ROTATE 0
 #endif
 #define SK_BK 64
 #define SK_ROWS 256
@@ -71,8 +71,9 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(const half_t* __restri
   }
   const int wr_t = n0 + (tid >> 3);  // (!WPRE) waves 0, 1 stage the 16 W rows of a tile (tid < 128)
   const unsigned wvoff = ((unsigned)(wr_t < N ? wr_t : N - 1) * (unsigned)ldw + cswz) * 2u;
-  // (experiment) K-tile ORDER rotated per workgroup: step t handles K-tile (t + rot) mod nk, rot = (workgroup / 8) mod nk.  Workgroup i runs on XCD i mod 8 and
-  // the 32 workgroups of an XCD stream the SAME rows of A: in lockstep every K-tile is a first touch of that XCD's L2 for all of them.
+  // (experiment, SK_ROTATE = 1; measured, off) K-tile ORDER rotated per workgroup: step t handles K-tile (t + rot) mod nk.  Two rotations were tried against the idea
+  // that 256 workgroups streaming the same A rows in lockstep camp on L2 channels / all miss the same lines together: rot = workgroup mod nk and rot =
+  // (workgroup / 8) mod nk (de-phasing inside an XCD).  Neither moved the K = 1024 launches (11.1 / 11.4 us vs 10.7): profiles/r05_latency_mode.txt.
   const int rot = SK_ROTATE ? (int)((blockIdx.x >> 3) % (unsigned)nk) : 0;
   auto tile_of = [&](int t) { return t + rot < nk ? t + rot : t + rot - nk; };
   auto issue = [&](int t) {
