@@ -764,13 +764,17 @@ static __global__ __launch_bounds__(256) void splitk_finish_resid_ln_kernel(cons
                                                                      const float* __restrict__ scale, long mod_stride) {
   __shared__ float red[4];
   const int m = blockIdx.x, img = m / tokens, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  f32x4 x[SPLITK_LN_MAXJ];
+  f32x4 x[SPLITK_LN_MAXJ], sc1[SPLITK_LN_MAXJ], sh[SPLITK_LN_MAXJ];
   float s = 0.f;
 #pragma unroll
   for (int j = 0; j < SPLITK_LN_MAXJ; ++j) {
     const int n = threadIdx.x * 4 + 1024 * j;
     x[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (n < N) {
+      if (A) {  // the modulation rows are requested WITH the slabs (round 5): behind the reductions' barriers they were one more dependent round trip
+        sc1[j] = *(const f32x4*)(scale + (long)img * mod_stride + n);
+        sh[j] = *(const f32x4*)(shift + (long)img * mod_stride + n);
+      }
       const float* p = slabs + (long)m * N + n;
       f32x4 v = *(const f32x4*)p;
       for (int q = 1; q < S; ++q) v += *(const f32x4*)(p + (long)q * slice_stride);
@@ -780,7 +784,7 @@ static __global__ __launch_bounds__(256) void splitk_finish_resid_ln_kernel(cons
     }
   }
   if (!A) return;
-  s = wave_sum(s);
+  s = wave_sum_dpp(s);  // DPP cross-lane network: six VALU adds instead of six ds_bpermute round trips
   if (lane == 0) red[wv] = s;
   __syncthreads();
   const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)N;
@@ -792,7 +796,7 @@ static __global__ __launch_bounds__(256) void splitk_finish_resid_ln_kernel(cons
       x[j] -= mean;
       q += (x[j].x * x[j].x + x[j].y * x[j].y) + (x[j].z * x[j].z + x[j].w * x[j].w);
     }
-  q = wave_sum(q);
+  q = wave_sum_dpp(q);
   if (lane == 0) red[wv] = q;
   __syncthreads();
   const float rstd = rsqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)N + 1e-6f);
@@ -800,7 +804,7 @@ static __global__ __launch_bounds__(256) void splitk_finish_resid_ln_kernel(cons
   for (int j = 0; j < SPLITK_LN_MAXJ; ++j) {
     const int n = threadIdx.x * 4 + 1024 * j;
     if (n < N) {
-      const f32x4 o = x[j] * rstd * (1.0f + *(const f32x4*)(scale + (long)img * mod_stride + n)) + *(const f32x4*)(shift + (long)img * mod_stride + n);
+      const f32x4 o = x[j] * rstd * (1.0f + sc1[j]) + sh[j];
       const half4_t h = {(half_t)o.x, (half_t)o.y, (half_t)o.z, (half_t)o.w};
       *(half4_t*)(A + (long)m * N + n) = h;
     }
