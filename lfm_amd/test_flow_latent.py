@@ -122,6 +122,21 @@ def run_sampling(model, first_stage_model, args, num_samples, generator, device,
     return first_stage_model.decode(fake_sample / args.scale_factor).sample
 
 
+def make_lanes(model, vae, device, n_lanes):
+    """[(model, vae, stream)] x n_lanes for batches in flight on one GPU: lane 0 is the model itself, the others are concurrency twins (same packed weights, own
+    workspace / solver buffers / captured graphs).  Every lane stream first waits for the stream the weights were loaded and packed on.  Batches of a sampling job
+    are independent (reference test_flow_latent_ddp.py:128-146) and a lane's result is bit-identical to the one-lane result (tests/test_gpu_cosched.py)."""
+    from .solvers import concurrency_twin
+
+    cur = torch.cuda.current_stream(device)
+    lanes = []
+    for k in range(max(1, n_lanes)):
+        st = torch.cuda.Stream(device)
+        st.wait_stream(cur)
+        lanes.append((model if k == 0 else concurrency_twin(model), vae if k == 0 or vae is None else concurrency_twin(vae), st))
+    return lanes
+
+
 def load_checkpoint(model, path, device, trust_checkpoint=False):
     """``model_{epoch}.pth`` (flat state_dict of an accelerate/DDP-wrapped model, train_flow_latent.py:211-214: ``module.`` stripped when
     present) or ``content.pth`` (train_flow_latent.py:196-203: the weights sit under ``model_dict``)."""
@@ -283,10 +298,26 @@ def main(argv=None):
             with open(args.output_log or os.devnull, "a") as f:
                 f.write("Epoch = {}, FID = {}\n".format(args.epoch_id, fid))
             return
+        # batches in flight: consecutive batches alternate between HIP streams (solvers.concurrency_twin: the same weights, own scratch and captured graphs),
+        # and batch i - 1 is converted / written by the host while batch i runs -- the reference's loop (:264-269) serialises solve, decode and JPEG writes
+        lanes = make_lanes(model, vae, device, int(getattr(args, "in_flight", 0) or 0) or 2)
+        pending = None
+
+        def drain(p):
+            if p is not None:
+                p[0].synchronize()
+                # the single-process script writes through torchvision.utils.save_image: ROUNDING uint8 conversion (:264-269)
+                save_images_uint8(p[1], save_dir, p[2] * n)
+
         for i in range(total_samples // n):
-            img = run_sampling(model, vae, args, n, generator, device)
-            # the single-process script writes through torchvision.utils.save_image: ROUNDING uint8 conversion (:264-269)
-            save_images_uint8(images_to_uint8(img, rounding=True), save_dir, i * n)
+            mdl, va, st = lanes[i % len(lanes)]
+            with torch.cuda.stream(st):
+                u8 = images_to_uint8(run_sampling(mdl, va, args, n, generator, device), rounding=True)
+                done = torch.cuda.Event()
+                done.record(st)
+            drain(pending)
+            pending = (done, u8, i)
+        drain(pending)
         print(f"wrote {total_samples} images to {save_dir} in {time.time() - t0:.1f}s; FID needs pytorch_fid + Inception weights "
               "(not available offline): run the reference's pytorch_fid on that directory (lfm_amd.io_formats has the statistics "
               "reader and the Frechet distance)")

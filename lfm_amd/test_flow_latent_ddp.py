@@ -141,14 +141,9 @@ def run(args, model, vae, generator, rank, world, device, to_uint8, save=None, l
     n_lanes = int(getattr(args, "in_flight", 0) or 0) or (2 if torch.device(device).type == "cuda" else 1)
     lanes = [(model, vae, None)]
     if n_lanes > 1 and torch.device(device).type == "cuda":
-        from .solvers import concurrency_twin
+        from .test_flow_latent import make_lanes
 
-        cur = torch.cuda.current_stream(device)
-        lanes = []
-        for k in range(n_lanes):
-            st = torch.cuda.Stream(device)
-            st.wait_stream(cur)  # weights were loaded / packed on the launching stream
-            lanes.append((model if k == 0 else concurrency_twin(model), vae if k == 0 or vae is None else concurrency_twin(vae), st))
+        lanes = make_lanes(model, vae, device, n_lanes)
     for i in range(iters):
         mdl, va, st = lanes[i % len(lanes)]
         if st is None:

@@ -38,6 +38,19 @@ def test_single_process_driver_euler_and_karras_heun(tmp_path):
     assert sorted(os.listdir(tmp_path / "d"), key=lambda s: int(s.split(".")[0])) == ["0.jpg", "1.jpg", "2.jpg", "3.jpg"]
 
 
+def test_batches_in_flight_write_the_same_files(tmp_path):
+    """--compute_fid with two lanes (default) and with --in_flight 1: four batches of two images each; every JPEG must be byte-identical (the lanes are
+    bit-identical to one lane, and the files are written in batch order under the same global indices)."""
+    cmd = [sys.executable, "-m", "lfm_amd.test_flow_latent", "--model_type", "DiT-S/2", "--num_classes", "1", "--label_dropout", "0.", "--method", "euler",
+           "--step_size", "0.25", "--compute_fid", *[("8" if COMMON[i - 1] == "--n_sample" else a) for i, a in enumerate(COMMON)]]
+    _run(cmd + ["--save_dir", str(tmp_path / "two")])
+    _run(cmd + ["--save_dir", str(tmp_path / "one"), "--in_flight", "1"])
+    names = sorted(os.listdir(tmp_path / "two"), key=lambda s: int(s.split(".")[0]))
+    assert names == [f"{i}.jpg" for i in range(8)] == sorted(os.listdir(tmp_path / "one"), key=lambda s: int(s.split(".")[0]))
+    for nm in names:
+        assert open(tmp_path / "two" / nm, "rb").read() == open(tmp_path / "one" / nm, "rb").read(), nm
+
+
 def test_single_process_driver_dit_at_512(tmp_path):
     """--image_size 512 with a DiT-x/2: 64x64 latents = 1024 tokens per image through the graph-captured Euler solver, decoded at 512x512."""
     common = [("512" if a == "256" else a) for a in COMMON]
