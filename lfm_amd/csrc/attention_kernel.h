@@ -120,29 +120,32 @@ __global__ __launch_bounds__((T / (32 * JQ)) * 64, HD == 64 ? (T / (32 * JQ)) / 
   constexpr int VMIN = SLOTS / NTHR;  // V^T DMAs every wave issues
   static_assert(VMIN == 8 || VMIN == 4, "the counted wait below is vmcnt(VMIN)");
   static_assert(SLOTS % NTHR == 0 || (SLOTS % NTHR) % 64 == 0, "a partial pass is made of whole waves");
-  auto stage_k = [&](int chunk) {
+  // (the chunk loop of the hd-64 kernel passes a laundered copy of tid: the 2 * NPASS per-lane offsets and LDS destinations are recomputed at every re-stage
+  // instead of living -- spilled, 19 dwords under the 128-VGPR budget of two workgroups per CU -- across the key-block loop: 8 x 16 x 1024 x 64 59-62 -> 53-55 us,
+  // tools/attn_1024_time.py; the NCH = 1 kernels issue both stages once, before anything else is live)
+  auto stage_k = [&](int chunk, unsigned tid_) {
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
-      const int s = p * NTHR + tid;
+      const unsigned s = p * NTHR + tid_, wave_ = tid_ >> 6;
       if (SLOTS % NTHR == 0 || p + 1 < NPASS || s < SLOTS) {
         const int row = s / KCH, ch = s - row * KCH;
         const int c = KSWZ ? (ch ^ ((row >> 1) & 7)) : ch;
-        if (MODE != 2) glds16_buf(rs_k, (unsigned)((chunk * T + row) * D + c * 8) * 2u, 0u, Ks + (p * NTHR + wave * 64) * 16);
+        if (MODE != 2) glds16_buf(rs_k, (unsigned)((chunk * T + row) * D + c * 8) * 2u, 0u, Ks + (p * NTHR + wave_ * 64) * 16);
       }
     }
   };
-  auto stage_v = [&](int chunk) {
+  auto stage_v = [&](int chunk, unsigned tid_) {
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
-      const int s = p * NTHR + tid;
+      const unsigned s = p * NTHR + tid_, wave_ = tid_ >> 6;
       if (SLOTS % NTHR == 0 || p + 1 < NPASS || s < SLOTS) {
         constexpr int CPR = T / 8;  // 16-B chunks per V^T row of the staged key chunk
         const int row = s / CPR, c = (s % CPR) ^ (row & VKEY);
-        if (MODE != 2) glds16_buf(rs_v, (unsigned)(row * TT + chunk * T + c * 8) * 2u, 0u, Vs + (p * NTHR + wave * 64) * 16);
+        if (MODE != 2) glds16_buf(rs_v, (unsigned)(row * TT + chunk * T + c * 8) * 2u, 0u, Vs + (p * NTHR + wave_ * 64) * 16);
       }
     }
   };
-  stage_k(0);
+  stage_k(0, tid);
   const int q0 = wave * 32 * JQ;
   const int hsel = lane >> 5, l31 = lane & 31;
   const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -155,7 +158,7 @@ __global__ __launch_bounds__((T / (32 * JQ)) * 64, HD == 64 ? (T / (32 * JQ)) / 
       if (ks * 16 + 16 <= HD) qf[jq][ks] = *(const half8_t*)(qp + ks * 16 + hsel * 8);
       else qf[jq][ks] = hsel ? zero8 : *(const half8_t*)(qp + ks * 16);
     }
-  stage_v(0);
+  stage_v(0, tid);
 
   if constexpr (MODE == 1) {  // everything has landed -> one output row per query, straight from the Q registers
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -282,8 +285,10 @@ __global__ __launch_bounds__((T / (32 * JQ)) * 64, HD == 64 ? (T / (32 * JQ)) / 
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      stage_k(chunk);
-      stage_v(chunk);
+      unsigned tid_l = threadIdx.x;
+      if constexpr (HD == 64) asm volatile("" : "+v"(tid_l));  // hd 72 runs one workgroup per CU under 256 VGPRs: hoisted offsets cost nothing there
+      stage_k(chunk, tid_l);
+      stage_v(chunk, tid_l);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
