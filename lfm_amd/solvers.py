@@ -439,8 +439,9 @@ class GraphedFixedGrid:
         self.ts[: n + 1].copy_(ts.to(torch.float32))
         self.dts[:n].copy_(dts.to(torch.float32))
         self.n_intervals = n
-        self._grid_host = tuple(float(v) for v in ts.detach().cpu().tolist())
-        self._refresh_cond()
+        if self.use_cond_table:  # the table's cache key; only the table needs the grid on the host (a device-resident Karras grid is read back once per solve)
+            self._grid_host = tuple(float(v) for v in ts.detach().cpu().tolist())
+            self._refresh_cond()
 
     def _refresh_cond(self):
         """(Re)fill the conditioning table when the grid or the model's weights changed since it was written (run() asks too: a load_state_dict between
