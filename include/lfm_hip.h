@@ -146,8 +146,9 @@ int lfm_gemm_qkv_f16(const void* A, long lda, const void* W, long ldw, void* Q, 
  * Kernel selection for the GEMMs: 0 = automatic (the 256x256 quadrant-phased kernel on 16x16x32 MFMAs for chip-filling shapes with K % 64 == 0,
  * the 256x128 two-workgroups-per-CU kernel for chip-filling shapes that are only 128 columns wide, the 128x128 kernel otherwise), 1 = force
  * 128x128, 4 = force 256x128, 5 = force 256x256 with eight waves, 6 = force 256x256 with one wave per SIMD (128x128 wave tiles; row-major A
- * operands, K % 64 == 0 -- other cases take kernel 5) (other values are refused); | flags << 4 = ablation / A-B switches.  For measurement and
- * parity tests. */
+ * operands, K % 64 == 0 -- other cases take kernel 5); 7 / 8 = lfm_gemm_f16 (epilogues 0-2, <= 256 rows) on the latency-mode kernels -- 64x64 tiles /
+ * all rows x 16 columns -- which refuse other shapes, every other entry point treats them as 1 (other values are refused); | flags << 4 =
+ * ablation / A-B switches.  For measurement and parity tests. */
 int lfm_gemm_select(int which);
 
 /* Measurement only: when enabled, every eager lfm_dit_forward records a HIP event pair around each block's fc1 GEMM (the
@@ -168,8 +169,9 @@ int lfm_profile_blocks_read(float* host_ms_out, int max_n);
 /* key 2 (LFM_OPT_GEMM_V6), value 0 / 1: the chip-filling row-major GEMMs (the four linears of a DiT block) on the one-wave-per-SIMD 256x256 kernel
  * (csrc/gemm256w_kernel.h) instead of the eight-wave one.  Same accumulation order per output element: bit-identical results. */
 #define LFM_OPT_GEMM_V6 2
-/* key 4 (LFM_OPT_SKINNY_GEMM), value 0 / 1, default 1: evaluations of ONE image of <= 256 tokens (--measure_time, test_flow_latent.py:223-246) run the four
- * linears of a DiTBlock on the all-rows x 16-columns kernel (csrc/gemm_skinny_kernel.h); 0 = the split-K 128x128 path (A/B and parity tests). */
+/* key 4 (LFM_OPT_SKINNY_GEMM), value 0 / 1 / 2, default 1: evaluations of <= 256 token rows (ONE image of 256 tokens: --measure_time, test_flow_latent.py:223-246)
+ * run the four linears of a DiTBlock on the latency-mode kernels -- 64x64 tiles (csrc/gemm_sq64_kernel.h) where the rows are whole 64-row tiles, else all rows x
+ * 16 columns (csrc/gemm_skinny_kernel.h); 2 = always the latter; 0 = the split-K 128x128 path (A/B and parity tests). */
 #define LFM_OPT_SKINNY_GEMM 4
 int lfm_set_option(int key, int value);
 /* The settings lfm_dit_forward would run `call` with if it were enqueued by the calling thread now (per-call fields over the library defaults):

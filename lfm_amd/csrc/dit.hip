@@ -3,6 +3,7 @@
 #include "../../include/lfm_hip.h"
 #include "gemm_dispatch.h"
 #include "gemm_skinny_kernel.h"
+#include "gemm_sq64_kernel.h"
 
 // Library-wide switches = process-wide DEFAULTS (lfm_gemm_select, lfm_set_option); a call that carries its own values (lfm_dit_call.fold_ln /
 // .gemm_select, ABI 4) overrides them in THREAD-LOCAL state for the duration of lfm_dit_forward: every launcher reads the effective value on the
@@ -28,12 +29,13 @@ int lfm_gemm_prefers_v4(int M, int N, int K) {
 }
 static int g_opt_v6 = 0;
 int lfm_gemm_v6_default() { return g_opt_v6; }
-static int g_opt_skinny = 1;  // LFM_OPT_SKINNY_GEMM: the all-rows x 16-columns kernel for the batch-1 DiT linears (gemm_skinny_kernel.h)
+static int g_opt_skinny = 1;  // LFM_OPT_SKINNY_GEMM: the batch-1 DiT linears on their own kernels (1: 64x64 tiles where the image has whole 64-token tiles,
+                               // gemm_sq64_kernel.h, else all rows x 16 columns, gemm_skinny_kernel.h; 2: always the latter; 0: the rounds 2-4 split-K path)
 static int g_stagger = 0;
 int lfm_stagger_ticks() { return g_stagger; }
 static inline bool gemm_select_valid(int which) {
   const int k = which & 15;
-  return which >= 0 && (k == 0 || k == 1 || k == 4 || k == 5 || k == 6);
+  return which >= 0 && (k == 0 || k == 1 || k == 4 || k == 5 || k == 6 || k == 7 || k == 8);  // 7, 8: the latency-mode kernels through lfm_gemm_f16 (tests)
 }
 struct CallScope {  // per-call settings of one lfm_dit_forward on this thread (restored on every return path)
   int sel_set, sel, dbg, fold;
@@ -79,7 +81,7 @@ extern "C" int lfm_set_option(int key, int value) {  // key 1 (LFM_OPT_FOLD_LN):
     return LFM_OK;
   }
   if (key == 4) {  // LFM_OPT_SKINNY_GEMM: 0 = the split-K 128x128 path of rounds 2-4 for M <= 256 (A/B, parity)
-    g_opt_skinny = value != 0;
+    g_opt_skinny = value < 0 || value > 2 ? 1 : value;
     return LFM_OK;
   }
 #ifdef LFM_MEASURE
@@ -90,7 +92,7 @@ extern "C" int lfm_set_option(int key, int value) {  // key 1 (LFM_OPT_FOLD_LN):
 #endif
   return LFM_ERR_ARG;
 }
-extern "C" int lfm_gemm_select(int which) {  // low 4 bits: kernel choice (0 auto, 1, 4, 5, 6); bits 4+: ablation flags (measurement only)
+extern "C" int lfm_gemm_select(int which) {  // low 4 bits: kernel choice (0 auto, 1, 4, 5, 6; 7, 8 for lfm_gemm_f16 only); bits 4+: ablation flags (measurement only)
   if (!gemm_select_valid(which)) return LFM_ERR_ARG;
   g_gemm_sel_default = which & 15;
   g_gemm_dbg_default = which >> 4;
@@ -998,6 +1000,19 @@ extern "C" int lfm_gemm_f16(const void* A, long lda, const void* W, long ldw, vo
   if ((lda % 8) || ((uintptr_t)A & 15)) return LFM_ERR_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   ASrcRowMajor a{(const half_t*)A, lda, M, 0};
+  if (g_gemm_sel == 7 || g_gemm_sel == 8) {  // the latency-mode kernels on their own (parity tests): 7 = 64x64 tiles, 8 = all rows x 16 columns; <= 256 rows
+    const int which = g_gemm_sel;
+    auto lat = [&](const auto& e) {
+      return which == 7 ? launch_gemm_sq64((const half_t*)A, lda, (const half_t*)W, ldw, M, N, K, e, 1, st)
+                        : launch_gemm_skinny((const half_t*)A, lda, (const half_t*)W, ldw, M, N, K, e, 1, st);
+    };
+    switch (epilogue) {
+      case 0: return lat(EpiBiasF16{(half_t*)C, ldc, bias});
+      case 1: return bias ? lat(EpiBiasGeluF16{(half_t*)C, ldc, bias}) : LFM_ERR_ARG;
+      case 2: return lat(EpiBiasF32{(float*)C, ldc, bias});
+      default: return LFM_ERR_ARG;
+    }
+  }
   switch (epilogue) {
     case 0:
 #ifdef LFM_MEASURE
@@ -1444,10 +1459,21 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
     while ((N_ / SK_BN) * (sl * 2) <= 256 && (K_ % (sl * 2 * SK_BK)) == 0 && K_ / (sl * 2) >= 2 * SK_BK && (size_t)(sl * 2) * M * N_ * 4 <= ws.slab_bytes) sl *= 2;
     return sl;
   };
-  const int sk_s_proj = sk_slices(D, D), sk_s_fc2 = sk_slices(D, H);
+  // ... or, for images of whole 64-token tiles, on the 64x64 kernel (gemm_sq64_kernel.h: half the bytes per workgroup)
+  auto sq_slices = [&](int N_, int K_) {
+    int sl = 1;
+    while ((N_ / SQ_T) * (M / SQ_T) * (sl * 2) <= 256 && (K_ % (sl * 2 * SQ_BK)) == 0 && K_ / (sl * 2) >= 2 * SQ_BK && (size_t)(sl * 2) * M * N_ * 4 <= ws.slab_bytes) sl *= 2;
+    return sl;
+  };
+  const bool sq64 = g_opt_skinny == 1 && M >= SQ_T && (M % SQ_T) == 0 && gemm_sq64_ok(ws.A, D, w->qkv_w, D, M, 3 * D, D, 1) && gemm_sq64_ok(ws.A, D, w->fc1_w, D, M, H, D, 1) &&
+                    gemm_sq64_ok(ws.A, D, w->proj_w, D, M, D, D, sq_slices(D, D)) && gemm_sq64_ok(ws.QKVH, H, w->fc2_w, H, M, D, H, sq_slices(D, H));
+  const int sk_s_proj = sq64 ? sq_slices(D, D) : sk_slices(D, D), sk_s_fc2 = sq64 ? sq_slices(D, H) : sk_slices(D, H);
   const bool skinny = !fold && g_opt_skinny && g_gemm_sel == 0 && M <= SK_ROWS && ws.slab && D <= 1024 * SPLITK_LN_MAXJ && (D % 4) == 0 &&
                       gemm_skinny_ok(ws.A, D, w->qkv_w, D, M, 3 * D, D, 1) && gemm_skinny_ok(ws.A, D, w->fc1_w, D, M, H, D, 1) &&
                       gemm_skinny_ok(ws.A, D, w->proj_w, D, M, D, D, sk_s_proj) && gemm_skinny_ok(ws.QKVH, H, w->fc2_w, H, M, D, H, sk_s_fc2);
+  auto lat_gemm = [&](const half_t* A_, long lda_, const half_t* W_, int N_, int K_, const auto& epi_, int S_) {  // the latency-mode linear: lda == ldw == K
+    return sq64 ? launch_gemm_sq64(A_, lda_, W_, (long)K_, M, N_, K_, epi_, S_, st) : launch_gemm_skinny(A_, lda_, W_, (long)K_, M, N_, K_, epi_, S_, st);
+  };
   bool a_ready = false;  // latency mode: the previous split-K finish already wrote this LayerNorm's output
   for (int i = 0; i < (fold ? 0 : s->depth); ++i) {
     const float* mod = ws.mod + (long)i * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
@@ -1457,7 +1483,7 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
     }
     a_ready = false;
     const EpiQKV e_qkv = EpiQKV::make(Qb, Kb, Vb, w->qkv_b + (size_t)i * 3 * D, D, D / s->heads, T);
-    if (skinny) rc = launch_gemm_skinny(ws.A, D, (const half_t*)w->qkv_w + (size_t)i * 3 * D * D, D, M, 3 * D, D, e_qkv, 1, st);
+    if (skinny) rc = lat_gemm(ws.A, D, (const half_t*)w->qkv_w + (size_t)i * 3 * D * D, 3 * D, D, e_qkv, 1);
     else {
       rc = launch_gemm_splitk(ws.A, D, (const half_t*)w->qkv_w + (size_t)i * 3 * D * D, D, M, 3 * D, D, e_qkv, ws.slab, ws.slab_bytes, st);
       if (rc == 1) rc = launch_gemm_auto(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->qkv_w + (size_t)i * 3 * D * D, D, M, 3 * D, D, e_qkv, st);
@@ -1468,7 +1494,7 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
     const EpiGateResidF32 e_proj{ws.X, D, w->proj_b + (size_t)i * D, mod + 2 * D, mstride, T};
     // small M: split-K whose finish kernel is also the LayerNorm-modulate in front of fc1 (its input ws.A is consumed by the slab GEMM before the finish writes it)
     if (skinny) {  // K-slices of the skinny kernel into slabs, then the row-owning finish that is also the LayerNorm-modulate in front of fc1
-      rc = launch_gemm_skinny(ws.A, D, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D, EpiSlabF32{ws.slab, (long)D, (long)M * D}, sk_s_proj, st);
+      rc = lat_gemm(ws.A, D, (const half_t*)w->proj_w + (size_t)i * D * D, D, D, EpiSlabF32{ws.slab, (long)D, (long)M * D}, sk_s_proj);
       if (rc) return rc;
       hipLaunchKernelGGL(splitk_finish_resid_ln_kernel, dim3(M), dim3(256), 0, st, ws.slab, sk_s_proj, (long)M * D, D, e_proj.X, e_proj.ldx, e_proj.bias, e_proj.gate,
                          e_proj.gate_stride, e_proj.tokens, ws.A, mod + 3 * D, mod + 4 * D, mstride);
@@ -1485,7 +1511,7 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
     const bool prof = prof_ok && g_prof_mode == 1 && g_prof_count < LFM_PROF_MAX;
     if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_count], st);
     const EpiBiasGeluF16 e_fc1{ws.QKVH, H, w->fc1_b + (size_t)i * H};
-    if (skinny) rc = launch_gemm_skinny(ws.A, D, (const half_t*)w->fc1_w + (size_t)i * H * D, D, M, H, D, e_fc1, 1, st);
+    if (skinny) rc = lat_gemm(ws.A, D, (const half_t*)w->fc1_w + (size_t)i * H * D, H, D, e_fc1, 1);
     else {
       rc = launch_gemm_splitk(ws.A, D, (const half_t*)w->fc1_w + (size_t)i * H * D, D, M, H, D, e_fc1, ws.slab, ws.slab_bytes, st);
       if (rc == 1) rc = launch_gemm_auto(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->fc1_w + (size_t)i * H * D, D, M, H, D, e_fc1, st);
@@ -1495,7 +1521,7 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
     const EpiGateResidF32 e_fc2{ws.X, D, w->fc2_b + (size_t)i * D, mod + 5 * D, mstride, T};
     const bool more = i + 1 < s->depth;  // ... and the one in front of the NEXT block's qkv (its shift_msa / scale_msa)
     if (skinny) {
-      rc = launch_gemm_skinny(ws.QKVH, H, (const half_t*)w->fc2_w + (size_t)i * D * H, H, M, D, H, EpiSlabF32{ws.slab, (long)D, (long)M * D}, sk_s_fc2, st);
+      rc = lat_gemm(ws.QKVH, H, (const half_t*)w->fc2_w + (size_t)i * D * H, D, H, EpiSlabF32{ws.slab, (long)D, (long)M * D}, sk_s_fc2);
       if (rc) return rc;
       hipLaunchKernelGGL(splitk_finish_resid_ln_kernel, dim3(M), dim3(256), 0, st, ws.slab, sk_s_fc2, (long)M * D, D, e_fc2.X, e_fc2.ldx, e_fc2.bias, e_fc2.gate,
                          e_fc2.gate_stride, e_fc2.tokens, more ? ws.A : (half_t*)nullptr, mod + 6 * D, mod + 7 * D, mstride);

@@ -56,6 +56,52 @@ def test_gemm_epilogues(dev, M, N, K, epi):
     assert rel_l2(got, ref) < (2e-3 if epi in (0, 1) else 2e-4)
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 3072, 1024), (256, 1024, 4096), (128, 192, 64), (192, 1152, 1152), (64, 64, 128), (256, 4608, 1152), (256, 2304, 768)])
+@pytest.mark.parametrize("kernel", [7, 8])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_latency_mode_kernels_alone(dev, kernel, M, N, K, epi):
+    """The two batch-1 kernels through lfm_gemm_f16 (lfm_gemm_select 7 = 64x64 tiles with the XCD-grouped tile order where the column tiles are a multiple
+    of 8 and the plain order elsewhere, csrc/gemm_sq64_kernel.h; 8 = all rows x 16 columns, csrc/gemm_skinny_kernel.h) against the fp32 product; K-tile counts
+    from 1 (every DMA in flight at once) to 64 (the ring wraps eight times); the same summation order per output element, so the two agree bit for bit."""
+    from lfm_amd import hip
+
+    g = torch.Generator().manual_seed(M * 5 + N + K + epi)
+    A = (torch.randn(M, K, generator=g) * 0.5).half().to(dev)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).half().to(dev)
+    bias = torch.randn(N, generator=g) * 0.1
+    ref = A.float().cpu() @ W.float().cpu().t() + bias
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref, approximate="tanh")
+    outs = {}
+    try:
+        for k in (kernel, 15 - kernel):
+            hip.gemm_select(k)
+            outs[k] = hip.gemm_f16(A, W, bias.to(dev), epilogue=epi).clone()
+    finally:
+        hip.gemm_select(0)
+    torch.cuda.synchronize()
+    assert rel_l2(outs[kernel], ref) < (2e-3 if epi in (0, 1) else 2e-4)
+    assert torch.equal(outs[7], outs[8])
+
+
+def test_latency_mode_kernels_refuse_other_shapes(dev):
+    from lfm_amd import hip
+
+    A = torch.zeros(200, 128, device=dev).half()
+    W = torch.zeros(64, 128, device=dev).half()
+    b = torch.zeros(64, device=dev)
+    try:
+        hip.gemm_select(7)
+        with pytest.raises(RuntimeError):
+            hip.gemm_f16(A, W, b, epilogue=0)  # 200 rows: not whole 64-row tiles
+        hip.gemm_select(8)
+        hip.gemm_f16(A, W, b, epilogue=0)  # the all-rows kernel takes ragged row counts
+        with pytest.raises(RuntimeError):
+            hip.gemm_f16(torch.zeros(320, 128, device=dev).half(), W, b, epilogue=0)  # more than 256 rows
+    finally:
+        hip.gemm_select(0)
+
+
 @functools.lru_cache(maxsize=64)
 def _gemm_case(M, N, K, epi):
     """Host operands and the fp32 reference of one (shape, epilogue) case: shared by every kernel the case is run with."""
@@ -344,9 +390,10 @@ def test_dit_matches_oracle_fullsize(dev, name, batch, kw):
     ("DiT-B/4", 3, dict(num_classes=1, label_dropout=0.0)),      # three images of 64 tokens: 192 rows (ragged against the kernel's 256), patch-4 embedding
 ])
 def test_skinny_latency_kernel_vs_splitk_path_and_oracle(dev, name, batch, kw):
-    """Evaluations of <= 256 token rows run their four block linears on the all-rows x 16-columns kernel (csrc/gemm_skinny_kernel.h, default): the same
-    forward as the split-K 128x128 path of rounds 2-4 (lfm_set_option(LFM_OPT_SKINNY_GEMM, 0)) up to the fp32 summation order, bit-repeatable, and inside
-    the per-forward budget against the CPU oracle."""
+    """Evaluations of <= 256 token rows run their four block linears on the latency-mode kernels (default: 64x64 tiles, csrc/gemm_sq64_kernel.h, where the
+    rows are whole 64-token tiles, else all rows x 16 columns, csrc/gemm_skinny_kernel.h; option value 2 forces the latter): the same forward as the
+    split-K 128x128 path of rounds 2-4 (lfm_set_option(LFM_OPT_SKINNY_GEMM, 0)) up to the fp32 summation order, bit-repeatable, and inside the
+    per-forward budget against the CPU oracle."""
     from lfm_amd import hip
     from lfm_amd.models import DiT_models
 
@@ -362,17 +409,21 @@ def test_skinny_latency_kernel_vs_splitk_path_and_oracle(dev, name, batch, kw):
     xd, td, yd = x.to(dev), t.to(dev), (y.to(dev) if y is not None else None)
     a = m(td, xd, yd).clone()
     b = m(td, xd, yd).clone()
-    hip.set_option(hip.OPT_SKINNY_GEMM, 0)
     try:
+        hip.set_option(hip.OPT_SKINNY_GEMM, 2)  # always all rows x 16 columns (1 = default: 64x64 tiles where the rows are whole 64-token tiles)
+        sk = m(td, xd, yd).clone()
+        sk2 = m(td, xd, yd).clone()
+        hip.set_option(hip.OPT_SKINNY_GEMM, 0)
         old = m(td, xd, yd).clone()
     finally:
         hip.set_option(hip.OPT_SKINNY_GEMM, 1)
     torch.cuda.synchronize()
-    assert torch.equal(a, b)
-    assert not torch.equal(a, old), "the skinny kernel did not run (preconditions?)"
-    assert rel_l2(a, old) < 2e-4  # same fp16 operands, fp32 accumulation in another order
+    assert torch.equal(a, b) and torch.equal(sk, sk2)
+    assert not torch.equal(a, old) and not torch.equal(sk, old), "the latency-mode kernels did not run (preconditions?)"
+    assert rel_l2(a, old) < 2e-4 and rel_l2(sk, old) < 2e-4  # same fp16 operands, fp32 accumulation in another order
+    assert torch.equal(a, sk)  # the two latency-mode kernels slice K alike and sum in the same order (which one ran: profiles/r05_latency_mode.txt)
     ref = dit_ref.dit_forward(sd, cfg, t, x, y)
-    assert rel_l2(a, ref) < 2e-3 and rel_l2(old, ref) < 2e-3
+    assert rel_l2(a, ref) < 2e-3 and rel_l2(sk, ref) < 2e-3 and rel_l2(old, ref) < 2e-3
 
 
 @pytest.mark.parametrize("name,batch,kw", [
