@@ -47,8 +47,11 @@ static __device__ unsigned long long att_wg_trace[ATT_WG_TRACE][4];
 // NCH > 1 (round 4: DiT at 1024 tokens, models/DiT.py:179-182 with --image_size 512): the sequence has NCH * T tokens.  A workgroup owns T QUERIES
 // (blockIdx.z = which block of T) and walks the keys in NCH chunks of T through the same LDS image -- the online softmax state carries over; a chunk
 // is re-staged behind a barrier (no cross-chunk prefetch: this shape is off the benchmarked path).
-template <int T, int JQ, int HD, int MODE = 0, int NCH = 1>
-__global__ __launch_bounds__((T / (32 * JQ)) * 64, HD == 64 ? (T / (32 * JQ)) / 2 : 2) void dit_attention_kernel(
+// QS > 1 (round 5, latency mode: one image = `heads` workgroups for 256 CUs): the queries of an (image, head) item are split over QS workgroups (blockIdx.z) that
+// each stage ALL keys; T / (32 JQ QS) waves, one per SIMD instead of two for QS = 2 -- the softmax VALU stream of a wave no longer shares its SIMD.  Same
+// arithmetic per query, same key order: bit-identical to QS = 1 (tests/test_gpu_dit.py::test_attention_query_split_matches).
+template <int T, int JQ, int HD, int MODE = 0, int NCH = 1, int QS = 1>
+__global__ __launch_bounds__((T / (32 * JQ * QS)) * 64, HD == 64 && QS == 1 ? (T / (32 * JQ)) / 2 : 2) void dit_attention_kernel(
     const half_t* __restrict__ Q, const half_t* __restrict__ K, const half_t* __restrict__ Vt, half_t* __restrict__ O, int D, int heads,
     float scale_log2e, int stag) {
   constexpr int TT = T * NCH;  // tokens of the sequence
@@ -62,9 +65,10 @@ __global__ __launch_bounds__((T / (32 * JQ)) * 64, HD == 64 ? (T / (32 * JQ)) / 
   }
 #endif
   static_assert(NCH == 1 || MODE == 0, "measurement variants are single-chunk");
+  static_assert(QS == 1 || (NCH == 1 && MODE == 0 && T % (32 * JQ * QS) == 0), "the query split is for the single-chunk product kernel");
   static_assert(HD % 8 == 0 && HD >= 32 && HD <= 128, "head_dim: whole 16-byte chunks");
   constexpr int NKB = T / 32;         // 32-key blocks
-  constexpr int NW = T / (32 * JQ);   // waves: each owns JQ blocks of 32 queries
+  constexpr int NW = T / (32 * JQ * QS);  // waves: each owns JQ blocks of 32 queries
   constexpr int NTHR = NW * 64;
   constexpr int KS = (HD + 15) / 16;  // k-slots of the S MFMAs (the last one half empty when HD % 16 == 8)
   constexpr int NDB = (HD + 31) / 32; // 32-row blocks of O^T
@@ -146,7 +150,7 @@ __global__ __launch_bounds__((T / (32 * JQ)) * 64, HD == 64 ? (T / (32 * JQ)) / 
     }
   };
   stage_k(0, tid);
-  const int q0 = wave * 32 * JQ;
+  const int q0 = ((QS > 1 ? (int)blockIdx.z * NW : 0) + wave) * 32 * JQ;
   const int hsel = lane >> 5, l31 = lane & 31;
   const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
   half8_t qf[JQ][KS];
@@ -493,6 +497,14 @@ static int attention_launch(const half_t* Q, const half_t* K, const half_t* Vt, 
       set |= dbit;
       hipLaunchKernelGGL((dit_attention_kernel<256, 1, 72, 0, 4>), grid4, dim3(512), (size_t)256 * 72 * 4, st, Q, K, Vt, O, D, heads, sl2, lfm_stagger_ticks());
     }
+    LFM_CHECK_LAUNCH();
+    return LFM_OK;
+  }
+  if (hd == 64 && T == 256 && narrow && batch * heads <= 64) {  // latency mode: two workgroups of four waves per (image, head)
+    static unsigned long long set = 0;
+    if (!(set & dbit)) (void)hipFuncSetAttribute((const void*)dit_attention_kernel<256, 1, 64, 0, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 64 * 4);
+    set |= dbit;
+    hipLaunchKernelGGL((dit_attention_kernel<256, 1, 64, 0, 1, 2>), dim3(heads, batch, 2), dim3(256), lds, st, Q, K, Vt, O, D, heads, sl2, 0);
     LFM_CHECK_LAUNCH();
     return LFM_OK;
   }

@@ -267,6 +267,27 @@ def test_attention(dev, T, heads, batch, hd):
     assert float(per_item.max()) < 4e-3  # no single (image, head) item is off (a stale-buffer bug would hit whole items)
 
 
+@pytest.mark.parametrize("small", [1, 2, 4])
+def test_attention_query_split_matches(dev, small):
+    """<= 64 (image, head) items of 256 tokens x hd 64 (latency mode: one to four DiT-L images) run the query-split kernel -- two four-wave workgroups per item,
+    each staging every key: the same arithmetic per query in the same key order, so the leading `small` images of a batch of 8 (128 items: the eight-wave
+    kernel) come out bit for bit the same when they are evaluated on their own."""
+    from lfm_amd import hip
+
+    T, heads, hd, batch = 256, 16, 64, 8
+    g = torch.Generator().manual_seed(small)
+    D = heads * hd
+    Q = (torch.randn(batch * T, D, generator=g) * 1.5).half().to(dev)
+    K = (torch.randn(batch * T, D, generator=g) * 1.5).half().to(dev)
+    Vt = torch.randn(batch, heads, hd, T, generator=g).half().to(dev)
+    K[5, :hd] *= 6  # a spiky key row of the first item
+    full = hip.dit_attention(Q, K, Vt, batch, heads, T, head_dim=hd)
+    part = hip.dit_attention(Q[: small * T].contiguous(), K[: small * T].contiguous(), Vt[:small].contiguous(), small, heads, T, head_dim=hd)
+    torch.cuda.synchronize()
+    assert torch.equal(part, full[: small * T])
+    assert float(part.float().abs().mean()) > 1e-3
+
+
 def test_attention_refuses_unbuilt_head_sizes(dev):
     from lfm_amd import hip
 
