@@ -1357,7 +1357,7 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
   }
   if (rc) return rc;
   if (pe_mfma) {
-    const int tpb = 2;
+    const int tpb = M <= 1024 ? 1 : 2;  // latency mode: twice the blocks (16 for one image), one 16-token tile each behind the weight-fragment prologue
     hipLaunchKernelGGL(patch_embed_ln_kernel, dim3(cdiv(M, 16 * tpb)), dim3(64 * (D / 256)), 0, st, c->x, w->patch_w, w->patch_b, w->pos_embed, ws.X,
                        M, cfg ? B / 2 : B, s->res, D, tpb, fold ? ws.A : (half_t*)nullptr, ws.mod + D, mstride, ws.ln_part, tiles_p, ws.cen[0]);
     LFM_CHECK_LAUNCH();
