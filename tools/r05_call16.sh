@@ -1,6 +1,6 @@
 #!/bin/bash
 # 1024-token attention without the staging-offset spills: tests + before/after timing (LFM_HIP_LIBRARY selects the library build)
-# the 'before' library (not tracked): check out csrc/attention_kernel.h of commit ffbb578^ (b749e2f), bash tools/build_variant.sh att_before, restore the file
+# the 'before' library (not tracked): git checkout ce23b04 -- lfm_amd/csrc/attention_kernel.h; bash tools/build_variant.sh att_before, restore the file
 mkdir -p gpurun_out
 {
 python -m pytest tests/test_gpu_dit.py -q -k "attention or 1024_tokens" 2>&1 | tail -3
