@@ -208,7 +208,8 @@ def require_gpu(t, what):
 
 # ----------------------------------------------------------------------------- thin op wrappers (used by tests)
 def gemm_select(which):
-    """Force a GEMM kernel (0 auto, 1 128x128, 4 256x128, 5 256x256 eight waves, 6 256x256 four waves) | ablation flags << 4; A/B measurements
+    """Force a GEMM kernel (0 auto, 1 128x128, 4 256x128, 5 256x256 eight waves, 6 256x256 four waves; 7 / 8: gemm_f16 on the batch-1 kernels, 64x64 tiles /
+    all rows x 16 columns) | ablation flags << 4; A/B measurements
     and parity tests only.  Raises on a value the library rejects (a silently ignored selection invalidates an A/B)."""
     check(lib().lfm_gemm_select(int(which)), "lfm_gemm_select")
 
