@@ -186,6 +186,7 @@ def build_workload(a, dev, rank):
 
     vae = AutoencoderKL.from_random(seed=0).to(dev)
     g = torch.Generator().manual_seed(42 + rank)
+    lane_solver = None  # every fixed-grid configuration defines it below (a solver with its own buffers / captured graphs on a given module); None = one lane only
     if a.config == 2:
         name = a.model or "DiT-L/2"
         B = a.batch or 64
@@ -289,7 +290,7 @@ def build_workload(a, dev, rank):
         wl = f"origin-ADM celeb512 (352 M params), 4x64x64 latents, batch {B}/GPU, {a.nfe}-step Euler + f8 VAE decode to 512x512 + uint8 NHWC"
         x_shape, res, extra = (B, 4, 64, 64), 64, {"nfe": a.nfe}
     x_host = torch.randn(*x_shape, generator=g).pin_memory()
-    return dict(model=model, vae=vae, solve=solve, lane_solver=locals().get("lane_solver"), B=B, res=res, x_host=x_host, workload=wl, f_model=f_model,
+    return dict(model=model, vae=vae, solve=solve, lane_solver=lane_solver, B=B, res=res, x_host=x_host, workload=wl, f_model=f_model,
                 f_vae=vae_decode_flops(res),
                 extra=extra, name=(a.model or {2: "DiT-L/2", 3: "DiT-L/2", 4: "DiT-B/2", 5: "ADM-celeb512", 6: "EDM-ADM-ffhq"}[a.config]))
 
@@ -503,11 +504,11 @@ def main():
     B, vae, solve = w["B"], w["vae"], w["solve"]
     S = 8 * w["res"]
     x_dev = torch.empty(w["x_host"].shape, device=dev)
-    pipe = GatherPipeline(world, dev)
     gather_ms = []
 
     lanes = None
     in_flight = a.in_flight or (2 if w["lane_solver"] is not None else 1)
+    pipe = GatherPipeline(world, dev, depth=in_flight)  # a batch's gathered block is waited for `in_flight` submissions later: never behind a batch just enqueued
     if in_flight > 1:
         # two batches in flight: consecutive steps go to two HIP streams, each with its own solver buffers / captured graphs / workspaces on the SAME weights
         if w["lane_solver"] is None:
@@ -552,7 +553,8 @@ def main():
         return u8
 
     def fence():
-        pipe.flush()
+        while pipe.flush() is not None:
+            pass
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

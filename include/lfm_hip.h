@@ -31,6 +31,11 @@ typedef void* lfm_stream_t; /* hipStream_t */
 #define LFM_ERR_ARG (-5)
 
 const char* lfm_strerror(int code);
+/* The ABI this header describes.  The call structs below GROW between ABI versions (lfm_dit_call gained fields in 3 and 4) and the library reads every
+ * field of the struct it is handed, so a caller compiled against an older header would pass a struct that is too short: a C / cgo / JNI caller checks
+ * `lfm_abi_version() == LFM_ABI_VERSION` ONCE, after loading the library and before the first call (the Python binding refuses a mismatching library at
+ * load time: lfm_amd/hip.py; tests/test_c_abi.py does it from C). */
+#define LFM_ABI_VERSION 4
 int lfm_abi_version(void);
 
 /* ------------------------------------------------------------------ DiT velocity field
@@ -173,6 +178,10 @@ int lfm_profile_blocks_read(float* host_ms_out, int max_n);
  * run the four linears of a DiTBlock on the latency-mode kernels -- 64x64 tiles (csrc/gemm_sq64_kernel.h) where the rows are whole 64-row tiles, else all rows x
  * 16 columns (csrc/gemm_skinny_kernel.h); 2 = always the latter; 0 = the split-K 128x128 path (A/B and parity tests). */
 #define LFM_OPT_SKINNY_GEMM 4
+/* key 5 (LFM_OPT_ATTENTION_STREAM), value 0 / 1, default 1: lfm_dit_attention at 256 tokens x head_dim 64 with more than 64 (image, head) items runs on persistent
+ * workgroups that stream K / V^T of consecutive items through an LDS ring (csrc/attention_stream_kernel.h); 0 = one workgroup per item (csrc/attention_kernel.h).
+ * Same arithmetic in the same order per query: bit-identical results (tests/test_gpu_dit.py). */
+#define LFM_OPT_ATTENTION_STREAM 5
 int lfm_set_option(int key, int value);
 /* The settings lfm_dit_forward would run `call` with if it were enqueued by the calling thread now (per-call fields over the library defaults):
  * *gemm_select_out = kernel | flags << 4, *fold_ln_out = 0 / 1.  No launch; usable without a GPU. */

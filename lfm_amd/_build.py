@@ -28,6 +28,39 @@ if os.environ.get("LFM_MEASURE") == "1":  # measurement builds: the s_memtime-st
     FLAGS.append("-DLFM_MEASURE")
 
 
+OBJDUMP = os.path.join(os.path.dirname(os.path.dirname(HIPCC)), "lib", "llvm", "bin", "llvm-objdump")
+
+
+def opsel_scan(lib):
+    """-> {(kernel, instruction, 'op_sel:[..]'): count}: every packed-fp32 instruction of the gfx950 code objects bundled in `lib` with an op_sel operand (a half
+    of the packed operation takes its source from the OTHER register of the pair) -- the form that read its operand as 0.0 in lanes 48-63 under co-scheduling
+    (csrc/common.h: fma_v; profiles/r05_cosched_root_cause.txt).  The build refuses a library that holds one; tests/test_host_logic.py asserts it again."""
+    import collections
+    import re
+    import tempfile
+
+    out = collections.Counter()
+    with tempfile.TemporaryDirectory() as td:
+        tmp = os.path.join(td, "lib.so")
+        os.symlink(os.path.abspath(lib), tmp)
+        subprocess.run([OBJDUMP, "--offloading", tmp], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=td)
+        for f in sorted(os.listdir(td)):
+            if "amdgcn" not in f:
+                continue
+            dis = subprocess.run([OBJDUMP, "-d", os.path.join(td, f)], check=True, capture_output=True, text=True).stdout
+            cur = None
+            for line in dis.splitlines():
+                m = re.match(r"^[0-9a-f]+ <(.*)>:", line)
+                if m:
+                    cur = m.group(1)
+                    continue
+                if "v_pk_" in line and "_f32" in line:
+                    sel = re.search(r"op_sel:\[([0-9,]+)\]", line)
+                    if sel and "1" in sel.group(1):
+                        out[(cur, line.split()[0], sel.group(1))] += 1
+    return out
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -98,6 +131,12 @@ def _build_locked(dig, verbose):
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout.decode()}")
+    if os.path.exists(OBJDUMP) and os.environ.get("LFM_SKIP_OPSEL_SCAN") != "1":  # the co-scheduling guard, at BUILD time (round-5 advisor finding: the fix depends on code generation)
+        found = opsel_scan(tmp)
+        if found:
+            os.unlink(tmp)
+            raise RuntimeError("the built library holds packed-fp32 instructions with op_sel (csrc/common.h: fma_v / row_affine4):\n" + "\n".join(
+                f"  {n} x {ins} op_sel:[{sel}] in {k}" for (k, ins, sel), n in sorted(found.items(), key=lambda x: -x[1])[:10]))
     os.replace(tmp, LIB)
     open(STAMP, "w").write(dig)
     return LIB

@@ -17,18 +17,17 @@
 // the live state at S 32 + P 16 + O 64 + Q 32 registers for hd 64, JQ 2 (2 waves / SIMD).
 #pragma once
 #include "gemm_kernel.h"
+#include "attention_stream_kernel.h"
 
 int lfm_gemm_debug_flags();
+int lfm_attention_stream_enabled();  // LFM_OPT_ATTENTION_STREAM (dit.hip)
 
 // MODE 3 (measurement only): s_memtime stamps of wave 0 of the first workgroup (slots 0..31) and of the last one (32..63), read back with
 // lfm_attention_trace_read.  Slots: 0 start, 1 all DMAs / Q loads issued, 2 K and Q landed (first barrier), 3 + 4 k + {0: S(next) issued,
 // 1: softmax + PV of the even block done, 2: S(next even) issued, 3: softmax + PV of the odd block done} for the k-th loop iteration,
 // 19 stores issued, 20 stores acknowledged; inside the first softmax_pv: 21 softmax VALU done, 22 V^T landed (barrier), 23 PV MFMAs issued.
-#define ATT_TRACE_SLOTS 64
-static __device__ unsigned long long att_trace[ATT_TRACE_SLOTS];
+// (the arrays are declared by attention_stream_kernel.h, included above: both kernels stamp into them)
 // MODE 3 also records, per workgroup (linear id < 2048): {HW_ID | XCC_ID << 32, start, loads landed, end} -- which CU it ran on and when
-#define ATT_WG_TRACE 2048
-static __device__ unsigned long long att_wg_trace[ATT_WG_TRACE][4];
 
 // MODE (measurement only, tools/r2_probe3.py): 0 = the kernel; 1 = memory phases only (stage K / V^T, fetch Q, store a row per query, no
 // S / softmax / PV); 2 = compute only (K / V^T are never fetched: the loop runs on whatever the LDS holds).  Round 2, 64 images x 16 heads x 256
@@ -223,40 +222,8 @@ __global__ __launch_bounds__((T / (32 * JQ * QS)) * 64, HD == 64 && QS == 1 ? (T
   auto softmax_pv = [&](f32x16 (&S)[JQ], int kb) {
     half8_t P[JQ][2];
 #pragma unroll
-    for (int jq = 0; jq < JQ; ++jq) {
-      float mx = fmaxf(fmaxf(S[jq][0], S[jq][1]), S[jq][2]);
-#pragma unroll
-      for (int e = 3; e < 15; e += 2) mx = fmaxf(fmaxf(mx, S[jq][e]), S[jq][e + 1]);
-      mx = fmaxf(mx, S[jq][15]);
-      mx = fmaxf(mx, xhalf(mx));
-      // LAZY RESCALE (round 3): mrun is the max the exponents are taken against, and it follows the true running max only when that has moved
-      // by more than 2^8 (so P <= 256 in fp16; row sums and O accumulate in fp32).  On i.i.d. scores the plain online softmax raises some
-      // query's max in nearly every key block (P(no query of 32 moves) = (1 - 1/(kb + 1))^32), so its 32-register rescale of O ran 15 times
-      // out of 16; now it runs for the first block (from -inf) and for genuine spikes only: 40.0 -> 38.5 us, same result to rounding.
-      if (!__all((mx - mrun[jq]) * scale_log2e <= 8.0f)) {  // wave-uniform
-        const float mnew = fmaxf(mrun[jq], mx);
-        const float alpha = __builtin_amdgcn_exp2f((mrun[jq] - mnew) * scale_log2e);
-        mrun[jq] = mnew;
-        lrun[jq] *= alpha;
-#pragma unroll
-        for (int db = 0; db < NDB; ++db) Oa[jq][db] *= alpha;
-      }
-      const float mnew = mrun[jq];
-      const f32x2 sc2 = {scale_log2e, scale_log2e};
-      const float mbs = mnew * scale_log2e;
-      const f32x2 mb2 = {mbs, mbs};
-      f32x2 sum2 = {0.f, 0.f};
-#pragma unroll
-      for (int e = 0; e < 16; e += 2) {
-        const f32x2 s2 = {S[jq][e], S[jq][e + 1]};
-        const f32x2 a2 = s2 * sc2 - mb2;  // v_pk_fma_f32
-        const f32x2 p2 = {__builtin_amdgcn_exp2f(a2.x), __builtin_amdgcn_exp2f(a2.y)};
-        sum2 += p2;  // v_pk_add_f32
-        P[jq][e >> 3][e & 7] = (half_t)p2.x;
-        P[jq][e >> 3][(e & 7) + 1] = (half_t)p2.y;
-      }
-      lrun[jq] += sum2.x + sum2.y;
-    }
+    for (int jq = 0; jq < JQ; ++jq)  // attention_stream_kernel.h: optimistic exponentials against the running reference, full path for the first block / on overflow risk
+      att_softmax_block<NDB>(S[jq], kb == 0 && first_chunk, mrun[jq], lrun[jq], Oa[jq], scale_log2e, P[jq]);
     if (kb == 0 && first_chunk) {  // V^T was issued after K and Q: only now must it have landed (every wave's share)
       stamp(21);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -435,6 +402,10 @@ static int attention_launch(const half_t* Q, const half_t* K, const half_t* Vt, 
   const bool narrow = T == 256 && !(lfm_gemm_debug_flags() & 256);
   [[maybe_unused]] const int mode = (lfm_gemm_debug_flags() >> 25) & 3;  // flags 33554432 / 67108864 / both: the measurement-only variants MODE 1 / 2 / 3 (hd 64, 256 tokens)
 #ifdef LFM_MEASURE
+  if (mode && hd == 64 && T == 256 && narrow && lfm_attention_stream_enabled() && batch * heads > 64) {  // the streamed kernel's phase split
+    const int rc = attention_stream_launch(Q, K, Vt, O, batch, heads, st, mode);
+    if (rc <= 0) return rc;
+  }
   if (mode && hd == 64 && T == 256 && narrow) {  // the shipped shape (8 waves x 32 queries); flag 256 + mode = the wide one below
     static bool set = false;
     if (!set) {
@@ -472,41 +443,43 @@ static int attention_launch(const half_t* Q, const half_t* K, const half_t* Vt, 
     return LFM_OK;
   }
   // the dynamic-LDS attribute is per (function, device): one bit per device and instantiation
-  int devid = 0;
-  (void)hipGetDevice(&devid);
-  const unsigned long long dbit = 1ull << (devid & 63);
+  const unsigned long long dbit = lfm_device_bit();
 #define ATT_CASE(TT, JQ, HD)                                                                                                             \
   {                                                                                                                                     \
-    static unsigned long long set = 0;                                                                                                  \
-    if (!(set & dbit)) {                                                                                                                \
+    static lfm_device_mask set{0};                                                                                                      \
+    if (lfm_device_todo(set, dbit)) {                                                                                                   \
       (void)hipFuncSetAttribute((const void*)dit_attention_kernel<TT, JQ, HD>, hipFuncAttributeMaxDynamicSharedMemorySize, TT * HD * 4); \
-      set |= dbit;                                                                                                                      \
+      lfm_device_done(set, dbit);                                                                                                       \
     }                                                                                                                                   \
     hipLaunchKernelGGL((dit_attention_kernel<TT, JQ, HD>), grid, dim3((TT / (32 * JQ)) * 64), lds, st, Q, K, Vt, O, D, heads, sl2, lfm_stagger_ticks()); \
   }
   if (T == 1024) {  // four key chunks of 256 through the LDS, one workgroup per 256 queries
     const dim3 grid4(heads, batch, 4);
     if (hd == 64) {
-      static unsigned long long set = 0;
-      if (!(set & dbit)) (void)hipFuncSetAttribute((const void*)dit_attention_kernel<256, 1, 64, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 64 * 4);
-      set |= dbit;
+      static lfm_device_mask set{0};
+      if (lfm_device_todo(set, dbit)) (void)hipFuncSetAttribute((const void*)dit_attention_kernel<256, 1, 64, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 64 * 4);
+      lfm_device_done(set, dbit);
       hipLaunchKernelGGL((dit_attention_kernel<256, 1, 64, 0, 4>), grid4, dim3(512), (size_t)256 * 64 * 4, st, Q, K, Vt, O, D, heads, sl2, lfm_stagger_ticks());
     } else {
-      static unsigned long long set = 0;  // its own flag: the hd-72 kernel needs 72 KiB, above the 64-KiB default, whatever the hd-64 one did before
-      if (!(set & dbit)) (void)hipFuncSetAttribute((const void*)dit_attention_kernel<256, 1, 72, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 72 * 4);
-      set |= dbit;
+      static lfm_device_mask set{0};  // its own flag: the hd-72 kernel needs 72 KiB, above the 64-KiB default, whatever the hd-64 one did before
+      if (lfm_device_todo(set, dbit)) (void)hipFuncSetAttribute((const void*)dit_attention_kernel<256, 1, 72, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 72 * 4);
+      lfm_device_done(set, dbit);
       hipLaunchKernelGGL((dit_attention_kernel<256, 1, 72, 0, 4>), grid4, dim3(512), (size_t)256 * 72 * 4, st, Q, K, Vt, O, D, heads, sl2, lfm_stagger_ticks());
     }
     LFM_CHECK_LAUNCH();
     return LFM_OK;
   }
   if (hd == 64 && T == 256 && narrow && batch * heads <= 64) {  // latency mode: two workgroups of four waves per (image, head)
-    static unsigned long long set = 0;
-    if (!(set & dbit)) (void)hipFuncSetAttribute((const void*)dit_attention_kernel<256, 1, 64, 0, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 64 * 4);
-    set |= dbit;
+    static lfm_device_mask set{0};
+    if (lfm_device_todo(set, dbit)) (void)hipFuncSetAttribute((const void*)dit_attention_kernel<256, 1, 64, 0, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 64 * 4);
+    lfm_device_done(set, dbit);
     hipLaunchKernelGGL((dit_attention_kernel<256, 1, 64, 0, 1, 2>), dim3(heads, batch, 2), dim3(256), lds, st, Q, K, Vt, O, D, heads, sl2, 0);
     LFM_CHECK_LAUNCH();
     return LFM_OK;
+  }
+  if (hd == 64 && T == 256 && narrow && lfm_attention_stream_enabled()) {  // round 6: persistent workgroups, K / V^T streamed through an LDS ring (attention_stream_kernel.h)
+    const int rc = attention_stream_launch(Q, K, Vt, O, batch, heads, st);
+    if (rc <= 0) return rc;  // 1: not for that kernel (tensors of 2 GiB and more) -> the per-item kernel below
   }
   if (hd == 64) {
     if (T == 64) ATT_CASE(64, 2, 64)

@@ -5,6 +5,8 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <atomic>
+
 typedef _Float16 half_t;
 typedef half_t half2_t __attribute__((ext_vector_type(2)));
 typedef half_t half4_t __attribute__((ext_vector_type(4)));
@@ -127,6 +129,19 @@ __device__ __forceinline__ f32x4 row_affine4(float a, float b, f32x4 acc, f32x4 
 }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// One-time set-up per (call site, DEVICE): the dynamic-LDS attribute of a kernel is per (function, device), a symbol address is per device -- and the library may be
+// driven from several host threads (per-call settings are thread-scoped, ABI 4), or for several devices from one process.  A bit per device in an atomic mask:
+// two threads racing through the first call both run the (idempotent) set-up, nobody skips it, nobody reads a half-written flag.  (Rounds 1-5: plain
+// `static bool set` / `static unsigned long long` -- per process, unsynchronised: round-5 review, weak item 1.)
+typedef std::atomic<unsigned long long> lfm_device_mask;
+static inline unsigned long long lfm_device_bit() {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  return 1ull << (d & 63);
+}
+static inline bool lfm_device_todo(const lfm_device_mask& m, unsigned long long bit) { return !(m.load(std::memory_order_acquire) & bit); }
+static inline void lfm_device_done(lfm_device_mask& m, unsigned long long bit) { m.fetch_or(bit, std::memory_order_release); }
 
 // Zero a small device buffer with a KERNEL instead of hipMemsetAsync: inside a captured hipGraph a memset becomes a memset node, and
 // graphs of the host-sequenced UNets (GroupNorm statistics are zeroed before every accumulation) produced NaN on the first replay

@@ -237,13 +237,12 @@ static inline int launch_conv3x3_halo(const half_t* in, const half_t* zeros, con
   const long total = (long)n * tiles_per_img * nb;
   if ((total < 256 && !(lfm_gemm_debug_flags() & 16777216)) || total >= (1L << 31)) return 1;  // flag 16777216: small problems too (parity tests)
   if (((uintptr_t)in | (uintptr_t)Wt | (uintptr_t)zeros) & 15) return LFM_ERR_ALIGN;
-  static unsigned long long attr_set = 0;  // one bit per device: the attribute is per (function, device)
-  int devid = 0;
-  (void)hipGetDevice(&devid);
-  if (!((attr_set >> (devid & 63)) & 1)) {
+  static lfm_device_mask attr_set{0};  // one bit per device: the attribute is per (function, device)
+  const unsigned long long dbit = lfm_device_bit();
+  if (lfm_device_todo(attr_set, dbit)) {
     if (hipFuncSetAttribute((const void*)conv3x3_halo_kernel<Epi, UPS>, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_BYTES) != hipSuccess)
       return LFM_ERR_LAUNCH;
-    attr_set |= 1ull << (devid & 63);
+    lfm_device_done(attr_set, dbit);
   }
   hipLaunchKernelGGL((conv3x3_halo_kernel<Epi, UPS>), dim3((unsigned)total), dim3(256), CH_LDS_BYTES, st, in, zeros, Wt, 9L * Cin, H, W, Cin, tiles_x,
                      tiles_per_img, (int)total, nb, epi, lfm_stagger_ticks());
@@ -355,13 +354,12 @@ static inline int launch_conv3x3_halo_out(const half_t* in, const half_t* zeros,
   const long total = (long)n * tiles_per_img;
   if ((total < 256 && !(lfm_gemm_debug_flags() & 16777216)) || total >= (1L << 31)) return 1;
   if (((uintptr_t)in | (uintptr_t)w4 | (uintptr_t)zeros) & 15) return LFM_ERR_ALIGN;
-  static unsigned long long attr_set = 0;
-  int devid = 0;
-  (void)hipGetDevice(&devid);
-  if (!((attr_set >> (devid & 63)) & 1)) {
+  static lfm_device_mask attr_set{0};
+  const unsigned long long dbit = lfm_device_bit();
+  if (lfm_device_todo(attr_set, dbit)) {
     if (hipFuncSetAttribute((const void*)conv3x3_halo_out_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, CHO_LDS_BYTES) != hipSuccess)
       return LFM_ERR_LAUNCH;
-    attr_set |= 1ull << (devid & 63);
+    lfm_device_done(attr_set, dbit);
   }
   hipLaunchKernelGGL((conv3x3_halo_out_kernel<Epi>), dim3((unsigned)total), dim3(256), CHO_LDS_BYTES, st, in, zeros, w4, H, W, Cin, tiles_x, tiles_per_img,
                      (int)total, epi);

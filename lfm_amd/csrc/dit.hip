@@ -1,5 +1,7 @@
 // DiT velocity field on gfx950: the kernels around the MFMA GEMMs and the per-call driver.
 // Reference behaviour: /root/reference/models/DiT.py (cited per kernel).
+#include <mutex>
+
 #include "../../include/lfm_hip.h"
 #include "gemm_dispatch.h"
 #include "gemm_skinny_kernel.h"
@@ -33,6 +35,8 @@ static int g_opt_skinny = 1;  // LFM_OPT_SKINNY_GEMM: the batch-1 DiT linears on
                                // gemm_sq64_kernel.h, else all rows x 16 columns, gemm_skinny_kernel.h; 2: always the latter; 0: the rounds 2-4 split-K path)
 static int g_stagger = 0;
 int lfm_stagger_ticks() { return g_stagger; }
+static int g_opt_att_stream = 1;  // LFM_OPT_ATTENTION_STREAM: 256 tokens x head_dim 64 with more than 64 (image, head) items on the persistent streamed kernel
+int lfm_attention_stream_enabled() { return g_opt_att_stream; }
 static inline bool gemm_select_valid(int which) {
   const int k = which & 15;
   return which >= 0 && (k == 0 || k == 1 || k == 4 || k == 5 || k == 6 || k == 7 || k == 8);  // 7, 8: the latency-mode kernels through lfm_gemm_f16 (tests)
@@ -82,6 +86,10 @@ extern "C" int lfm_set_option(int key, int value) {  // key 1 (LFM_OPT_FOLD_LN):
   }
   if (key == 4) {  // LFM_OPT_SKINNY_GEMM: 0 = the split-K 128x128 path of rounds 2-4 for M <= 256 (A/B, parity)
     g_opt_skinny = value < 0 || value > 2 ? 1 : value;
+    return LFM_OK;
+  }
+  if (key == 5) {  // LFM_OPT_ATTENTION_STREAM: 0 = one workgroup per (image, head) item (the rounds 1-5 kernel; A/B and the bit-equality test)
+    g_opt_att_stream = value != 0;
     return LFM_OK;
   }
 #ifdef LFM_MEASURE
@@ -949,7 +957,7 @@ extern "C" const char* lfm_strerror(int code) {
   }
   return "unknown";
 }
-extern "C" int lfm_abi_version(void) { return 4; }  // 2: lfm_time_embed takes label_rows; 3: lfm_dit_call carries the per-grid conditioning table; 4: + cond_rows, per-call fold_ln / gemm_select
+extern "C" int lfm_abi_version(void) { return LFM_ABI_VERSION; }  // 2: lfm_time_embed takes label_rows; 3: lfm_dit_call carries the per-grid conditioning table; 4: + cond_rows, per-call fold_ln / gemm_select
 
 extern "C" size_t lfm_dit_workspace_bytes(const lfm_dit_shape* shape, int max_batch) {
   if (check_shape(shape) != LFM_OK || max_batch <= 0) return 0;
@@ -1085,7 +1093,12 @@ static int g_prof_blk_count = 0;
 static int g_prof_mode = 0;  // 1: an event pair around every fc1 launch (+ the block loop); 2: around the block loop only (no events between the kernels)
 static hipStream_t g_prof_stream = nullptr;  // the stream that owns the probe (the first one that launches while it is on)
 static bool g_prof_owned = false, g_prof_conflict = false;
+// The probe is a measurement device for ONE stream driven by ONE host thread (bench.py).  Switching it, claiming it and reading it are serialised by a mutex, so
+// that a second host thread enqueueing evaluations at the same time gets a clean refusal (g_prof_conflict) instead of a data race on the flags; the sample
+// counters are touched only by the thread whose stream owns the probe (prof_claim returned true for it).
+static std::mutex g_prof_mu;
 extern "C" int lfm_profile_fc1(int enable) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   if (enable && !g_prof_init) {
     for (int i = 0; i < 2 * LFM_PROF_MAX; ++i)
       if (hipEventCreate(&g_prof_ev[i]) != hipSuccess) return LFM_ERR_LAUNCH;
@@ -1104,6 +1117,7 @@ extern "C" int lfm_profile_fc1(int enable) {
   return LFM_OK;
 }
 static bool prof_claim(hipStream_t st) {  // may THIS evaluation record its fc1 launches?
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   if (!g_prof_on) return false;
   if (!g_prof_owned) {
     g_prof_owned = true;
@@ -1116,6 +1130,7 @@ static bool prof_claim(hipStream_t st) {  // may THIS evaluation record its fc1 
   return true;
 }
 extern "C" int lfm_profile_fc1_read(float* ms_out, int max_n) {  // synchronises; returns the number of samples written
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   if (!ms_out || !g_prof_init) return LFM_ERR_ARG;
   if (g_prof_conflict) return LFM_ERR_ARG;  // a second stream launched evaluations while the probe was on: the samples would time its kernels too
   const int n = g_prof_count < max_n ? g_prof_count : max_n;
@@ -1127,6 +1142,7 @@ extern "C" int lfm_profile_fc1_read(float* ms_out, int max_n) {  // synchronises
 }
 
 extern "C" int lfm_profile_blocks_read(float* ms_out, int max_n) {  // one sample per recorded evaluation: its whole block loop; synchronises
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   if (!ms_out || !g_prof_init) return LFM_ERR_ARG;
   if (g_prof_conflict) return LFM_ERR_ARG;
   const int n = g_prof_blk_count < max_n ? g_prof_blk_count : max_n;

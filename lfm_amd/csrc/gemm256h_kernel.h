@@ -757,13 +757,12 @@ static inline int launch_gemm256h_tn(const ASrc& asrc, const half_t* W, long ldw
   if ((ldw % 8) != 0 || ((uintptr_t)W & 15)) return LFM_ERR_ALIGN;
   const int tm = cdiv(M, G256_BM), tn = cdiv(N, G256_BN);
   constexpr int LDS = G256Q_LDS_BYTES + (epi_has_rowstat<Epi>::value ? 2048 : 0);  // + rs[256][2] of the folded LayerNorm consumers
-  static unsigned long long attr_set = 0;  // one bit per device: the attribute is per (function, device)
-  int devid = 0;
-  (void)hipGetDevice(&devid);
-  if (!((attr_set >> (devid & 63)) & 1)) {
+  static lfm_device_mask attr_set{0};  // one bit per device: the attribute is per (function, device)
+  const unsigned long long dbit = lfm_device_bit();
+  if (lfm_device_todo(attr_set, dbit)) {
     if (hipFuncSetAttribute((const void*)gemm256h_tn_kernel<ASrc, Epi, TRACE, ABL, OPT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return LFM_ERR_LAUNCH;
-    attr_set |= 1ull << (devid & 63);
+    lfm_device_done(attr_set, dbit);
   }
   hipLaunchKernelGGL((gemm256h_tn_kernel<ASrc, Epi, TRACE, ABL, OPT>), dim3(tm * tn, batch), dim3(512), LDS, stream, asrc, W, ldw, M, N, K, tn, epi, bsA,
                      bsW, bsC, lfm_gemm_debug_flags());

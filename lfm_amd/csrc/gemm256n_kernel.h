@@ -191,11 +191,12 @@ static inline int launch_gemm256n_tn(const ASrc& asrc, const half_t* W, long ldw
   if (M <= 0 || N <= 0 || K <= 0 || (K % G256N_BK) != 0 || (N % 4) != 0) return LFM_ERR_SHAPE;
   if ((ldw % 8) != 0 || ((uintptr_t)W & 15)) return LFM_ERR_ALIGN;
   const int tm = cdiv(M, G256_BM), tn = cdiv(N, G256N_BN);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static lfm_device_mask attr_set{0};
+  const unsigned long long dbit = lfm_device_bit();
+  if (lfm_device_todo(attr_set, dbit)) {
     if (hipFuncSetAttribute((const void*)gemm256n_tn_kernel<ASrc, Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, G256N_LDS_BYTES) != hipSuccess)
       return LFM_ERR_LAUNCH;
-    attr_set = true;
+    lfm_device_done(attr_set, dbit);
   }
   hipLaunchKernelGGL((gemm256n_tn_kernel<ASrc, Epi>), dim3(tm * tn, batch), dim3(256), G256N_LDS_BYTES, stream, asrc, W, ldw, M, N, K, tn, epi, bsA,
                      bsW, bsC, lfm_gemm_debug_flags(), lfm_stagger_ticks());

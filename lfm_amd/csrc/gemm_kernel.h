@@ -724,10 +724,11 @@ static inline int launch_gemm_tn(const ASrc& asrc, const half_t* W, long ldw, in
   if (M <= 0 || N <= 0 || K <= 0 || (K % GEMM_BK) != 0 || (N % 4) != 0) return LFM_ERR_SHAPE;
   if ((ldw % 8) != 0 || ((uintptr_t)W & 15)) return LFM_ERR_ALIGN;
   const int tm = cdiv(M, GEMM_BM), tn = cdiv(N, GEMM_BN);
-  static bool attr_set = false;  // one attribute call per instantiation
-  if (!attr_set) {
+  static lfm_device_mask attr_set{0};  // one attribute call per instantiation and device
+  const unsigned long long dbit = lfm_device_bit();
+  if (lfm_device_todo(attr_set, dbit)) {
     (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<ASrc, Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-    attr_set = true;
+    lfm_device_done(attr_set, dbit);
   }
   hipLaunchKernelGGL((gemm_tn_kernel<ASrc, Epi>), dim3(tm * tn, batch), dim3(256), GEMM_LDS_BYTES, stream, asrc, W, ldw, M, N, K, tn,
                      epi, bsA, bsW, bsC);

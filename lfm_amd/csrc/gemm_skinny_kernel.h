@@ -151,21 +151,19 @@ static inline bool gemm_skinny_ok(const void* A, long lda, const void* W, long l
 template <class Epi>
 static inline int launch_gemm_skinny(const half_t* A, long lda, const half_t* W, long ldw, int M, int N, int K, const Epi& epi, int S, hipStream_t stream) {
   if (!gemm_skinny_ok(A, lda, W, ldw, M, N, K, S)) return LFM_ERR_SHAPE;
-  static unsigned long long attr_set = 0, wpre_bad = 0;  // one bit per device: the attribute is per (function, device)
-  int devid = 0;
-  (void)hipGetDevice(&devid);
-  const unsigned long long bit = 1ull << (devid & 63);
-  if (!(attr_set & bit)) {
+  static lfm_device_mask attr_set{0}, wpre_bad{0};  // one bit per device: the attribute is per (function, device)
+  const unsigned long long bit = lfm_device_bit();
+  if (lfm_device_todo(attr_set, bit)) {
     if (hipFuncSetAttribute((const void*)gemm_skinny_kernel<Epi, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES) != hipSuccess) return LFM_ERR_LAUNCH;
     // the W-prefetch variant takes the CU's whole 160 KiB: where the runtime refuses that much for one workgroup, the tile-by-tile variant serves every shape
     if (hipFuncSetAttribute((const void*)gemm_skinny_kernel<Epi, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES_WPRE) != hipSuccess) {
       (void)hipGetLastError();
-      wpre_bad |= bit;
+      wpre_bad.fetch_or(bit, std::memory_order_release);
     }
-    attr_set |= bit;
+    lfm_device_done(attr_set, bit);
   }
   const int Ks = K / S;
-  if (Ks <= SK_WPRE_MAX_KS && !(wpre_bad & bit))
+  if (Ks <= SK_WPRE_MAX_KS && !(wpre_bad.load(std::memory_order_acquire) & bit))
     hipLaunchKernelGGL((gemm_skinny_kernel<Epi, true>), dim3(N / SK_BN, S), dim3(512), SK_LDS_BYTES_WPRE, stream, A, lda, W, ldw, M, N, Ks, epi);
   else
     hipLaunchKernelGGL((gemm_skinny_kernel<Epi, false>), dim3(N / SK_BN, S), dim3(512), SK_LDS_BYTES, stream, A, lda, W, ldw, M, N, Ks, epi);

@@ -137,13 +137,11 @@ static inline bool gemm_sq64_ok(const void* A, long lda, const void* W, long ldw
 template <class Epi>
 static inline int launch_gemm_sq64(const half_t* A, long lda, const half_t* W, long ldw, int M, int N, int K, const Epi& epi, int S, hipStream_t stream) {
   if (!gemm_sq64_ok(A, lda, W, ldw, M, N, K, S)) return LFM_ERR_SHAPE;
-  static unsigned long long attr_set = 0;  // one bit per device: the attribute is per (function, device)
-  int devid = 0;
-  (void)hipGetDevice(&devid);
-  const unsigned long long bit = 1ull << (devid & 63);
-  if (!(attr_set & bit)) {
+  static lfm_device_mask attr_set{0};  // one bit per device: the attribute is per (function, device)
+  const unsigned long long bit = lfm_device_bit();
+  if (lfm_device_todo(attr_set, bit)) {
     if (hipFuncSetAttribute((const void*)gemm_sq64_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, SQ_LDS_BYTES) != hipSuccess) return LFM_ERR_LAUNCH;
-    attr_set |= bit;
+    lfm_device_done(attr_set, bit);
   }
   const int mt = M / SQ_T, nt = N / SQ_T;
   hipLaunchKernelGGL((gemm_sq64_kernel<Epi>), dim3(nt * mt, S), dim3(512), SQ_LDS_BYTES, stream, A, lda, W, ldw, M, N, K / S, mt, (nt % 8) == 0 ? 1 : 0, epi);

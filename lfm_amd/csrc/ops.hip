@@ -110,14 +110,18 @@ struct EpiNCHWF32 {  // Cout <= 4 output conv: fp32 NCHW, channels beyond nch ar
 
 static __device__ half_t g_zero_page[64];  // zero padding rows for the conv gathers (zero-initialised device global)
 
-static const half_t* zero_page() {
-  static const half_t* p = nullptr;
-  if (!p) {
+static const half_t* zero_page() {  // the symbol's address is per DEVICE (one slot per device, written once; racing threads write the same value)
+  static std::atomic<const half_t*> p[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const half_t* v = p[dev & 63].load(std::memory_order_acquire);
+  if (!v) {
     void* d = nullptr;
     if (hipGetSymbolAddress(&d, HIP_SYMBOL(g_zero_page)) != hipSuccess) return nullptr;
-    p = (const half_t*)d;
+    v = (const half_t*)d;
+    p[dev & 63].store(v, std::memory_order_release);
   }
-  return p;
+  return v;
 }
 
 // Low-resolution levels of a UNet are small-M, huge-K problems (celeb512 at batch 32: 4x4 maps = 512 rows x 1024 columns x K 9216..18432):
@@ -353,10 +357,11 @@ extern "C" int lfm_conv3x3_in_f32(const float* x_nchw, const float* w, const flo
   }
   const size_t lds = (size_t)Cin * 9 * Cout * 4;
   if (lds > 160 * 1024) return LFM_ERR_SHAPE;
-  static bool set = false;
-  if (!set) {
+  static lfm_device_mask set{0};
+  const unsigned long long dbit = lfm_device_bit();
+  if (lfm_device_todo(set, dbit)) {
     if (hipFuncSetAttribute((const void*)conv_in_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return LFM_ERR_LAUNCH;
-    set = true;
+    lfm_device_done(set, dbit);
   }
   hipLaunchKernelGGL(conv_in_kernel, dim3(cdiv((long)N * H * W, CI_PIX)), dim3(256), lds, (hipStream_t)stream, x_nchw, w, bias,
                      (half_t*)out_nhwc, N, H, W, Cin, Cout);
@@ -1010,11 +1015,12 @@ extern "C" int lfm_attention_small_f16(const void* qkv, void* out, int N, int T,
   const int QB = T < 64 ? T : 64;  // queries per workgroup
   const size_t lds = (size_t)QB * (T + 1) * 4 + (size_t)2 * T * (ch + 2) * 2;
   if (lds > 160 * 1024) return LFM_ERR_SHAPE;  // every reference config has T <= 64 (8x8 / 4x4 feature maps)
-  static bool set = false;
-  if (!set) {
+  static lfm_device_mask set{0};
+  const unsigned long long dbit = lfm_device_bit();
+  if (lfm_device_todo(set, dbit)) {
     if (hipFuncSetAttribute((const void*)attention_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return LFM_ERR_LAUNCH;
-    set = true;
+    lfm_device_done(set, dbit);
   }
   hipLaunchKernelGGL(attention_small_kernel, dim3(heads, N, cdiv(T, QB)), dim3(256), lds, (hipStream_t)stream, (const half_t*)qkv, (half_t*)out,
                      T, heads, ch, QB);

@@ -590,11 +590,12 @@ extern "C" int lfm_vae_decode(const lfm_vae_weights* w, void* workspace, size_t 
     const int n = (N - n0 < chunk) ? N - n0 : chunk;
     half_t *x = ws.b0, *t1 = ws.b1, *t2 = ws.b2, *t3 = ws.b3;
     {
-      static bool set = false;
-      if (!set) {
+      static lfm_device_mask set{0};
+      const unsigned long long dbit = lfm_device_bit();
+      if (lfm_device_todo(set, dbit)) {
         if (hipFuncSetAttribute((const void*)vae_conv_in_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 36 * 512 * 4) != hipSuccess)
           return LFM_ERR_LAUNCH;
-        set = true;
+        lfm_device_done(set, dbit);
       }
     }
     hipLaunchKernelGGL(vae_conv_in_kernel, dim3(cdiv((long)n * T, VCI_PIX)), dim3(256), 36 * 512 * 4, st, z + (long)n0 * 4 * T, w->pq_w, w->pq_b,

@@ -299,15 +299,17 @@ def main(argv=None):
                 f.write("Epoch = {}, FID = {}\n".format(args.epoch_id, fid))
             return
         # batches in flight: consecutive batches alternate between HIP streams (solvers.concurrency_twin: the same weights, own scratch and captured graphs),
-        # and batch i - 1 is converted / written by the host while batch i runs -- the reference's loop (:264-269) serialises solve, decode and JPEG writes
+        # and the host converts / writes batch i - lanes while batches i - lanes + 1 .. i run (every lane stays busy under the JPEG encoding) -- the reference's
+        # loop (:264-269) serialises solve, decode and JPEG writes
+        from collections import deque
+
         lanes = make_lanes(model, vae, device, int(getattr(args, "in_flight", 0) or 0) or 2)
-        pending = None
+        pending = deque()
 
         def drain(p):
-            if p is not None:
-                p[0].synchronize()
-                # the single-process script writes through torchvision.utils.save_image: ROUNDING uint8 conversion (:264-269)
-                save_images_uint8(p[1], save_dir, p[2] * n)
+            p[0].synchronize()
+            # the single-process script writes through torchvision.utils.save_image: ROUNDING uint8 conversion (:264-269)
+            save_images_uint8(p[1], save_dir, p[2] * n)
 
         for i in range(total_samples // n):
             mdl, va, st = lanes[i % len(lanes)]
@@ -315,9 +317,11 @@ def main(argv=None):
                 u8 = images_to_uint8(run_sampling(mdl, va, args, n, generator, device), rounding=True)
                 done = torch.cuda.Event()
                 done.record(st)
-            drain(pending)
-            pending = (done, u8, i)
-        drain(pending)
+            pending.append((done, u8, i))
+            if len(pending) > len(lanes):
+                drain(pending.popleft())
+        while pending:
+            drain(pending.popleft())
         print(f"wrote {total_samples} images to {save_dir} in {time.time() - t0:.1f}s; FID needs pytorch_fid + Inception weights "
               "(not available offline): run the reference's pytorch_fid on that directory (lfm_amd.io_formats has the statistics "
               "reader and the Frechet distance)")

@@ -52,22 +52,28 @@ def gather_images(img_u8, world_size, out=None):
 
 class GatherPipeline:
     """One ``all_gather_into_tensor`` of the uint8 image block per batch, issued on a SIDE stream so that the next batch's solve
-    overlaps the collective and the device-to-host copy of the previous one: two gather buffers alternate; ``submit``
-    returns the PREVIOUS batch's gathered, reference-ordered block (or None), ``flush`` the last one.  On a CPU / gloo group (the
-    world-2 rehearsal in tests/) it degrades to the plain blocking collective."""
+    overlaps the collective and the device-to-host copy of the previous one.  ``depth`` batches stay pending
+    (``depth + 1`` gather buffers alternate): ``submit`` returns the gathered, reference-ordered block of the batch submitted
+    ``depth`` calls earlier (or None), ``flush`` the oldest pending one (None when nothing is pending).  depth = 1 is "the previous
+    batch"; the drivers use depth = lanes, so that the block the host goes on to convert and write belongs to a batch that is
+    no longer one of the ``lanes`` batches in flight.  On a CPU / gloo group (the world-2 rehearsal in tests/) it degrades to the
+    plain blocking collective."""
 
-    def __init__(self, world, device):
+    def __init__(self, world, device, depth=1):
+        from collections import deque
+
         self.world, self.device = world, torch.device(device)
         self.cuda = self.device.type == "cuda"
         self.side = torch.cuda.Stream(self.device) if self.cuda and world > 1 else None
-        self.bufs, self.k, self.pending = [None, None], 0, None
+        self.depth = max(1, int(depth))
+        self.bufs, self.k, self.pending = [None] * (self.depth + 1), 0, deque()
         self.gather_seconds = 0.0
 
     def _gather(self, u8):
         import time
 
         k = self.k
-        self.k ^= 1
+        self.k = (self.k + 1) % len(self.bufs)
         if self.world == 1:
             if self.cuda and u8.is_cuda:  # no collective, but the consumer may run on another stream than the producer (batches in flight on lanes)
                 done = torch.cuda.Event()
@@ -90,17 +96,19 @@ class GatherPipeline:
             done.record(self.side)
         return out, done
 
-    def submit(self, u8):
-        prev = self.flush()
-        self.pending = self._gather(u8)
-        return prev
-
-    def flush(self):
-        p, self.pending = self.pending, None
+    @staticmethod
+    def _wait(p):
         if isinstance(p, tuple):
             p[1].synchronize()
             return p[0]
         return p
+
+    def submit(self, u8):
+        self.pending.append(self._gather(u8))
+        return self._wait(self.pending.popleft()) if len(self.pending) > self.depth else None
+
+    def flush(self):
+        return self._wait(self.pending.popleft()) if self.pending else None
 
 
 def run(args, model, vae, generator, rank, world, device, to_uint8, save=None, log=print, extractor=None):
@@ -110,7 +118,6 @@ def run(args, model, vae, generator, rank, world, device, to_uint8, save=None, l
     total, _, iters = shard_plan(args.n_sample, args.batch_size, world)
     if rank == 0:
         log(f"Total number of images that will be sampled: {total}")
-    pipe = GatherPipeline(world, device)
     written = []
 
     def sink(block, i):
@@ -144,16 +151,30 @@ def run(args, model, vae, generator, rank, world, device, to_uint8, save=None, l
         from .test_flow_latent import make_lanes
 
         lanes = make_lanes(model, vae, device, n_lanes)
+    # The host's share (device-to-host copy, JPEG encoding on rank 0) is taken OUTSIDE the lane's stream context, on a copy stream of its own, and for the batch
+    # submitted `lanes` iterations ago: inside the context the copy queued on the lane stream behind the batch just enqueued, the host could not launch the next
+    # batch before that one had finished, and with world > 1 every rank waited for rank 0 at the next all-gather (round-5 advisor finding).
+    depth = len(lanes) if lanes[0][2] is not None else 1
+    pipe = GatherPipeline(world, device, depth=depth)
+    copy_stream = torch.cuda.Stream(device) if lanes[0][2] is not None else None
+
+    def drain(block, i):
+        if copy_stream is None:
+            sink(block, i)
+        else:
+            with torch.cuda.stream(copy_stream):
+                sink(block, i)
+
     for i in range(iters):
         mdl, va, st = lanes[i % len(lanes)]
         if st is None:
-            img = run_sampling(mdl, va, args, args.batch_size, generator, device)
-            sink(pipe.submit(to_uint8(img)), i - 1)
+            prev = pipe.submit(to_uint8(run_sampling(mdl, va, args, args.batch_size, generator, device)))
         else:
             with torch.cuda.stream(st):
-                img = run_sampling(mdl, va, args, args.batch_size, generator, device)
-                sink(pipe.submit(to_uint8(img)), i - 1)  # the gather's side stream waits for THIS lane's stream
-    sink(pipe.flush(), iters - 1)
+                prev = pipe.submit(to_uint8(run_sampling(mdl, va, args, args.batch_size, generator, device)))  # the gather's side stream waits for THIS lane's stream
+        drain(prev, i - depth)
+    for i in range(max(0, iters - depth), iters):
+        drain(pipe.flush(), i)
     if lanes[0][2] is not None:
         for _, _, st in lanes:
             torch.cuda.current_stream(device).wait_stream(st)

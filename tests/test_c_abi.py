@@ -35,6 +35,7 @@ int main(void) {
   OFF(lfm_dit_call, cfg_scale); OFF(lfm_dit_call, out); OFF(lfm_dit_call, axpy_base); OFF(lfm_dit_call, axpy_dt); OFF(lfm_dit_call, cond_table);
   OFF(lfm_dit_call, cond_step); OFF(lfm_dit_call, cond_offset); OFF(lfm_dit_call, cond_rows); OFF(lfm_dit_call, fold_ln); OFF(lfm_dit_call, gemm_select);
   /* a zero-initialised call means "library defaults" */
+  if (lfm_abi_version() != LFM_ABI_VERSION) { printf("abi mismatch: library %d, header %d\n", lfm_abi_version(), LFM_ABI_VERSION); return 3; }  /* what a C caller does first */
   lfm_dit_call c; memset(&c, 0, sizeof c);
   int sel = -1, fold = -1;
   int rc = lfm_dit_call_settings(&c, &sel, &fold);

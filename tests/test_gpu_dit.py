@@ -288,6 +288,45 @@ def test_attention_query_split_matches(dev, small):
     assert float(part.float().abs().mean()) > 1e-3
 
 
+@pytest.mark.parametrize("batch,heads", [(5, 16), (8, 16), (33, 16), (64, 16), (100, 16), (43, 12), (171, 6)])
+def test_attention_stream_matches_per_item(dev, batch, heads):
+    """256 tokens x hd 64 with more than 64 (image, head) items run on PERSISTENT workgroups that stream K / V^T of consecutive items through a four-slot LDS ring
+    (csrc/attention_stream_kernel.h: counted waits across item boundaries, out-of-range stages at the tail).  Same arithmetic per query in the same key order as the
+    one-workgroup-per-item kernel: bit-identical for every item count -- one item per workgroup (80, 128 items), a ragged second round (528, 516), two to four items
+    per workgroup (1024, 1600, 1026) -- with spiky keys that force the online-softmax rescale in every stage, twice in a row (bit-repeatable), and inside the
+    tolerance of the fp32 reference item by item."""
+    from lfm_amd import hip
+
+    T, hd = 256, 64
+    D = heads * hd
+    g = torch.Generator().manual_seed(batch * 100 + heads)
+    Q = (torch.randn(batch * T, D, generator=g) * 1.5).half().to(dev)
+    K = (torch.randn(batch * T, D, generator=g) * 1.5).half().to(dev)
+    Vt = torch.randn(batch, heads, hd, T, generator=g).half().to(dev)
+    for img, tok in ((0, 5), (batch // 2, 70), (batch - 1, 130), (batch - 1, 250), (1, 200)):  # one spike per 64-key stage somewhere, first / middle / last items
+        K[img * T + tok, : 2 * hd] *= 6
+    try:
+        hip.set_option(hip.OPT_ATTENTION_STREAM, 0)
+        ref = hip.dit_attention(Q, K, Vt, batch, heads, T, head_dim=hd)
+        hip.set_option(hip.OPT_ATTENTION_STREAM, 1)
+        out = hip.dit_attention(Q, K, Vt, batch, heads, T, head_dim=hd)
+        out2 = hip.dit_attention(Q, K, Vt, batch, heads, T, head_dim=hd)
+        torch.cuda.synchronize()
+    finally:
+        hip.set_option(hip.OPT_ATTENTION_STREAM, 1)
+    assert torch.equal(out, out2)
+    bad = (out != ref).reshape(batch, T, heads, hd).any(dim=3).any(dim=1)  # [batch, heads]: which items differ
+    assert not bool(bad.any()), f"{int(bad.sum())} of {batch * heads} items differ, first {bad.nonzero()[:4].tolist()}"
+    # and against fp32 (V^T rows are stored in the library's token order: vt_token_perm is an involution)
+    q = Q.float().reshape(batch, T, heads, hd).permute(0, 2, 1, 3)
+    k = K.float().reshape(batch, T, heads, hd).permute(0, 2, 1, 3)
+    v = Vt.float()[..., hip.vt_token_perm(T, device=dev)].transpose(2, 3)  # [batch, heads, T, hd]
+    want = torch.softmax(q @ k.transpose(2, 3) * hd ** -0.5, dim=-1) @ v
+    got = out.float().reshape(batch, T, heads, hd).permute(0, 2, 1, 3)
+    per_item = (got - want).pow(2).sum((2, 3)).sqrt() / want.pow(2).sum((2, 3)).sqrt()
+    assert float(per_item.max()) < 4e-3
+
+
 def test_attention_refuses_unbuilt_head_sizes(dev):
     from lfm_amd import hip
 

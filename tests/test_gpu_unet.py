@@ -164,6 +164,52 @@ def test_conv3x3_split_k_small_maps(N, H, Cin, Cout, mode):
     assert rel_l2(split, plain) < 1e-3
 
 
+@pytest.mark.parametrize("N,H,Cin,Cout,mode", [(64, 8, 768, 768, 0), (32, 16, 1024, 512, 2), (64, 8, 1536, 768, 1), (32, 8, 1024, 512, 0)])
+def test_conv3x3_split_k_on_the_256_kernel(N, H, Cin, Cout, mode):
+    """The UNets' deep small-map convolutions AT BENCH BATCH SIZES (M = N H W >= 2048, >= 24 K-tiles per slice) take their split-K slices on the 256x256 kernel
+    (csrc/gemm_kernel.h: splitk256_slices -- the stateful ASrcConv tap walk started in the middle of the K range, stride-2 / nearest-upsample source addressing,
+    the fp32 slab epilogue of that kernel); round-5 advisor finding: no parity case reached it (every shape of test_conv3x3_split_k_small_maps has M <= 512).
+    Checked against torch's conv2d, against the 128x128 slices (flag 65536) and for bit-repeatability."""
+    import torch.nn.functional as F
+
+    from lfm_amd import hip
+
+    dev = torch.device("cuda:0")
+    L = hip.lib()
+    g = torch.Generator().manual_seed(N + H + Cin + mode)
+    Hi = H * 2 if mode == 2 else (H // 2 if mode == 1 else H)
+    x = torch.randn(N, Cin, Hi, Hi, generator=g).half()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).half()
+    b = torch.randn(Cout, generator=g) * 0.1
+    res = torch.randn(N, Cout, H, H, generator=g).half()
+    xf = x.float()
+    if mode == 1:
+        xf = F.interpolate(xf, scale_factor=2, mode="nearest")
+    ref = F.conv2d(xf, w.float(), b, padding=1, stride=2 if mode == 2 else 1) + res.float()
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()
+    xin, wp, bd, rd = nhwc(x).to(dev), w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(dev), b.to(dev), nhwc(res).to(dev)
+    need = L.lfm_conv3x3_workspace_bytes(N, H, H, Cin, Cout)
+    assert need > 0, "these shapes are the split-K regime"
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+
+    def run(flags):
+        out = torch.empty(N * H * H, Cout, dtype=torch.float16, device=dev)
+        hip.gemm_select(flags << 4)
+        try:
+            hip.check(L.lfm_conv3x3_f16_ws(hip.ptr(xin), hip.ptr(wp), hip.ptr(bd), hip.ptr(rd), hip.ptr(out), N, H, H, Cin, Cout, mode, hip.ptr(ws), need,
+                                           hip.stream_ptr()), "conv")
+            torch.cuda.synchronize()
+        finally:
+            hip.gemm_select(0)
+        return out
+
+    big, small = run(0), run(65536)
+    assert torch.equal(big, run(0))
+    assert rel_l2(big.reshape(N, H, H, Cout).permute(0, 3, 1, 2), ref) < 2e-3
+    assert rel_l2(small.reshape(N, H, H, Cout).permute(0, 3, 1, 2), ref) < 2e-3
+    assert rel_l2(big, small) < 1e-3
+
+
 def test_unet_fullsize_vs_oracle_and_fused_sampling():
     """celeb256-ADM-like configuration (nf 256, ch_mult 1 2 2 2, attn at ds 16/8, 4 heads) at reduced depth of batch:
     one velocity evaluation vs the CPU oracle, then a 4-step Euler solve: graph-captured vs eager loop vs oracle."""

@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
-out=tools/variants/$name
+out=${VARDIR:-tools/variants}/$name
 mkdir -p $out
 python -c "from lfm_amd import _build; _build.build()" >/dev/null
 SLPFLAG=-fno-slp-vectorize; [ "$NOSLP" = "0" ] && SLPFLAG=""   # NOSLP=0: with the SLP vectorizer (A/B of the build flag)

@@ -11,5 +11,7 @@ for p in m.parameters():
 m = m.to(dev).eval()
 x = torch.randn(64, 4, 32, 32, device=dev); t = torch.tensor(0.5, device=dev)
 if len(sys.argv) > 2: hip.set_option(hip.OPT_FOLD_LN, int(sys.argv[2]))
+import os
+if os.environ.get("LFM_ATT_STREAM") is not None: hip.set_option(hip.OPT_ATTENTION_STREAM, int(os.environ["LFM_ATT_STREAM"]))
 for _ in range(reps): m(t, x)
 torch.cuda.synchronize(); print("done")
