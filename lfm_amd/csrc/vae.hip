@@ -261,7 +261,7 @@ struct EpiMomentsNCHW {  // encoder conv_out (+ folded quant_conv): fp32 NCHW [i
 #define VCI_PIX 256
 __global__ __launch_bounds__(256) void vae_conv_in_kernel(const float* __restrict__ z, const float* __restrict__ pq_w,
                                                           const float* __restrict__ pq_b, const float* __restrict__ w,
-                                                          const float* __restrict__ b, half_t* __restrict__ out, int N, int R, int Cout) {
+                                                          const float* __restrict__ b, half_t* __restrict__ out, int N, int R, int Cout, int ppb) {
   extern __shared__ __attribute__((aligned(16))) float wl[];  // conv_in weights transposed to [k = (c,ky,kx)][Cout]
   for (int e = threadIdx.x; e < 36 * Cout; e += 256) {
     const int co = e / 36, k = e - co * 36;
@@ -272,8 +272,8 @@ __global__ __launch_bounds__(256) void vae_conv_in_kernel(const float* __restric
   const int oct = threadIdx.x % c8n, prow = threadIdx.x / c8n;
   if (prow >= rows) return;
   const int co = oct * 8;
-  const long total = (long)N * R * R, p0 = (long)blockIdx.x * VCI_PIX;
-  for (long pix = p0 + prow; pix < p0 + VCI_PIX && pix < total; pix += rows) {
+  const long total = (long)N * R * R, p0 = (long)blockIdx.x * ppb;  // ppb = VCI_PIX pixels per block, fewer when the batch alone cannot fill the chip
+  for (long pix = p0 + prow; pix < p0 + ppb && pix < total; pix += rows) {
     const int x = (int)(pix % R), y = (int)((pix / R) % R), n = (int)(pix / ((long)R * R));
     f32x4 a0 = *(const f32x4*)(b + co), a1 = *(const f32x4*)(b + co + 4);
 #pragma unroll
@@ -431,6 +431,7 @@ struct VaeWs {
   float* part;                // [chunk, VGN_MAX_SLABS, 128, 2] partial sums of the two-stage GroupNorm statistics
   half_t* zeros;              // 256 B
   float* S;                   // [chunk, T, T] scores
+  size_t part_pairs;          // capacity of `part` in (sum, sum of squares) pairs
   size_t total;
 };
 
@@ -455,7 +456,8 @@ static VaeWs vae_carve(int R, int chunk, void* ws) {
   // the larger of: the statistics kernel's slabs (VGN_MAX_SLABS x C / 4 <= 128 half-octets) and the convolution epilogues' 128-row slabs
   // (2 HW / 256 per image x C / 4 half-octets: at most (8R)^2 * 256 / 512 for the 256-channel tensor at full resolution)
   const size_t part_conv = (size_t)(8 * R) * (8 * R) * 256 / 512, part_stats = (size_t)VGN_MAX_SLABS * 128;
-  w.part = (float*)take((size_t)chunk * (part_conv > part_stats ? part_conv : part_stats) * 2 * 4);
+  w.part_pairs = (size_t)chunk * (part_conv > part_stats ? part_conv : part_stats);
+  w.part = (float*)take(w.part_pairs * 2 * 4);
   w.zeros = (half_t*)take(256);
   w.S = (float*)take((size_t)chunk * T * T * 4);
   w.total = off;
@@ -475,12 +477,24 @@ extern "C" size_t lfm_vae_workspace_bytes(int R, int chunk) {
 
 // ready_slabs > 0: the convolution that produced x already left its partial sums in `part` (EpiConvStatsF16), in that many slabs per image
 static int gn(const half_t* x, half_t* y, float* stats, float* part, const float* g, const float* b, int n, int HW, int C, bool silu,
-              hipStream_t st, int ready_slabs = 0) {
+              hipStream_t st, int ready_slabs = 0, size_t part_pairs = 0) {
   if (C % 128 || 256 % (C / 8) || C > 512) return LFM_ERR_SHAPE;  // groups of >= 4 channels, octet-per-thread mapping
   int slabs = ready_slabs;
   if (!ready_slabs) {
+    // slabs per image: VGN_MAX_SLABS when the images fill the chip; a FEW images (--measure_time decodes ONE) get up to 512 -- 64 blocks walked a 256x256x128 map in
+    // 64 dependent 16-byte loads per thread, 68 us per GroupNorm and 38 % of the batch-1 decode (profiles/r06_latency_mode.txt) -- as far as `part` has room
+    // (part_pairs = its capacity in pairs, 0 = unknown: the old cap)
+    int cap = VGN_MAX_SLABS;
+    if (part_pairs && n * VGN_MAX_SLABS < 1024) {
+      const long room = (long)(part_pairs / ((size_t)n * (C / 4)));
+      const long want = 1024 / n;
+      cap = (int)(want < room ? want : room);
+      if (cap > 512) cap = 512;
+      if (cap < VGN_MAX_SLABS) cap = VGN_MAX_SLABS;
+    }
     int ppb = 1024;
-    if (cdiv(HW, ppb) > VGN_MAX_SLABS) ppb = cdiv(HW, VGN_MAX_SLABS);
+    if (cap > VGN_MAX_SLABS) ppb = cdiv(HW, cap) > 64 ? cdiv(HW, cap) : 64;  // >= 64 pixels per block: at least a few loads per thread
+    if (cdiv(HW, ppb) > cap) ppb = cdiv(HW, cap);
     slabs = cdiv(HW, ppb);
     hipLaunchKernelGGL(gn_stats_kernel, dim3(slabs, n), dim3(256), 0, st, x, part, HW, C, ppb);
     LFM_CHECK_LAUNCH();
@@ -533,9 +547,9 @@ static int resnet(const lfm_vae_resnet* r, half_t*& x, half_t*& t1, half_t*& t2,
                   int* x_slabs = nullptr) {
   const int HW = H * W, M = n * HW;
   int mid_slabs = 0, out_slabs = 0;
-  RC(gn(x, t1, ws.stats, ws.part, r->n1_g, r->n1_b, n, HW, r->cin, true, st, x_slabs ? *x_slabs : 0));
+  RC(gn(x, t1, ws.stats, ws.part, r->n1_g, r->n1_b, n, HW, r->cin, true, st, x_slabs ? *x_slabs : 0, ws.part_pairs));
   RC(conv3(t1, (const half_t*)r->c1_w, r->c1_b, nullptr, t2, ws.zeros, n, H, W, r->cin, r->cout, false, st, ws.part, &mid_slabs));
-  RC(gn(t2, t1, ws.stats, ws.part, r->n2_g, r->n2_b, n, HW, r->cout, true, st, mid_slabs));
+  RC(gn(t2, t1, ws.stats, ws.part, r->n2_g, r->n2_b, n, HW, r->cout, true, st, mid_slabs, ws.part_pairs));
   const half_t* skip = x;
   if (r->sc_w) {  // 1x1 conv shortcut
     RC(launch_gemm_auto(ASrcRowMajor{x, r->cin, M, 0}, (const half_t*)r->sc_w, r->cin, M, r->cout, r->cin, EpiConvF16{t3, r->cout, r->sc_b, nullptr}, st));
@@ -556,7 +570,7 @@ static int mid_attention(const float* at_g, const float* at_b, const void* q_w, 
                          const float* v_b, const void* o_w, const float* o_b, half_t*& x, half_t*& t1, half_t*& t2, half_t*& t3, const VaeWs& ws,
                          int n, int T, hipStream_t st, int x_slabs = 0) {
   const int M = n * T, C = 512;
-  RC(gn(x, t1, ws.stats, ws.part, at_g, at_b, n, T, C, false, st, x_slabs));
+  RC(gn(x, t1, ws.stats, ws.part, at_g, at_b, n, T, C, false, st, x_slabs, ws.part_pairs));
   half_t* Qb = t2;                 // [M, C]
   half_t* Kb = t2 + (size_t)M * C;  // [M, C]
   half_t* Vt = t3;                 // [n, C, T]
@@ -598,8 +612,11 @@ extern "C" int lfm_vae_decode(const lfm_vae_weights* w, void* workspace, size_t 
         lfm_device_done(set, dbit);
       }
     }
-    hipLaunchKernelGGL(vae_conv_in_kernel, dim3(cdiv((long)n * T, VCI_PIX)), dim3(256), 36 * 512 * 4, st, z + (long)n0 * 4 * T, w->pq_w, w->pq_b,
-                       w->cin_w, w->cin_b, x, n, R, 512);
+    // batch 1 (--measure_time: run_sampling(1, ..), reference test_flow_latent.py:223-246): 1024 pixels are FOUR blocks of 256 pixels -- 183 us for 38 MFLOP
+    // (profiles/r06_latency_mode.txt); 16 pixels per block put them on 64 CUs
+    const int vci_ppb = (long)n * T >= 256L * VCI_PIX ? VCI_PIX : ((long)n * T >= 64L * VCI_PIX ? 64 : 16);
+    hipLaunchKernelGGL(vae_conv_in_kernel, dim3(cdiv((long)n * T, vci_ppb)), dim3(256), 36 * 512 * 4, st, z + (long)n0 * 4 * T, w->pq_w, w->pq_b,
+                       w->cin_w, w->cin_b, x, n, R, 512, vci_ppb);
     LFM_CHECK_LAUNCH();
     int H = R;
     int xs = 0;  // partial-sum slabs per image that the producer of x left in ws.part (0 = none: the GroupNorm runs its own statistics pass)
@@ -618,7 +635,7 @@ extern "C" int lfm_vae_decode(const lfm_vae_weights* w, void* workspace, size_t 
         x = o;
       }
     }
-    RC(gn(x, t1, ws.stats, ws.part, w->no_g, w->no_b, n, H * H, 128, true, st, xs));
+    RC(gn(x, t1, ws.stats, ws.part, w->no_g, w->no_b, n, H * H, 128, true, st, xs, ws.part_pairs));
     const int M = n * H * H;
     {
       const EpiConvOutNCHW eo{out + (long)n0 * 3 * H * H, w->cout_b, H * H};
@@ -676,7 +693,7 @@ extern "C" int lfm_vae_encode(const lfm_vae_enc_weights* w, void* workspace, siz
     RC(resnet(&w->mid[0], h, t1, t2, t3, ws, n, H, H, st));
     RC(mid_attention(w->at_g, w->at_b, w->q_w, w->q_b, w->k_w, w->k_b, w->v_w, w->v_b, w->o_w, w->o_b, h, t1, t2, t3, ws, n, H * H, st));
     RC(resnet(&w->mid[1], h, t1, t2, t3, ws, n, H, H, st));
-    RC(gn(h, t1, ws.stats, ws.part, w->no_g, w->no_b, n, H * H, 512, true, st));
+    RC(gn(h, t1, ws.stats, ws.part, w->no_g, w->no_b, n, H * H, 512, true, st, 0, ws.part_pairs));
     const int M = n * H * H;
     RC(launch_gemm_tn(ASrcConv3x3<0>{t1, ws.zeros, H, H, 512, M, 0, 0}, (const half_t*)w->cout_w, 9L * 512, M, 8, 9 * 512,
                       EpiMomentsNCHW{moments + (long)n0 * 8 * H * H, w->cout_b, H * H, 8}, st));
