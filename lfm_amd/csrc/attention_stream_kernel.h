@@ -256,6 +256,33 @@ __global__ __launch_bounds__(512, 4) void dit_attention_stream_kernel(const half
     for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[ks]));  // the compiler's own wait for the Q loads goes HERE, before the next LDS-DMAs are issued
     dma_k(kb_cur, true, 3);
     dma_v(vb_cur, true, 2);
+    // ---- stage j + 1 landed; every wave is past its reads of K stage j and V^T stage j - 1: counted wait, barrier, the next two LDS-DMAs
+    auto next_stage = [&](int j) {
+      if (tr_item < 2) stamp(2 + 14 * tr_item + 3 * (j + 1));
+      if (j == 0) {
+        if (first) ATS_VMCNT(3);
+        else ATS_VMCNT(10);
+      } else {
+        ATS_VMCNT(2);
+      }
+      if (tr_item < 2) stamp(3 + 14 * tr_item + 3 * (j + 1));
+      ATS_BARRIER();
+      if (tr_item < 2) stamp(4 + 14 * tr_item + 3 * (j + 1));
+      if (j == 0) {
+        dma_k(kb_next, has_next, 0);
+        dma_v(vb_cur, true, 3);
+      } else if (j == 1) {
+        dma_k(kb_next, has_next, 1);
+        dma_v(vb_next, has_next, 0);
+      } else {
+        dma_k(kb_next, has_next, 2);
+        dma_v(vb_next, has_next, 1);
+      }
+    };
+    // The eight key blocks of the item, MFMA-first: the S MFMAs of block b + 1 are issued before the softmax arithmetic of block b, so the matrix pipe works under the
+    // VALU-heavy part.  (Measured and not kept, round 6: waves 4-7 in VALU-first order so that a SIMD's two waves of this workgroup want the pipe and the issue port
+    // at different times -- 33.4 vs 31.8 us, 6144 items 180.7 vs 170.0: the VALU-first half loses its software pipeline, and the second code path costs 8 spilled
+    // dwords under the 128-register budget.)
     f32x16 Sa, Sb;
     qk(Sa, 0, 0);
 #pragma unroll
@@ -264,27 +291,7 @@ __global__ __launch_bounds__(512, 4) void dit_attention_stream_kernel(const half
       if (j == 3 && has_next) load_q(kb_next);  // the old fragments are dead: the next item's arrive under the last two softmax blocks and the output pass
       softmax_pv(Sa, j, 0, j == 0);
       if (j < 3) {
-        // ---- stage j + 1 landed; every wave is past its reads of K stage j and V^T stage j - 1
-        if (tr_item < 2) stamp(2 + 14 * tr_item + 3 * (j + 1));
-        if (j == 0) {
-          if (first) ATS_VMCNT(3);
-          else ATS_VMCNT(10);
-        } else {
-          ATS_VMCNT(2);
-        }
-        if (tr_item < 2) stamp(3 + 14 * tr_item + 3 * (j + 1));
-        ATS_BARRIER();
-        if (tr_item < 2) stamp(4 + 14 * tr_item + 3 * (j + 1));
-        if (j == 0) {
-          dma_k(kb_next, has_next, 0);
-          dma_v(vb_cur, true, 3);
-        } else if (j == 1) {
-          dma_k(kb_next, has_next, 1);
-          dma_v(vb_next, has_next, 0);
-        } else {
-          dma_k(kb_next, has_next, 2);
-          dma_v(vb_next, has_next, 1);
-        }
+        next_stage(j);
         qk(Sa, j + 1, 0);
       }
       softmax_pv(Sb, j, 1, false);
