@@ -257,12 +257,46 @@ class DhariwalUNet(nn.Module):
         hip.check(hip.lib().lfm_avgpool2_f16(hip.ptr(x), hip.ptr(y), N, Ho, Wo, C, hip.stream_ptr(x.device)), "lfm_avgpool2_f16")
         return y
 
+    def _gn2(self, xa, xb, N, HW, gb, silu, eps=1e-5):
+        """GroupNorm of the channel concat [xa | xb] read in place (``torch.cat([x, skips.pop()], dim=1)``, EDM.py:840-842, is never materialised)."""
+        Ca, Cb = xa.shape[1], xb.shape[1]
+        y = torch.empty(xa.shape[0], Ca + Cb, dtype=torch.float16, device=xa.device)
+        need = hip.lib().lfm_groupnorm_scratch_bytes(N, Ca + Cb)
+        if self._scratch is None or self._scratch.numel() < need or self._scratch.device != xa.device:
+            self._scratch = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=xa.device)
+            self._gen += 1
+        hip.check(hip.lib().lfm_groupnorm2_f16(hip.ptr(xa), Ca, hip.ptr(xb), Cb, hip.ptr(y), hip.ptr(gb[0]), hip.ptr(gb[1]), None, 0, hip.ptr(self._scratch),
+                                               N, HW, min(32, (Ca + Cb) // 4), eps, 1 if silu else 0, hip.stream_ptr(xa.device)), "lfm_groupnorm2_f16")
+        return y
+
+    def _linear2(self, xa, xb, wb):
+        M, Nout = xa.shape[0], wb[0].shape[0]
+        out = torch.empty(M, Nout, dtype=torch.float16, device=xa.device)
+        hip.check(hip.lib().lfm_linear2_f16(hip.ptr(xa), xa.shape[1], hip.ptr(xb), xb.shape[1], hip.ptr(wb[0]), wb[0].stride(0), hip.ptr(out), Nout, M, Nout,
+                                            hip.ptr(wb[1]), None, hip.stream_ptr(xa.device)), "lfm_linear2_f16")
+        return out
+
+    def _cat(self, pair):
+        h, s = pair
+        cat = torch.empty(h.shape[0], h.shape[1] + s.shape[1], dtype=torch.float16, device=h.device)
+        hip.check(hip.lib().lfm_concat_channels_f16(hip.ptr(h), hip.ptr(s), hip.ptr(cat), h.shape[0], h.shape[1], s.shape[1], hip.stream_ptr(h.device)),
+                  "lfm_concat_channels_f16")
+        return cat
+
     def _block(self, name, b, x, N, H, W, film_all):
-        """UNetBlock.forward (EDM.py:258-292).  Returns (out, H, W)."""
+        """UNetBlock.forward (EDM.py:258-292).  Returns (out, H, W).  `x` may be the pair (h, skip) of a decoder block: its channel concat is then read in place
+        by the block's two consumers -- the first GroupNorm and the 1x1 skip convolution -- as in the origin-ADM UNet (round 6; the concat kernel was 2 % of an
+        evaluation at the ffhq_adm size)."""
         p = self._packed[name]
         Cin, Cout = b.in_channels, b.out_channels
+        pair = None
+        if isinstance(x, tuple):
+            if b.down or b.up or p["skip"] is None or x[0].shape[1] % 64 or x[1].shape[1] % 8:
+                x = self._cat(x)  # resampled / identity-skip inputs need the tensor itself
+            else:
+                pair = x
         orig = x
-        t = self._gn(x, N, H * W, Cin, p["gn0"], None, True)
+        t = self._gn2(pair[0], pair[1], N, H * W, p["gn0"], True) if pair is not None else self._gn(x, N, H * W, Cin, p["gn0"], None, True)
         if b.down:
             H, W = H // 2, W // 2
             t = self._pool(t, N, H, W, Cin)
@@ -280,7 +314,10 @@ class DhariwalUNet(nn.Module):
             up = torch.empty(N * H * W, Cin, dtype=torch.float16, device=x.device)
             hip.check(hip.lib().lfm_upsample2_f16(hip.ptr(orig), hip.ptr(up), N, H, W, Cin, hip.stream_ptr(x.device)), "lfm_upsample2_f16")
             orig = up
-        skip = orig if p["skip"] is None else self._linear(orig, p["skip"])
+        if pair is not None:
+            skip = self._linear2(pair[0], pair[1], p["skip"])
+        else:
+            skip = orig if p["skip"] is None else self._linear(orig, p["skip"])
         x = self._conv(t, p["c1"], N, H, W, Cout, Cout, resid=skip)
         if b.num_heads:
             T, ch = H * W, Cout // b.num_heads
@@ -335,11 +372,8 @@ class DhariwalUNet(nn.Module):
             skips.append((h, h.shape[1]))
         for name, b in self.dec.items():
             if h.shape[1] != b.in_channels:
-                s, cs = skips.pop()
-                cat = torch.empty(h.shape[0], h.shape[1] + cs, dtype=torch.float16, device=dev)
-                hip.check(L.lfm_concat_channels_f16(hip.ptr(h), hip.ptr(s), hip.ptr(cat), h.shape[0], h.shape[1], cs, hip.stream_ptr(dev)),
-                          "lfm_concat_channels_f16")
-                h = cat
+                s, _ = skips.pop()
+                h = (h, s)  # torch.cat([x, skips.pop()], dim=1) (EDM.py:840-842): consumed in place by the block where its shape allows it
             h, H, W = self._block("dec." + name, b, h, N, H, W, film_all)
         t1 = self._gn(h, N, H * W, h.shape[1], P["gn_out"], None, True)
         out = torch.empty(N, self.out_channels, H, W, device=dev)
