@@ -19,12 +19,14 @@
 //     four registers address both;
 //   * Q fragments and O rows go through buffer instructions: per item only two SGPR offsets change.
 // VMEM bookkeeping (vmcnt counts loads, LDS-DMAs and stores alike and retires in issue order).  Per wave and item: 8 LDS-DMAs (one per stage and operand), 4 Q loads,
-// 4 O stores.  Issue order, g = 4 item + stage: prologue K0 Q Q Q Q V0 K1 V1 K2 (four operations behind the Q loads, as in the steady state: the compiler's own wait for the fragments is vmcnt(4) on both paths); after barrier b: K(b+3), V(b+2); behind barrier 4i+3 also Q(i+1) x 4 (once the last
+// 4 O stores.  Issue order, g = 4 item + stage: prologue K0 Q Q Q Q V0 K1 V1 K2 (four operations behind the
+// Q loads, as in the steady state: the compiler's own wait for the fragments is vmcnt(4) on both paths); after barrier b: K(b+3), V(b+2); behind barrier 4i+3 also Q(i+1) x 4 (once the last
 // S MFMAs of item i have consumed the old fragments) and O(i) x 4.  Barrier b needs K(b) and V(b) (and Q for b = 4i): the counted waits are 4 / 10 / 2 / 2 for stage
 // 0 / 1 / 2 / 3 (first item: 3 / 3 / 2 / 2).  Stages past the workgroup's last item are issued with an out-of-range buffer offset (no memory traffic, zeros, but they
 // COUNT), so the waits are the same to the end.
 // LDS: 4 x 16 KiB ring + 8 x 1 KiB output staging (a wave's 8 rows x 128 B per pass, four passes: a store instruction covers eight whole 128-byte rows) = 72 KiB: two
-// workgroups per CU, four waves per SIMD, <= 128 VGPRs.  (80 KiB -- 2 KiB of staging per wave -- measured as ONE resident workgroup per CU: 2 x 80 KiB is the whole LDS.)
+// workgroups per CU, four waves per SIMD, <= 128 VGPRs.  (80 KiB -- 2 KiB of staging per wave, two passes -- measured the same time; the occupancy query answers two workgroups per CU for both sizes and the
+// per-workgroup trace shows both resident from the start: profiles/r06_attention_stream.txt.)
 #pragma once
 #include <stdlib.h>
 #include "gemm_kernel.h"
