@@ -182,6 +182,10 @@ int lfm_profile_blocks_read(float* host_ms_out, int max_n);
  * workgroups that stream K / V^T of consecutive items through an LDS ring (csrc/attention_stream_kernel.h); 0 = one workgroup per item (csrc/attention_kernel.h).
  * Same arithmetic in the same order per query: bit-identical results (tests/test_gpu_dit.py). */
 #define LFM_OPT_ATTENTION_STREAM 5
+/* key 6 (LFM_OPT_FUSED_QKV_ATTENTION), value 0 / 1, default 1: on the folded path, at 256 tokens per image and head_dim 64, the QKV projection and the attention
+ * core of a DiTBlock (models/DiT.py:120) run as ONE kernel -- a workgroup per (image, head) computes the head's 256 x 192 slice of the projection and attends on
+ * it out of the LDS; Q, K, V never reach HBM (csrc/qkv_attention_kernel.h); 0 = two kernels.  Same arithmetic in the same order: bit-identical results. */
+#define LFM_OPT_FUSED_QKV_ATTENTION 6
 int lfm_set_option(int key, int value);
 /* The settings lfm_dit_forward would run `call` with if it were enqueued by the calling thread now (per-call fields over the library defaults):
  * *gemm_select_out = kernel | flags << 4, *fold_ln_out = 0 / 1.  No launch; usable without a GPU. */

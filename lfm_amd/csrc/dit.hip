@@ -6,6 +6,7 @@
 #include "gemm_dispatch.h"
 #include "gemm_skinny_kernel.h"
 #include "gemm_sq64_kernel.h"
+#include "qkv_attention_kernel.h"
 
 // Library-wide switches = process-wide DEFAULTS (lfm_gemm_select, lfm_set_option); a call that carries its own values (lfm_dit_call.fold_ln /
 // .gemm_select, ABI 4) overrides them in THREAD-LOCAL state for the duration of lfm_dit_forward: every launcher reads the effective value on the
@@ -37,6 +38,7 @@ static int g_stagger = 0;
 int lfm_stagger_ticks() { return g_stagger; }
 static int g_opt_att_stream = 1;  // LFM_OPT_ATTENTION_STREAM: 256 tokens x head_dim 64 with more than 64 (image, head) items on the persistent streamed kernel
 int lfm_attention_stream_enabled() { return g_opt_att_stream; }
+static int g_opt_fused_qkv = 1;  // LFM_OPT_FUSED_QKV_ATTENTION: folded path at 256 tokens x head_dim 64: QKV projection + attention in one kernel (qkv_attention_kernel.h)
 static inline bool gemm_select_valid(int which) {
   const int k = which & 15;
   return which >= 0 && (k == 0 || k == 1 || k == 4 || k == 5 || k == 6 || k == 7 || k == 8);  // 7, 8: the latency-mode kernels through lfm_gemm_f16 (tests)
@@ -90,6 +92,10 @@ extern "C" int lfm_set_option(int key, int value) {  // key 1 (LFM_OPT_FOLD_LN):
   }
   if (key == 5) {  // LFM_OPT_ATTENTION_STREAM: 0 = one workgroup per (image, head) item (the rounds 1-5 kernel; A/B and the bit-equality test)
     g_opt_att_stream = value != 0;
+    return LFM_OK;
+  }
+  if (key == 6) {  // LFM_OPT_FUSED_QKV_ATTENTION: 0 = the QKV GEMM and the attention kernel as two launches (A/B and the bit-equality test)
+    g_opt_fused_qkv = value != 0;
     return LFM_OK;
   }
 #ifdef LFM_MEASURE
@@ -1424,24 +1430,36 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
 #endif
   const bool prof_blk = prof_ok && g_prof_blk_count < LFM_PROF_BLK_MAX;
   if (prof_blk) (void)hipEventRecord(g_prof_blk_ev[2 * g_prof_blk_count], st);
+  // QKV projection + attention in one kernel (qkv_attention_kernel.h): one (image, head) per workgroup -- images of exactly one 256-token tile, head_dim 64
+  const bool fused = fold && g_opt_fused_qkv && !w6 && T == 256 && D == s->heads * 64;
   if (fold) {
     for (int i = 0; i < s->depth; ++i) {
       const float* mod = ws.mod + (long)i * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
       const float* uq = ws.uvq + (long)i * 2 * rows * 3 * D;
       const float* uf = ws.uvf + (long)i * 2 * rows * H;
-      const EpiQKVMod e_qkv{Qb, Kb, Vb, uq, uq + (long)rows * 3 * D, uvs_q, D, D / s->heads, T, EpiQKV::log2_or_neg(T), rowstat_src(), nullptr, 0};
-      rc = launch_fold(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->qkv_w + (size_t)i * 3 * D * D, D, M, 3 * D, D, e_qkv);
-      if (rc) return rc;
-      DIT_CHK(ws.QKVH, (size_t)3 * M * D * 2, 0);
-      rc = attention_launch(Qb, Kb, Vb, ws.A, B, s->heads, D / s->heads, T, st);
-      if (rc) return rc;
-      DIT_CHK(ws.A, (size_t)M * D * 2, 1);
+      // attention output / proj operand `Ob` and the fc1 operand `A1b`: the two-kernel path reuses ws.A for O (the QKV GEMM is over); the fused kernel writes
+      // an image's O while other heads of the image still read its A' rows, so O goes to ws.A2 and proj hands A' back through ws.A
+      half_t* Ob = fused ? ws.A2 : ws.A;
+      half_t* A1b = fused ? ws.A : ws.A2;
+      if (fused) {
+        const QkvAttnArgs e_qa{uq, uq + (long)rows * 3 * D, uvs_q, rowstat_src(), Ob, D, s->heads, 0.125f * 1.4426950408889634f, nullptr, 0};
+        rc = launch_qkv_attention(ws.A, D, (const half_t*)w->qkv_w + (size_t)i * 3 * D * D, D, M, D, s->heads, D, e_qa, st);
+        if (rc) return rc;
+      } else {
+        const EpiQKVMod e_qkv{Qb, Kb, Vb, uq, uq + (long)rows * 3 * D, uvs_q, D, D / s->heads, T, EpiQKV::log2_or_neg(T), rowstat_src(), nullptr, 0};
+        rc = launch_fold(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->qkv_w + (size_t)i * 3 * D * D, D, M, 3 * D, D, e_qkv);
+        if (rc) return rc;
+        DIT_CHK(ws.QKVH, (size_t)3 * M * D * 2, 0);
+        rc = attention_launch(Qb, Kb, Vb, Ob, B, s->heads, D / s->heads, T, st);
+        if (rc) return rc;
+      }
+      DIT_CHK(Ob, (size_t)M * D * 2, 1);
       // proj: X += gate_msa * (.), A' for fc1 with scale_mlp, partials; c = the row means the qkv GEMM just published
-      const EpiGateResidMod e_proj{ws.X, D, w->proj_b + (size_t)i * D, mod + 2 * D, mstride, T, ws.A2, mod + 4 * D, mstride, ws.cen[cen_cur], ws.ln_part, tiles_p};
-      rc = launch_fold(ASrcRowMajor{ws.A, D, M, 0}, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D, e_proj);
+      const EpiGateResidMod e_proj{ws.X, D, w->proj_b + (size_t)i * D, mod + 2 * D, mstride, T, A1b, mod + 4 * D, mstride, ws.cen[cen_cur], ws.ln_part, tiles_p};
+      rc = launch_fold(ASrcRowMajor{Ob, D, M, 0}, (const half_t*)w->proj_w + (size_t)i * D * D, D, M, D, D, e_proj);
       if (rc) return rc;
       DIT_CHK(ws.X, (size_t)M * D * 4, 2);
-      DIT_CHK(ws.A2, (size_t)M * D * 2, 3);
+      DIT_CHK(A1b, (size_t)M * D * 2, 3);
       DIT_CHK(ws.ln_part, (size_t)M * tiles_p * 8, 4);
       const bool prof = prof_ok && g_prof_mode == 1 && g_prof_count < LFM_PROF_MAX;
       if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_count], st);
@@ -1451,7 +1469,7 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
 #else
       const EpiModGeluF16 e_fc1{ws.QKVH, H, uf, uf + (long)rows * H, uvs_f, T, rowstat_src(), nullptr, 0};
 #endif
-      rc = launch_fold(ASrcRowMajor{ws.A2, D, M, 0}, (const half_t*)w->fc1_w + (size_t)i * H * D, D, M, H, D, e_fc1);
+      rc = launch_fold(ASrcRowMajor{A1b, D, M, 0}, (const half_t*)w->fc1_w + (size_t)i * H * D, D, M, H, D, e_fc1);
       if (rc) return rc;
       if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_count++ + 1], st);
       DIT_CHK(ws.QKVH, (size_t)M * H * 2, 5);

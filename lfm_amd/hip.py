@@ -249,6 +249,7 @@ def ln_modulate(X, shift, scale, tokens, mod_stride):
 OPT_FOLD_LN = 1  # adaLN LayerNorm-modulate folded into the GEMM epilogues, default on (include/lfm_hip.h)
 OPT_SKINNY_GEMM = 4  # batch-1 DiT linears on the latency-mode kernels (1, default: csrc/gemm_sq64_kernel.h where rows % 64 == 0, else csrc/gemm_skinny_kernel.h; 2: always the latter; 0: split-K path)
 OPT_ATTENTION_STREAM = 5  # 256-token hd-64 attention on persistent workgroups with an LDS ring of K / V^T stages (csrc/attention_stream_kernel.h), default on; 0: one workgroup per item
+OPT_FUSED_QKV_ATTENTION = 6  # folded path, 256 tokens x hd 64: QKV projection + attention in one kernel (csrc/qkv_attention_kernel.h), default on; 0: two kernels
 OPT_GEMM_V6 = 2  # chip-filling row-major GEMMs on the one-wave-per-SIMD 256x256 kernel (csrc/gemm256w_kernel.h) instead of the 8-wave one
 
 

@@ -624,6 +624,46 @@ def test_folded_ln_epilogues_match_separate_launches_and_the_oracle(dev, name, b
     assert rel_l2(a[:k].cpu(), ref) < 2e-3 and rel_l2(base[:k].cpu(), ref) < 2e-3
 
 
+@pytest.mark.parametrize("name,batch,labels", [("DiT-L/2", 48, False), ("DiT-L/2", 64, False), ("DiT-B/2", 64, True), ("DiT-B/2", 67, False)])
+def test_fused_qkv_attention_matches_two_kernels(dev, name, batch, labels):
+    """lfm_set_option(LFM_OPT_FUSED_QKV_ATTENTION) (default on): on the folded path at 256 tokens x head_dim 64 the QKV projection and the attention core of a block
+    run as ONE kernel, a workgroup per (image, head) (csrc/qkv_attention_kernel.h: the 256 x 192 slice of the projection on the quadrant-phased K loop, Q / K / V^T
+    handed over through the LDS, the key loop of the per-item attention kernel).  Same K-tile order, same row affine, same softmax block: the forward must be
+    BIT-IDENTICAL to the two-kernel path and bit-repeatable -- one shared conditioning row (DiT-L/2) and one row per image (class-conditional DiT-B/2: u / v per
+    image), D = 1024 (16 K-tiles, 16 heads) and 768 (12 K-tiles, 12 heads: the tile order's group size changes), a batch that is not a multiple of the
+    XCD count."""
+    from lfm_amd import hip
+    from lfm_amd.models import DiT_models
+
+    kw = dict(num_classes=1000, label_dropout=0.1) if labels else dict(num_classes=1, label_dropout=0.0)
+    cfg = dit_ref.DiTCfg.named(name, **kw)
+    sd = dit_ref.make_dit_state(cfg, seed=9)
+    m = DiT_models[name](img_resolution=32, in_channels=4, **kw)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).eval()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(batch, 4, 32, 32, generator=g)
+    y = torch.randint(0, 1001, (batch,), generator=g) if labels else None
+    t = torch.linspace(0.05, 0.95, batch) if labels else torch.tensor(0.4)
+    xd, td, yd = x.to(dev), t.to(dev), (y.to(dev) if labels else None)
+    try:
+        hip.set_option(hip.OPT_FUSED_QKV_ATTENTION, 0)
+        two = m(td, xd, yd).clone()
+        hip.set_option(hip.OPT_FUSED_QKV_ATTENTION, 1)
+        a = m(td, xd, yd).clone()
+        b = m(td, xd, yd).clone()
+        torch.cuda.synchronize()
+    finally:
+        hip.set_option(hip.OPT_FUSED_QKV_ATTENTION, 1)
+    assert bool(torch.isfinite(a).all())
+    assert torch.equal(a, b)
+    bad = (a != two).flatten(1).any(dim=1)
+    assert not bool(bad.any()), f"{int(bad.sum())} of {batch} images differ (first {bad.nonzero()[:4].flatten().tolist()}), rel-L2 {rel_l2(a, two):.3e}"
+    k = 2
+    ref = dit_ref.dit_forward(sd, cfg, t[:k] if labels else t, x[:k], y[:k] if labels else None)
+    assert rel_l2(a[:k].cpu(), ref) < 2e-3
+
+
 @pytest.mark.parametrize("fold", [1, 0])
 def test_trained_like_dynamic_range(dev, fold):
     """Every other parity test runs on xavier / N(0, 0.02) weights.  A trained DiT has a few 'massive' residual channels, large adaLN scales and a wide
