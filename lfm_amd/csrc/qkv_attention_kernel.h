@@ -18,6 +18,15 @@
 // addresses), i.e. accumulator tiles j = 0 (Q), 1 (K), 2 (V).  Piece B0 = the Q and K rows (128 rows, 16 KiB, as before), piece B1 = the V rows (64 rows,
 // 8 KiB: ONE LDS-DMA per thread), so the phases are A0xB0 (16 MFMAs) | A0xB1 (8) | A1xB1 (8) | A1xB0 (16) and the counted vmcnt waits 5 5 5 6 instead of
 // 6 6 6 6.  The V tile is issued with the operands swapped (a lane then owns FOUR CONSECUTIVE TOKENS of one head dim = one 8-byte write into a V^T row).
+//
+// PERSISTENT workgroups (one per CU, items strided over the grid).  Measured with one workgroup per item (profiles/r06_fused_qkv_attention.txt): of 122 us the
+// K loop beyond its first tile takes 74, the key loop 32 and everything else 28 = 7 us per item -- workgroup dispatch, the row statistics, the first LDS-DMA round
+// trip, one K-tile, the hand-over, the stores.  Here the NEXT item's first four operand pieces, its row statistics and column constants are requested as soon as
+// every wave holds its Q fragments (the hand-over puts Q into the ring's first half and K / V^T into the second, so the first half is free during the key loop),
+// and the two pieces that land in the second half right behind the key loop: an item starts its K loop on operands that are already there.
+// VMEM bookkeeping (vmcnt counts loads, LDS-DMAs and stores alike and retires in issue order, as in attention_stream_kernel.h): per wave and item, in issue
+// order, [6 row-statistic loads (waves 0-3)] [6 column-constant loads] A0(0) A0(0) B0(0) B0(0) B1(0) A1(0) A1(0) | key loop | 4 output stores | A0(1) A0(1) B0(1)
+// B0(1): the K loop may start once B1(0) has landed = all but the newest 10 (the first item of a workgroup: 6, there are no stores in between).
 #pragma once
 #include "attention_kernel.h"
 #include "gemm256h_kernel.h"
@@ -34,36 +43,46 @@ struct QkvAttnArgs {
   int m0;
 };
 
-#define QKVA_LDS_BYTES (G256Q_LDS_BYTES + 2048)
+#define QKVA_LDS_BYTES (G256Q_LDS_BYTES + 8 * 4096)  // operand ring | output staging (4 KiB per wave), whose first 2 KiB hold the (a, b) of the 256 rows until the hand-over
 
 __global__ __launch_bounds__(512) void qkv_attention_kernel(const half_t* __restrict__ A, long lda, const half_t* __restrict__ W, long ldw, int M, int K,
-                                                            QkvAttnArgs ep, int dbg) {
+                                                            QkvAttnArgs ep, int items, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = wave >> 2, wn = wave & 3;
   const int D = ep.D;
 
+  // item = (image, head) in the tile order of the 256-row GEMMs (an XCD walks 4- or 8-image x all-heads patches: few A' panels and W slices per L2); a workgroup's
+  // items are gridDim.x apart -- a multiple of 8 when it matters, so they stay on its XCD's range
+  int item = blockIdx.x;
   int tile_m, head;
-  g256_tile_order(blockIdx.x, gridDim.x, ep.heads, dbg, tile_m, head);
-  const int m0 = tile_m * G256_BM;
+  g256_tile_order(item, items, ep.heads, dbg, tile_m, head);
+  int m0 = tile_m * G256_BM;
 
   // ---- DMA sources (piece = rows x 128 B; thread tid stages 16-byte chunk tid of an 8-KiB issue; chunk c of LDS row r holds logical chunk c ^ ((r >> 1) & 7))
   const int cswz = ((tid & 7) ^ ((tid >> 4) & 7)) * 8;
   const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, -1, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, -1, 0x00020000);
   unsigned avoff[2][2], wvoff0[2], wvoff1;
+  auto set_item = [&](int m0_, int head_) {
 #pragma unroll
-  for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
-    for (int p = 0; p < 2; ++p) avoff[s][p] = ((unsigned)(m0 + p * 128 + s * 64 + (tid >> 3)) * (unsigned)lda + (unsigned)cswz) * 2u;
+      for (int p = 0; p < 2; ++p) avoff[s][p] = ((unsigned)(m0_ + p * 128 + s * 64 + (tid >> 3)) * (unsigned)lda + (unsigned)cswz) * 2u;
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {  // B0: LDS row wn' * 32 + c, c < 16: Q dim 16 wn' + c, else K dim 16 wn' + c - 16
-    const int wnp = p * 2 + (tid >> 8), c = (tid >> 3) & 31;
-    const int n = (c >> 4) * D + head * 64 + wnp * 16 + (c & 15);
-    wvoff0[p] = ((unsigned)n * (unsigned)ldw + (unsigned)cswz) * 2u;
-  }
-  wvoff1 = ((unsigned)(2 * D + head * 64 + (tid >> 3)) * (unsigned)ldw + (unsigned)cswz) * 2u;  // B1: LDS row = V dim
+    for (int p = 0; p < 2; ++p) {  // B0: LDS row wn' * 32 + c, c < 16: Q dim 16 wn' + c, else K dim 16 wn' + c - 16
+      const int wnp = p * 2 + (tid >> 8), c = (tid >> 3) & 31;
+      const int n = (c >> 4) * D + head_ * 64 + wnp * 16 + (c & 15);
+      wvoff0[p] = ((unsigned)n * (unsigned)ldw + (unsigned)cswz) * 2u;
+    }
+    wvoff1 = ((unsigned)(2 * D + head_ * 64 + (tid >> 3)) * (unsigned)ldw + (unsigned)cswz) * 2u;  // B1: LDS row = V dim
+  };
+  set_item(m0, head);
+#ifdef LFM_MEASURE  // phase split (tools/fused_qkv_phases.py; results are garbage): flag 67108864 = two K-tiles only, 33554432 = no key loop
+  const int nk = (dbg & 67108864) ? 2 : K / G256Q_BK;
+#else
   const int nk = K / G256Q_BK;
+#endif
   const int dma_off = wave * 1024;
   auto issue_a = [&](int s, int kt, char* slot) {
     glds16_buf(rsa, avoff[s][0], (unsigned)kt * (G256Q_BK * 2), slot + dma_off);
@@ -76,10 +95,6 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(const half_t* __rest
   auto issue_b1 = [&](int kt, char* slot) { glds16_buf(rsw, wvoff1, (unsigned)kt * (G256Q_BK * 2), slot + dma_off); };
 
   f32x4_t acc[8][3];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   const int l15 = lane & 15, l4 = lane >> 4;
   const int rkey = (l15 >> 1) & 7;
@@ -197,25 +212,25 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(const half_t* __rest
     __builtin_amdgcn_s_setprio(0);
   };
 
-  // ---- prologue: row statistics and column constants requested BEFORE the first DMAs (vmcnt retires in order), pieces A0(0) B0(0) B1(0) A1(0) [A0(1) B0(1)]
+  // ---- prologue of the workgroup's first item: row statistics and column constants requested BEFORE the first DMAs, pieces A0(0) B0(0) B1(0) A1(0) A0(1) B0(1)
   G256hRowStatRegs rsr = g256h_rowstat_load(ep, m0, M);
-  const long uvo = (long)tile_m * ep.uv_stride + head * 64 + wn * 16;
-  const f32x4 uq = *(const f32x4*)(ep.u + uvo + 4 * l4), vq = *(const f32x4*)(ep.v + uvo + 4 * l4);
-  const f32x4 uk = *(const f32x4*)(ep.u + uvo + D + 4 * l4), vk = *(const f32x4*)(ep.v + uvo + D + 4 * l4);
-  const float uv_ = ep.u[uvo + 2 * D + l15], vv_ = ep.v[uvo + 2 * D + l15];
+  f32x4 uq, vq, uk, vk;
+  float uv_, vv_;
+  auto load_consts = [&](int tile_m_, int head_) {
+    const long uvo = (long)tile_m_ * ep.uv_stride + head_ * 64 + wn * 16;
+    uq = *(const f32x4*)(ep.u + uvo + 4 * l4), vq = *(const f32x4*)(ep.v + uvo + 4 * l4);
+    uk = *(const f32x4*)(ep.u + uvo + D + 4 * l4), vk = *(const f32x4*)(ep.v + uvo + D + 4 * l4);
+    uv_ = ep.u[uvo + 2 * D + l15], vv_ = ep.v[uvo + 2 * D + l15];
+  };
+  load_consts(tile_m, head);
   __builtin_amdgcn_sched_barrier(0);
   issue_a(0, 0, smem + G256Q_SLOT_A0);
   issue_b0(0, smem + G256Q_SLOT_B0);
   issue_b1(0, smem + G256Q_SLOT_B1);
   issue_a(1, 0, smem + G256Q_SLOT_A1);
-  if (nk > 1) {
-    issue_a(0, 1, smem + G256Q_BUF_BYTES + G256Q_SLOT_A0);
-    issue_b0(1, smem + G256Q_BUF_BYTES + G256Q_SLOT_B0);
-  }
+  issue_a(0, 1, smem + G256Q_BUF_BYTES + G256Q_SLOT_A0);
+  issue_b0(1, smem + G256Q_BUF_BYTES + G256Q_SLOT_B0);
   g256h_rowstat_finish(ep, rsr, smem, m0, M, head);
-  if (nk > 1) QKVA_VMCNT(6);
-  else QKVA_VMCNT(2);
-  G256_BARRIER();
   auto run = [&](auto GC) {
     constexpr int G = decltype(GC)::value;
     if constexpr (G == 0) load_part(g256q_ic<0>{}, g256q_ic<0>{}, 0, 1 < nk, 2 < nk);
@@ -247,130 +262,245 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(const half_t* __rest
     }
     if (t < nk) tile(g256q_ic<0>{}, t);
   };
-  if (g == 0) run(g256q_ic<0>{});
-  else run(g256q_ic<1>{});
+  // LDS in the attention phase: Q [256][64] in the first ring half (its A0 / B0 slots), K [256][64] and V^T [64][256] in the second half; above the ring the
+  // (a, b) rows and 1 KiB of output staging per wave.  Q, K: 128-byte rows, chunk c of row r at c ^ ((r >> 1) & 7); V^T: 512-byte rows, tokens of a 16-group in
+  // the vt_pos order, chunk c of row d at c ^ (d & 15) -- the images dit_attention_kernel<256, 1, 64> stages from HBM.
+  char* const Qs = smem;
+  char* const Ks = smem + G256Q_BUF_BYTES;
+  char* const Vs = smem + G256Q_BUF_BYTES + 32768;
+  const float* const rs = (const float*)(smem + G256Q_LDS_BYTES);
+  char* const ob = smem + G256Q_LDS_BYTES + wave * 4096;
+  const float scale_log2e = ep.scale_log2e;
+  bool first = true;
+  // (measurement builds, flag 2: s_memtime stamps of waves 0 and 4 of workgroup 0 -> att_trace[0..31] / [32..63], read with lfm_attention_trace_read; per item k, slot
+  // 7 k + {0 loop top, 1 operands landed (barrier), 2 K loop done, 3 hand-over done (barrier), 4 next item requested, 5 key loop done, 6 stores issued})
+  [[maybe_unused]] int tr_k = 0;
+  auto stamp = [&](int slot) {
+#ifdef LFM_MEASURE
+    if ((dbg & 2) && blockIdx.x == 0 && (wave & 3) == 0 && tr_k < 4) {
+      unsigned long long t;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+      if (lane == 0) att_trace[(wave >> 2) * 32 + 7 * tr_k + slot] = t;
+    }
+#else
+    (void)slot;
+#endif
+  };
+#pragma unroll 1
+  for (;;) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    stamp(0);
+    if (first) QKVA_VMCNT(6);
+    else QKVA_VMCNT(10);
+    G256_BARRIER();
+    stamp(1);
+    if (g == 0) run(g256q_ic<0>{});
+    else run(g256q_ic<1>{});
+    stamp(2);
+
+    // ---- hand-over: the ring is dead (every wave is past the last barrier, its fragment reads retired before its MFMAs).  (The lane id is laundered per phase:
+    // the phases' per-lane LDS addresses are loop invariants the compiler would otherwise keep in registers across the K loop, which has none to spare.)
+    {
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      const int l15 = ln & 15, l4 = ln >> 4;
+      const int d = wn * 16 + l15;  // V dim of this lane
+      // the (a, b) rows first, four 16-row tiles at a time: reads behind the Q / K / V^T writes could not be moved up by the compiler (same address space), and a
+      // read - compute - write chain per tile costs an LDS round trip each (measured: 3600 ticks of an item's 52600, tools/fused_qkv_trace.py)
+#pragma unroll
+      for (int ih = 0; ih < 2; ++ih) {
+        f32x2 ab[4];
+        f32x4 r0[4], r1[4];
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+          const int i = ih * 4 + ii;
+          ab[ii] = *(const f32x2*)(rs + 2 * (g * 128 + i * 16 + l15));
+          const int t0 = g * 128 + i * 16 + 4 * l4;  // tokens t0 .. t0 + 3 of V dim d
+          r0[ii] = *(const f32x4*)(rs + 2 * t0);
+          r1[ii] = *(const f32x4*)(rs + 2 * t0 + 4);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+          const int i = ih * 4 + ii;
+          const int m = g * 128 + i * 16 + l15;
+          const f32x4 q = row_affine4(ab[ii].x, ab[ii].y, acc[i][0], uq, vq);
+          const f32x4 k = row_affine4(ab[ii].x, ab[ii].y, acc[i][1], uk, vk);
+          const int off = m * 128 + (((2 * wn + (l4 >> 1)) ^ ((m >> 1) & 7)) << 4) + (l4 & 1) * 8;
+          *(half4_t*)(Qs + off) = (half4_t){(half_t)q.x, (half_t)q.y, (half_t)q.z, (half_t)q.w};
+          *(half4_t*)(Ks + off) = (half4_t){(half_t)k.x, (half_t)k.y, (half_t)k.z, (half_t)k.w};
+          const half4_t h = {(half_t)fma_v(r0[ii].x, acc[i][2][0], fma_v(r0[ii].y, uv_, vv_)), (half_t)fma_v(r0[ii].z, acc[i][2][1], fma_v(r0[ii].w, uv_, vv_)),
+                             (half_t)fma_v(r1[ii].x, acc[i][2][2], fma_v(r1[ii].y, uv_, vv_)), (half_t)fma_v(r1[ii].z, acc[i][2][3], fma_v(r1[ii].w, uv_, vv_))};
+          // tokens 4 l4 .. + 3 of the 16-group sit at positions {0, 8, 4, 12}[l4] .. + 3: 16-byte chunk 2 group + (l4 & 1), upper half for l4 >= 2
+          *(half4_t*)(Vs + d * 512 + (((2 * (8 * g + i) + (l4 & 1)) ^ (d & 15)) << 4) + (l4 >> 1) * 8) = h;
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    G256_BARRIER();
+    stamp(3);
+
+    // ---- attention: wave w owns queries 32 w .. 32 w + 31 (dit_attention_kernel<256, 1, 64>: S^T = K Q^T and O^T = V^T P^T on v_mfma_f32_32x32x16_f16).
+    // (Measured and not kept: the SIMD's two waves taking turns at s_setprio 1 per pair of key blocks -- the second-dispatched wave group runs its key loop
+    // ~25 % longer than the first, 9400 vs 7400 ticks -- 10448 vs 10463 us per DiT-L/2 forward.)
+    int lna = lane;
+    asm volatile("" : "+v"(lna));
+    const int hsel = lna >> 5, l31 = lna & 31;
+    const int akey = (l31 >> 1) & 7;
+    half8_t qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const half8_t*)(Qs + (wave * 32 + l31) * 128 + (((ks * 2 + hsel) ^ akey) << 4));
+    // the workgroup's next item: once every wave holds its Q fragments the first ring half is free -- request its row statistics, column constants and first
+    // four operand pieces now, under the key loop
+    const int nitem = item + (int)gridDim.x;
+    const bool has_next = nitem < items;
+    int ntile_m = 0, nhead = 0;
+    if (has_next) {
+      g256_tile_order(nitem, items, ep.heads, dbg, ntile_m, nhead);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      G256_BARRIER();
+      set_item(ntile_m * G256_BM, nhead);
+      rsr = g256h_rowstat_load(ep, ntile_m * G256_BM, M);
+      load_consts(ntile_m, nhead);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // its seven LDS-DMAs go out one per half key block: an issue stalls the wave ~110 cycles (tools/ubench/ldsdma_rate.hip), which the SIMD's other wave can use
+    // inside the key loop and nobody can in front of it
+    auto next_dma = [&](int idx) {
+      if (!has_next) return;
+      if (idx == 0) glds16_buf(rsa, avoff[0][0], 0u, smem + G256Q_SLOT_A0 + dma_off);
+      else if (idx == 1) glds16_buf(rsa, avoff[0][1], 0u, smem + G256Q_SLOT_A0 + 8192 + dma_off);
+      else if (idx == 2) glds16_buf(rsw, wvoff0[0], 0u, smem + G256Q_SLOT_B0 + dma_off);
+      else if (idx == 3) glds16_buf(rsw, wvoff0[1], 0u, smem + G256Q_SLOT_B0 + 8192 + dma_off);
+      else if (idx == 4) glds16_buf(rsw, wvoff1, 0u, smem + G256Q_SLOT_B1 + dma_off);
+      else if (idx == 5) glds16_buf(rsa, avoff[1][0], 0u, smem + G256Q_SLOT_A1 + dma_off);
+      else if (idx == 6) glds16_buf(rsa, avoff[1][1], 0u, smem + G256Q_SLOT_A1 + 8192 + dma_off);
+    };
+    stamp(4);
+    f32x16 Oa[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Oa[0][e] = 0.f, Oa[1][e] = 0.f;
+    float mrun = -3.0e38f, lrun = 0.f;
+    f32x16 zero16;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) zero16[e] = 0.f;
+    auto qk = [&](f32x16& S, int kb) {
+      const char* kp = Ks + (kb * 32 + l31) * 128;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const half8_t kf = *(const half8_t*)(kp + (((ks * 2 + hsel) ^ akey) << 4));
+        S = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? zero16 : S, 0, 0, 0);
+      }
+    };
+    auto softmax_pv = [&](f32x16& S, int kb) {
+      half8_t P[2];
+      att_softmax_block<2>(S, kb == 0, mrun, lrun, Oa, scale_log2e, P);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const int dd = db * 32 + l31;
+          const int c0 = kb * 4 + 2 * s + hsel;
+          const half8_t vf = *(const half8_t*)(Vs + dd * 512 + ((c0 ^ (dd & 15)) << 4));
+          Oa[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, P[s], Oa[db], 0, 0, 0);
+        }
+    };
+    f32x16 Sa, Sb;
+#ifdef LFM_MEASURE
+    if (!(dbg & 33554432))
+#endif
+    {
+      qk(Sa, 0);
+#pragma unroll
+      for (int kb = 0; kb < 8; kb += 2) {
+        qk(Sb, kb + 1);
+        next_dma(kb);
+        softmax_pv(Sa, kb);
+        if (kb + 2 < 8) qk(Sa, kb + 2);
+        next_dma(kb + 1);
+        softmax_pv(Sb, kb + 1);
+      }
+    }
+#ifdef LFM_MEASURE
+    else {
+#pragma unroll
+      for (int i = 0; i < 7; ++i) next_dma(i);
+    }
+#endif
+    stamp(5);
+    // ---- normalise and store: lane owns query l31, d = db * 32 + 8 g + 4 hsel + r.  One pass through the wave's 4 KiB of staging (32 rows x 128 B; 8-byte position
+    // p of row r at p ^ ((r & 7) << 1)), read back as 16-byte chunks: a store instruction covers eight whole 128-byte output rows.  The staging lies above the
+    // ring, over the (a, b) rows of THIS item, dead since the hand-over.
+    {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const float inv = 1.0f / (lrun + xhalf(lrun));
+      const unsigned ow = (unsigned)(l31 * 128), okey2 = (unsigned)((l31 & 7) << 1);
+      const int orow = lna >> 3, och = lna & 7;
+      const unsigned ord0 = (unsigned)(orow * 128 + ((och ^ orow) << 4));
+      half_t* const obase = ep.O + ((long)m0 + wave * 32 + orow) * D + head * 64 + och * 8;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+          half4_t hv = {(half_t)(Oa[db][4 * gg] * inv), (half_t)(Oa[db][4 * gg + 1] * inv), (half_t)(Oa[db][4 * gg + 2] * inv), (half_t)(Oa[db][4 * gg + 3] * inv)};
+          *(half4_t*)(ob + ow + ((((unsigned)(db * 8 + 2 * gg + hsel)) ^ okey2) << 3)) = hv;
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private rows: no barrier (also the compiler barrier between the half4 writes and the f32x4 reads)
+      f32x4 vrow[4];
+#pragma unroll
+      for (int h = 0; h < 4; ++h) vrow[h] = *(const f32x4*)(ob + h * 1024 + ord0);
+#pragma unroll
+      for (int h = 0; h < 4; ++h) *(f32x4*)(obase + (long)(h * 8) * D) = vrow[h];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    stamp(6);
+    ++tr_k;
+    if (!has_next) break;
+    // every wave is done with K / V^T and with its output staging: the next item's (a, b) rows (its statistics have long landed), and the second ring half
+    // takes its A0(1) B0(1)
+    G256_BARRIER();
+    g256h_rowstat_finish(ep, rsr, smem, ntile_m * G256_BM, M, nhead);
+    issue_a(0, 1, smem + G256Q_BUF_BYTES + G256Q_SLOT_A0);
+    issue_b0(1, smem + G256Q_BUF_BYTES + G256Q_SLOT_B0);
+    item = nitem;
+    tile_m = ntile_m;
+    head = nhead;
+    m0 = ntile_m * G256_BM;
+    first = false;
+  }
 #undef QKVA_VMCNT
 #undef QKVA_LGKM
-
-  // ---- hand-over: the ring is dead (every wave is past the last barrier, its fragment reads retired before its MFMAs).  Q [256][64], K [256][64]: 128-byte rows,
-  // chunk c of row r at c ^ ((r >> 1) & 7); V^T [64][256]: 512-byte rows, tokens of a 16-group in the vt_pos order, chunk c of row d at c ^ (d & 15) -- the images
-  // dit_attention_kernel<256, 1, 64> stages from HBM.
-  char* const Qs = smem;
-  char* const Ks = smem + 32768;
-  char* const Vs = smem + 65536;
-  {
-    const float* rs = ep.rs;
-    const int d = wn * 16 + l15;  // V dim of this lane
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int m = g * 128 + i * 16 + l15;
-      const f32x2 ab = *(const f32x2*)(rs + 2 * m);
-      const f32x4 q = row_affine4(ab.x, ab.y, acc[i][0], uq, vq);
-      const f32x4 k = row_affine4(ab.x, ab.y, acc[i][1], uk, vk);
-      const int off = m * 128 + (((2 * wn + (l4 >> 1)) ^ ((m >> 1) & 7)) << 4) + (l4 & 1) * 8;
-      *(half4_t*)(Qs + off) = (half4_t){(half_t)q.x, (half_t)q.y, (half_t)q.z, (half_t)q.w};
-      *(half4_t*)(Ks + off) = (half4_t){(half_t)k.x, (half_t)k.y, (half_t)k.z, (half_t)k.w};
-      const int t0 = g * 128 + i * 16 + 4 * l4;  // tokens t0 .. t0 + 3 of V dim d
-      const f32x4 r0 = *(const f32x4*)(rs + 2 * t0), r1 = *(const f32x4*)(rs + 2 * t0 + 4);
-      const half4_t h = {(half_t)fma_v(r0.x, acc[i][2][0], fma_v(r0.y, uv_, vv_)), (half_t)fma_v(r0.z, acc[i][2][1], fma_v(r0.w, uv_, vv_)),
-                         (half_t)fma_v(r1.x, acc[i][2][2], fma_v(r1.y, uv_, vv_)), (half_t)fma_v(r1.z, acc[i][2][3], fma_v(r1.w, uv_, vv_))};
-      // tokens 4 l4 .. + 3 of the 16-group sit at positions {0, 8, 4, 12}[l4] .. + 3: 16-byte chunk 2 group + (l4 & 1), upper half for l4 >= 2
-      *(half4_t*)(Vs + d * 512 + (((2 * (8 * g + i) + (l4 & 1)) ^ (d & 15)) << 4) + (l4 >> 1) * 8) = h;
-    }
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  G256_BARRIER();
-
-  // ---- attention: wave w owns queries 32 w .. 32 w + 31 (dit_attention_kernel<256, 1, 64>: S^T = K Q^T and O^T = V^T P^T on v_mfma_f32_32x32x16_f16)
-  const int hsel = lane >> 5, l31 = lane & 31;
-  const int akey = (l31 >> 1) & 7;
-  half8_t qf[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const half8_t*)(Qs + (wave * 32 + l31) * 128 + (((ks * 2 + hsel) ^ akey) << 4));
-  f32x16 zero16;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) zero16[e] = 0.f;
-  f32x16 Oa[2];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) Oa[0][e] = 0.f, Oa[1][e] = 0.f;
-  float mrun = -3.0e38f, lrun = 0.f;
-  const float scale_log2e = ep.scale_log2e;
-  auto qk = [&](f32x16& S, int kb) {
-    const char* kp = Ks + (kb * 32 + l31) * 128;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const half8_t kf = *(const half8_t*)(kp + (((ks * 2 + hsel) ^ akey) << 4));
-      S = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? zero16 : S, 0, 0, 0);
-    }
-  };
-  auto softmax_pv = [&](f32x16& S, int kb) {
-    half8_t P[2];
-    att_softmax_block<2>(S, kb == 0, mrun, lrun, Oa, scale_log2e, P);
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int db = 0; db < 2; ++db) {
-        const int dd = db * 32 + l31;
-        const int c0 = kb * 4 + 2 * s + hsel;
-        const half8_t vf = *(const half8_t*)(Vs + dd * 512 + ((c0 ^ (dd & 15)) << 4));
-        Oa[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, P[s], Oa[db], 0, 0, 0);
-      }
-  };
-  f32x16 Sa, Sb;
-  qk(Sa, 0);
-#pragma unroll
-  for (int kb = 0; kb < 8; kb += 2) {
-    qk(Sb, kb + 1);
-    softmax_pv(Sa, kb);
-    if (kb + 2 < 8) qk(Sa, kb + 2);
-    softmax_pv(Sb, kb + 1);
-  }
-  // ---- normalise and store: lane owns query l31, d = db * 32 + 8 g + 4 hsel + r.  Four passes of 8 rows through 1 KiB of the wave's own (dead) Q rows:
-  // 8-byte position p of staging row r at p ^ (r << 1), read back as 16-byte chunks -- a store instruction covers eight whole 128-byte output rows.
-  {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const float inv = 1.0f / (lrun + xhalf(lrun));
-    char* const ob = Qs + wave * 4096;
-    const unsigned ow = (unsigned)((l31 & 7) * 128), okey2 = (unsigned)((l31 & 7) << 1);
-    const int orow = lane >> 3, och = lane & 7;
-    const unsigned ord0 = (unsigned)(orow * 128 + ((och ^ orow) << 4));
-    half_t* const obase = ep.O + ((long)m0 + wave * 32 + orow) * D + head * 64 + och * 8;
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {
-      if ((l31 >> 3) == h) {
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-          for (int gg = 0; gg < 4; ++gg) {
-            half4_t hv = {(half_t)(Oa[db][4 * gg] * inv), (half_t)(Oa[db][4 * gg + 1] * inv), (half_t)(Oa[db][4 * gg + 2] * inv), (half_t)(Oa[db][4 * gg + 3] * inv)};
-            *(half4_t*)(ob + ow + ((((unsigned)(db * 8 + 2 * gg + hsel)) ^ okey2) << 3)) = hv;
-          }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private rows: no barrier (also the compiler barrier between the half4 writes and the f32x4 read)
-      const f32x4 vrow = *(const f32x4*)(ob + ord0);
-      *(f32x4*)(obase + (long)(h * 8) * D) = vrow;
-      if (h < 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the rows of pass h are in registers before pass h + 1 overwrites them
-    }
-  }
 }
 
 // A: [M, lda] fp16 (the centred, (1 + scale)-weighted rows A' of the folded path), W: [3 D, ldw] fp16 (rows q | k | v, head-major), O: [M, D].
 // M = images x 256 tokens, D = heads x 64, K % 64 == 0.
 static inline int launch_qkv_attention(const half_t* A, long lda, const half_t* W, long ldw, int M, int D, int heads, int K, const QkvAttnArgs& ep,
                                        hipStream_t stream) {
-  if (M <= 0 || (M % G256_BM) != 0 || heads <= 0 || D != heads * 64 || K <= 0 || (K % G256Q_BK) != 0) return LFM_ERR_SHAPE;
+  if (M <= 0 || (M % G256_BM) != 0 || heads <= 0 || D != heads * 64 || K < 2 * G256Q_BK || (K % G256Q_BK) != 0) return LFM_ERR_SHAPE;
   if ((long)M * lda >= (1L << 30) || (long)3 * D * ldw >= (1L << 30)) return LFM_ERR_SHAPE;  // 32-bit byte offsets of the buffer-addressed LDS-DMAs
   if ((lda % 8) != 0 || (ldw % 8) != 0 || ((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)ep.O & 15) || ((uintptr_t)ep.u & 15) || ((uintptr_t)ep.v & 15) ||
       (ep.uv_stride % 4) != 0)
     return LFM_ERR_ALIGN;
   if (ep.st.tiles_p > G256H_MAX_PARTS) return LFM_ERR_SHAPE;
+  int devid = 0;
+  (void)hipGetDevice(&devid);
   static lfm_device_mask attr_set{0};
-  const unsigned long long dbit = lfm_device_bit();
+  static std::atomic<int> cus[64];
+  const unsigned long long dbit = 1ull << (devid & 63);
   if (lfm_device_todo(attr_set, dbit)) {
     if (hipFuncSetAttribute((const void*)qkv_attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, QKVA_LDS_BYTES) != hipSuccess) return LFM_ERR_LAUNCH;
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, devid) != hipSuccess || n <= 0) n = 256;
+    cus[devid & 63].store(n, std::memory_order_relaxed);
     lfm_device_done(attr_set, dbit);
   }
-  hipLaunchKernelGGL(qkv_attention_kernel, dim3((M / G256_BM) * heads), dim3(512), QKVA_LDS_BYTES, stream, A, lda, W, ldw, M, K, ep, lfm_gemm_debug_flags());
+  const int items = (M / G256_BM) * heads, ncu = cus[devid & 63].load(std::memory_order_relaxed);
+  const int dbg = lfm_gemm_debug_flags();
+  const int grid = (items <= ncu || (dbg & 4194304)) ? items : ncu;  // one persistent workgroup per CU (flag 4194304: one workgroup per item, A/B)
+  hipLaunchKernelGGL(qkv_attention_kernel, dim3(grid), dim3(512), QKVA_LDS_BYTES, stream, A, lda, W, ldw, M, K, ep, items, dbg);
   LFM_CHECK_LAUNCH();
   return LFM_OK;
 }
