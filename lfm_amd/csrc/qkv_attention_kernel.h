@@ -70,9 +70,9 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(const half_t* __rest
 #pragma unroll
       for (int p = 0; p < 2; ++p) avoff[s][p] = ((unsigned)(m0_ + p * 128 + s * 64 + (tid >> 3)) * (unsigned)lda + (unsigned)cswz) * 2u;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {  // B0: LDS row wn' * 32 + c, c < 16: Q dim 16 wn' + c, else K dim 16 wn' + c - 16
-      const int wnp = p * 2 + (tid >> 8), c = (tid >> 3) & 31;
-      const int n = (c >> 4) * D + head_ * 64 + wnp * 16 + (c & 15);
+    for (int p = 0; p < 2; ++p) {  // B0: LDS row wn' * 32 + c = column cc = c & 15 of wave wn''s tile c >> 4: dim 32 (wn' & 1) + 8 (cc >> 2) + 4 (c >> 4) + (cc & 3) of Q (wn' < 2) / K
+      const int wnp = p * 2 + (tid >> 8), c = (tid >> 3) & 31, cc = c & 15;
+      const int n = (wnp >> 1) * D + head_ * 64 + (wnp & 1) * 32 + (cc >> 2) * 8 + (c >> 4) * 4 + (cc & 3);
       wvoff0[p] = ((unsigned)n * (unsigned)ldw + (unsigned)cswz) * 2u;
     }
     wvoff1 = ((unsigned)(2 * D + head_ * 64 + (tid >> 3)) * (unsigned)ldw + (unsigned)cswz) * 2u;  // B1: LDS row = V dim
@@ -217,10 +217,11 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(const half_t* __rest
   f32x4 uq, vq, uk, vk;
   float uv_, vv_;
   auto load_consts = [&](int tile_m_, int head_) {
-    const long uvo = (long)tile_m_ * ep.uv_stride + head_ * 64 + wn * 16;
-    uq = *(const f32x4*)(ep.u + uvo + 4 * l4), vq = *(const f32x4*)(ep.v + uvo + 4 * l4);
-    uk = *(const f32x4*)(ep.u + uvo + D + 4 * l4), vk = *(const f32x4*)(ep.v + uvo + D + 4 * l4);
-    uv_ = ep.u[uvo + 2 * D + l15], vv_ = ep.v[uvo + 2 * D + l15];
+    const long uvh = (long)tile_m_ * ep.uv_stride + head_ * 64;
+    const long uvo = uvh + (wn >> 1) * D + (wn & 1) * 32 + 8 * l4;  // the lane's eight consecutive dims of Q (waves 0, 1) / K (waves 2, 3): tile 0 = the first four, tile 1 = the others
+    uq = *(const f32x4*)(ep.u + uvo), vq = *(const f32x4*)(ep.v + uvo);
+    uk = *(const f32x4*)(ep.u + uvo + 4), vk = *(const f32x4*)(ep.v + uvo + 4);
+    uv_ = ep.u[uvh + 2 * D + wn * 16 + l15], vv_ = ep.v[uvh + 2 * D + wn * 16 + l15];
   };
   load_consts(tile_m, head);
   __builtin_amdgcn_sched_barrier(0);
@@ -323,19 +324,43 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(const half_t* __rest
           r1[ii] = *(const f32x4*)(rs + 2 * t0 + 4);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        char* const QKs = wn < 2 ? Qs : Ks;
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
           const int i = ih * 4 + ii;
           const int m = g * 128 + i * 16 + l15;
-          const f32x4 q = row_affine4(ab[ii].x, ab[ii].y, acc[i][0], uq, vq);
-          const f32x4 k = row_affine4(ab[ii].x, ab[ii].y, acc[i][1], uk, vk);
-          const int off = m * 128 + (((2 * wn + (l4 >> 1)) ^ ((m >> 1) & 7)) << 4) + (l4 & 1) * 8;
-          *(half4_t*)(Qs + off) = (half4_t){(half_t)q.x, (half_t)q.y, (half_t)q.z, (half_t)q.w};
-          *(half4_t*)(Ks + off) = (half4_t){(half_t)k.x, (half_t)k.y, (half_t)k.z, (half_t)k.w};
-          const half4_t h = {(half_t)fma_v(r0[ii].x, acc[i][2][0], fma_v(r0[ii].y, uv_, vv_)), (half_t)fma_v(r0[ii].z, acc[i][2][1], fma_v(r0[ii].w, uv_, vv_)),
-                             (half_t)fma_v(r1[ii].x, acc[i][2][2], fma_v(r1[ii].y, uv_, vv_)), (half_t)fma_v(r1[ii].z, acc[i][2][3], fma_v(r1[ii].w, uv_, vv_))};
-          // tokens 4 l4 .. + 3 of the 16-group sit at positions {0, 8, 4, 12}[l4] .. + 3: 16-byte chunk 2 group + (l4 & 1), upper half for l4 >= 2
-          *(half4_t*)(Vs + d * 512 + (((2 * (8 * g + i) + (l4 & 1)) ^ (d & 15)) << 4) + (l4 >> 1) * 8) = h;
+          // tiles 0 and 1 of the wave are the two halves of EIGHT consecutive dims of one matrix (the W rows were gathered that way): one 16-byte write per row
+          const f32x4 lo = row_affine4(ab[ii].x, ab[ii].y, acc[i][0], uq, vq);
+          const f32x4 hi = row_affine4(ab[ii].x, ab[ii].y, acc[i][1], uk, vk);
+#ifdef LFM_MEASURE  // (hand-over ablation: flag 524288 = no Q / K writes, 262144 = no V^T writes)
+          if (!(dbg & 524288))
+#endif
+            *(half8_t*)(QKs + m * 128 + (((4 * (wn & 1) + l4) ^ ((m >> 1) & 7)) << 4)) =
+                (half8_t){(half_t)lo.x, (half_t)lo.y, (half_t)lo.z, (half_t)lo.w, (half_t)hi.x, (half_t)hi.y, (half_t)hi.z, (half_t)hi.w};
+        }
+        // V^T: a lane holds tokens 4 l4 .. + 3 of 16-token group 8 g + i for V dim d, i.e. positions {0, 8, 4, 12}[l4] .. + 3 of the group (vt_pos): lanes l and l + 32
+        // (l4 and l4 + 2) hold the two halves of one 16-byte chunk.  One v_permlane32_swap per register over a PAIR of groups gives the lower half-wave the whole
+        // chunk of the even group and the upper half-wave that of the odd one: a 16-byte write per lane and pair.
+#pragma unroll
+        for (int ip = 0; ip < 2; ++ip) {
+          half4_t hv[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int ii = ip * 2 + e, i = ih * 4 + ii;
+            hv[e] = (half4_t){(half_t)fma_v(r0[ii].x, acc[i][2][0], fma_v(r0[ii].y, uv_, vv_)), (half_t)fma_v(r0[ii].z, acc[i][2][1], fma_v(r0[ii].w, uv_, vv_)),
+                              (half_t)fma_v(r1[ii].x, acc[i][2][2], fma_v(r1[ii].y, uv_, vv_)), (half_t)fma_v(r1[ii].z, acc[i][2][3], fma_v(r1[ii].w, uv_, vv_))};
+          }
+          typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+          const u32x2 ea = __builtin_bit_cast(u32x2, hv[0]), eb = __builtin_bit_cast(u32x2, hv[1]);
+          const auto s0 = __builtin_amdgcn_permlane32_swap(ea.x, eb.x, false, false);  // [0]: (even group: own | odd group: lane - 32's), [1]: (even: lane + 32's | odd: own)
+          const auto s1 = __builtin_amdgcn_permlane32_swap(ea.y, eb.y, false, false);
+          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+          const u32x4 chunk = {s0[0], s1[0], s0[1], s1[1]};  // positions 0-3 (tokens 0-3 / 4-7 of the group), then 4-7 (tokens 8-11 / 12-15)
+          const int G2 = 8 * g + ih * 4 + ip * 2 + (l4 >> 1);  // the group this lane writes
+#ifdef LFM_MEASURE
+          if (!(dbg & 262144))
+#endif
+            *(u32x4*)(Vs + d * 512 + (((2 * G2 + (l4 & 1)) ^ (d & 15)) << 4)) = chunk;
         }
       }
     }

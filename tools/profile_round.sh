@@ -23,7 +23,7 @@ pmc() { # tag counters
 }
 pmc mfma "$C0"; pmc sq "$C1"; pmc lds "$C2"; pmc fetch "FETCH_SIZE"; pmc write "WRITE_SIZE"
 cd $R
-for k in EpiModGeluF16 EpiQKVMod EpiGateResidMod dit_attention; do python tools/pmc_parse.py $O $k; done > $O/pmc_summary.txt 2>&1
+for k in EpiModGeluF16 EpiQKVMod EpiGateResidMod dit_attention qkv_attention_kernel; do python tools/pmc_parse.py $O $k; done > $O/pmc_summary.txt 2>&1
 python - "$O" <<'PY'
 import json, sys
 # FETCH_SIZE / WRITE_SIZE (KiB per launch, mean over the launches after the first) of the folded fc1 GEMM -> the tracked file bench.py reads `traffic` from
