@@ -25,8 +25,8 @@
 // every wave holds its Q fragments (the hand-over puts Q into the ring's first half and K / V^T into the second, so the first half is free during the key loop),
 // and the two pieces that land in the second half right behind the key loop: an item starts its K loop on operands that are already there.
 // VMEM bookkeeping (vmcnt counts loads, LDS-DMAs and stores alike and retires in issue order, as in attention_stream_kernel.h): per wave and item, in issue
-// order, [6 row-statistic loads (waves 0-3)] [6 column-constant loads] A0(0) A0(0) B0(0) B0(0) B1(0) A1(0) A1(0) | key loop | 4 output stores | A0(1) A0(1) B0(1)
-// B0(1): the K loop may start once B1(0) has landed = all but the newest 10 (the first item of a workgroup: 6, there are no stores in between).
+// order, inside the key loop {column-constant and (waves 0-3) row-statistic loads interleaved with A0(0) A0(0) B0(0) B0(0) B1(0)} A1(0) A1(0), then 4 output stores,
+// A0(1) A0(1) B0(1) B0(1): the K loop may start once B1(0) has landed = all but the newest 10 (the first item of a workgroup: 6, there are no stores in between).
 #pragma once
 #include "attention_kernel.h"
 #include "gemm256h_kernel.h"
@@ -378,31 +378,61 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(const half_t* __rest
     half8_t qf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const half8_t*)(Qs + (wave * 32 + l31) * 128 + (((ks * 2 + hsel) ^ akey) << 4));
-    // the workgroup's next item: once every wave holds its Q fragments the first ring half is free -- request its row statistics, column constants and first
-    // four operand pieces now, under the key loop
+    // the workgroup's next item: once every wave holds its Q fragments the first ring half is free -- its first four operand pieces (seven LDS-DMAs), its row
+    // statistics and column constants are requested under the key loop, one group per half key block: a VMEM issue stalls the wave ~110 cycles
+    // (tools/ubench/ldsdma_rate.hip), which the SIMD's other wave can use inside the key loop and nobody can in front of it.  Order (the counted wait at the loop
+    // top relies on it): every plain load goes out BEFORE the fifth DMA (piece B1(0)).
     const int nitem = item + (int)gridDim.x;
     const bool has_next = nitem < items;
     int ntile_m = 0, nhead = 0;
+    long nuvh = 0;
+    const float* nrow_part = nullptr;
+    int nrow_m = 0;
     if (has_next) {
       g256_tile_order(nitem, items, ep.heads, dbg, ntile_m, nhead);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       G256_BARRIER();
       set_item(ntile_m * G256_BM, nhead);
-      rsr = g256h_rowstat_load(ep, ntile_m * G256_BM, M);
-      load_consts(ntile_m, nhead);
-      __builtin_amdgcn_sched_barrier(0);
+      nuvh = (long)ntile_m * ep.uv_stride + nhead * 64;
+      nrow_m = ntile_m * G256_BM + (int)threadIdx.x;
+      nrow_part = ep.st.part + (long)nrow_m * ep.st.tiles_p * 2;
     }
-    // its seven LDS-DMAs go out one per half key block: an issue stalls the wave ~110 cycles (tools/ubench/ldsdma_rate.hip), which the SIMD's other wave can use
-    // inside the key loop and nobody can in front of it
-    auto next_dma = [&](int idx) {
+    auto next_req = [&](int idx) {
       if (!has_next) return;
-      if (idx == 0) glds16_buf(rsa, avoff[0][0], 0u, smem + G256Q_SLOT_A0 + dma_off);
-      else if (idx == 1) glds16_buf(rsa, avoff[0][1], 0u, smem + G256Q_SLOT_A0 + 8192 + dma_off);
-      else if (idx == 2) glds16_buf(rsw, wvoff0[0], 0u, smem + G256Q_SLOT_B0 + dma_off);
-      else if (idx == 3) glds16_buf(rsw, wvoff0[1], 0u, smem + G256Q_SLOT_B0 + 8192 + dma_off);
-      else if (idx == 4) glds16_buf(rsw, wvoff1, 0u, smem + G256Q_SLOT_B1 + dma_off);
-      else if (idx == 5) glds16_buf(rsa, avoff[1][0], 0u, smem + G256Q_SLOT_A1 + dma_off);
+      __builtin_amdgcn_sched_barrier(0);
+      const long uvo = nuvh + (wn >> 1) * D + (wn & 1) * 32 + 8 * l4;
+      const bool rows = threadIdx.x < 256;  // waves 0-3: a row's statistics each (g256h_rowstat_load, spread)
+      auto part = [&](int t) { return rows && t < ep.st.tiles_p ? ((const f32x2*)nrow_part)[t] : (f32x2){0.f, 0.f}; };
+      if (idx == 0) {
+        uq = *(const f32x4*)(ep.u + uvo);
+        rsr.p[0] = part(0);
+        __builtin_amdgcn_sched_barrier(0);
+        glds16_buf(rsa, avoff[0][0], 0u, smem + G256Q_SLOT_A0 + dma_off);
+      } else if (idx == 1) {
+        vq = *(const f32x4*)(ep.v + uvo);
+        rsr.p[1] = part(1);
+        __builtin_amdgcn_sched_barrier(0);
+        glds16_buf(rsa, avoff[0][1], 0u, smem + G256Q_SLOT_A0 + 8192 + dma_off);
+      } else if (idx == 2) {
+        uk = *(const f32x4*)(ep.u + uvo + 4);
+        rsr.p[2] = part(2);
+        __builtin_amdgcn_sched_barrier(0);
+        glds16_buf(rsw, wvoff0[0], 0u, smem + G256Q_SLOT_B0 + dma_off);
+      } else if (idx == 3) {
+        vk = *(const f32x4*)(ep.v + uvo + 4);
+        uv_ = ep.u[nuvh + 2 * D + wn * 16 + l15];
+        rsr.p[3] = part(3);
+        rsr.p[4] = part(4);
+        __builtin_amdgcn_sched_barrier(0);
+        glds16_buf(rsw, wvoff0[1], 0u, smem + G256Q_SLOT_B0 + 8192 + dma_off);
+      } else if (idx == 4) {
+        vv_ = ep.v[nuvh + 2 * D + wn * 16 + l15];
+        if (rows) rsr.c = ep.st.cen_in[nrow_m];
+        __builtin_amdgcn_sched_barrier(0);
+        glds16_buf(rsw, wvoff1, 0u, smem + G256Q_SLOT_B1 + dma_off);
+      } else if (idx == 5) glds16_buf(rsa, avoff[1][0], 0u, smem + G256Q_SLOT_A1 + dma_off);
       else if (idx == 6) glds16_buf(rsa, avoff[1][1], 0u, smem + G256Q_SLOT_A1 + 8192 + dma_off);
+      __builtin_amdgcn_sched_barrier(0);
     };
     stamp(4);
     f32x16 Oa[2];
@@ -442,17 +472,17 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(const half_t* __rest
 #pragma unroll
       for (int kb = 0; kb < 8; kb += 2) {
         qk(Sb, kb + 1);
-        next_dma(kb);
+        next_req(kb);
         softmax_pv(Sa, kb);
         if (kb + 2 < 8) qk(Sa, kb + 2);
-        next_dma(kb + 1);
+        next_req(kb + 1);
         softmax_pv(Sb, kb + 1);
       }
     }
 #ifdef LFM_MEASURE
     else {
 #pragma unroll
-      for (int i = 0; i < 7; ++i) next_dma(i);
+      for (int i = 0; i < 7; ++i) next_req(i);
     }
 #endif
     stamp(5);

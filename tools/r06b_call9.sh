@@ -1,6 +1,6 @@
 R=$GRAFT_REPO_ROOT
-cd $R; mkdir -p gpurun_out/f9
-timeout 900 python -m pytest tests/test_gpu_dit.py -x -q -k "fused_qkv" 2>&1 | tail -5 > gpurun_out/f9/test.log; cat gpurun_out/f9/test.log
-timeout 600 python tools/fused_qkv_ab.py DiT-L/2 64 20 > gpurun_out/f9/ab_L.log 2>&1; cat gpurun_out/f9/ab_L.log
-LFM_HIP_LIBRARY=$R/tools/_var/measure/liblfm_hip.so timeout 300 python tools/fused_qkv_trace.py > gpurun_out/f9/trace.log 2>&1
-sed -n 9,16p gpurun_out/f9/trace.log
+cd $R; mkdir -p gpurun_out/f10
+timeout 900 python -m pytest tests/test_gpu_dit.py -x -q -k "fused_qkv" 2>&1 | tail -5 > gpurun_out/f10/test.log; cat gpurun_out/f10/test.log
+timeout 600 python tools/fused_qkv_ab.py DiT-L/2 64 20 > gpurun_out/f10/ab_L.log 2>&1; cat gpurun_out/f10/ab_L.log
+LFM_HIP_LIBRARY=$R/tools/_var/measure/liblfm_hip.so timeout 300 python tools/fused_qkv_trace.py > gpurun_out/f10/trace.log 2>&1
+sed -n 9,16p gpurun_out/f10/trace.log
