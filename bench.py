@@ -367,7 +367,7 @@ def roofline_dit(model, lat, rows, dev):
     blk_s = sum(blk) / len(blk) * 1e-3 / model.depth
     block = {"bound": "mfma", "block_us": blk_s * 1e6, "algorithmic_flop": blk_flop, "achieved": blk_flop / blk_s / 1e12, "peak": MFMA_PEAK_TFLOPS,
              "unit": "TFLOP/s", "frac": blk_flop / blk_s / 1e12 / MFMA_PEAK_TFLOPS, "evaluations_timed": len(blk),
-             "what": "one DiTBlock (qkv GEMM, attention, proj GEMM, fc1 GEMM, fc2 GEMM with their fused epilogues) = the eager block loop of an evaluation "
+             "what": "one DiTBlock (qkv projection + attention core as ONE kernel where the folded path applies, proj GEMM, fc1 GEMM, fc2 GEMM with their fused epilogues) = the eager block loop of an evaluation "
                      "/ depth, HIP events on the launching stream, one batch in flight"}
     blk2 = block_time_two_lanes(model, lat, rows, dev)
     block["two_lanes"] = {"block_us_upper_bound": blk2 * 1e6, "achieved": blk_flop / blk2 / 1e12, "frac": blk_flop / blk2 / 1e12 / MFMA_PEAK_TFLOPS,

@@ -354,6 +354,8 @@ def test_library_options_are_host_state_only():
         hip.set_option(99, 1)
     hip.set_option(hip.OPT_FOLD_LN, 0)
     hip.set_option(hip.OPT_FOLD_LN, 1)
+    hip.set_option(hip.OPT_FUSED_QKV_ATTENTION, 0)  # QKV projection + attention as one kernel (default on)
+    hip.set_option(hip.OPT_FUSED_QKV_ATTENTION, 1)
 
 
 def test_conv_split_k_plan_for_the_small_maps():
