@@ -1431,7 +1431,7 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
   const bool prof_blk = prof_ok && g_prof_blk_count < LFM_PROF_BLK_MAX;
   if (prof_blk) (void)hipEventRecord(g_prof_blk_ev[2 * g_prof_blk_count], st);
   // QKV projection + attention in one kernel (qkv_attention_kernel.h): one (image, head) per workgroup -- images of exactly one 256-token tile, head_dim 64
-  const bool fused = fold && g_opt_fused_qkv && !w6 && T == 256 && D == s->heads * 64;
+  const bool fused = fold && g_opt_fused_qkv && !w6 && T == 256 && D == s->heads * 64 && (long)M * D < (1L << 31) && (long)3 * D * D < (1L << 31);  // 32-bit LDS-DMA byte offsets / 2
   if (fold) {
     for (int i = 0; i < s->depth; ++i) {
       const float* mod = ws.mod + (long)i * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp

@@ -535,7 +535,7 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(const half_t* __rest
 static inline int launch_qkv_attention(const half_t* A, long lda, const half_t* W, long ldw, int M, int D, int heads, int K, const QkvAttnArgs& ep,
                                        hipStream_t stream) {
   if (M <= 0 || (M % G256_BM) != 0 || heads <= 0 || D != heads * 64 || K < 2 * G256Q_BK || (K % G256Q_BK) != 0) return LFM_ERR_SHAPE;
-  if ((long)M * lda >= (1L << 30) || (long)3 * D * ldw >= (1L << 30)) return LFM_ERR_SHAPE;  // 32-bit byte offsets of the buffer-addressed LDS-DMAs
+  if ((long)M * lda >= (1L << 31) || (long)3 * D * ldw >= (1L << 31)) return LFM_ERR_SHAPE;  // unsigned 32-bit byte offsets of the buffer-addressed LDS-DMAs
   if ((lda % 8) != 0 || (ldw % 8) != 0 || ((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)ep.O & 15) || ((uintptr_t)ep.u & 15) || ((uintptr_t)ep.v & 15) ||
       (ep.uv_stride % 4) != 0)
     return LFM_ERR_ALIGN;
