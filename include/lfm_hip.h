@@ -118,6 +118,13 @@ size_t lfm_dit_workspace_bytes(const lfm_dit_shape* shape, int max_batch);
 int lfm_dit_forward(const lfm_dit_shape* shape, const lfm_dit_weights* w, void* workspace, size_t workspace_bytes,
                     const lfm_dit_call* call, lfm_stream_t stream);
 
+/* Which form of the block loop lfm_dit_forward would take for `call` if it were enqueued by the calling thread now (library defaults, per-call fields, shape and
+ * batch): *plan_out = LFM_PLAN_FOLDED_LN (adaLN LayerNorm-modulate folded into the GEMM epilogues: LFM_OPT_FOLD_LN) | LFM_PLAN_FUSED_QKV_ATTENTION (QKV projection
+ * + attention core as one kernel: LFM_OPT_FUSED_QKV_ATTENTION).  Reads call->batch, t_len, y (NULL or not), fold_ln, gemm_select; no launch; usable without a GPU. */
+#define LFM_PLAN_FOLDED_LN 1
+#define LFM_PLAN_FUSED_QKV_ATTENTION 2
+int lfm_dit_plan(const lfm_dit_shape* shape, const lfm_dit_call* call, int* plan_out);
+
 /* Per-grid conditioning tables for the unconditional models (test_args/{celeb256,ffhq,bed,church}_dit.txt: num_classes 1, no labels, scalar t -- the
  * closure `denoiser` of test_flow_latent.py:55-59 calls model(t, x) with the solver's grid time): c = t_embedder(t), the adaLN modulation of every block and
  * of the final layer (models/DiT.py:128, 170, 259-262) and the u / v rows of the folded LayerNorm path are pure functions of t, so a fixed-grid solver

@@ -1338,6 +1338,39 @@ extern "C" int lfm_dit_cond_table_build(const lfm_dit_shape* s, const lfm_dit_we
   return LFM_OK;
 }
 
+// Which form of the block loop an evaluation takes (read on the calling thread, inside the call's scope): the folded LayerNorm-modulate path, its GEMMs on the
+// one-wave-per-SIMD kernel, the QKV projection + attention core as one kernel.  Shared by lfm_dit_forward and lfm_dit_plan.
+struct DitPlan {
+  bool fold, w6, fused;
+};
+static DitPlan dit_plan(const lfm_dit_shape* s, int B, int rows) {
+  const int D = s->hidden, H = s->mlp_hidden, grid = s->res / s->patch, T = grid * grid, M = B * T;
+  const int tiles_p = D / 256;
+  DitPlan p;
+  // folded LayerNorm-modulate: only where its preconditions hold -- whole 256-row tiles of ONE image each (or one shared modulation row), row partials in D / 256
+  // slots, all four GEMMs chip-filling on the 16x16x32 kernel
+  p.fold = g_opt_fold_ln && (D % 256 == 0) && (M % 256 == 0) && (rows == 1 || T % 256 == 0) && (long)(M / 256) * tiles_p >= 192 &&
+           (g_gemm_sel == 0 || g_gemm_sel == 6) && (H % 64 == 0) && s->depth >= 1;
+  p.w6 = g_gemm_sel == 6 || (g_gemm_sel == 0 && g_opt_v6);  // the block GEMMs of the folded path on the one-wave-per-SIMD kernel
+  // QKV projection + attention in one kernel (qkv_attention_kernel.h): one (image, head) per work item -- images of exactly one 256-token tile, head_dim 64,
+  // operands inside the unsigned 32-bit byte offsets of its LDS-DMAs
+  p.fused = p.fold && g_opt_fused_qkv && !p.w6 && T == 256 && D == s->heads * 64 && (long)M * D < (1L << 31) && (long)3 * D * D < (1L << 31);
+  return p;
+}
+// The plan of an evaluation without launching it (tests; a caller that sizes its expectations): *plan_out = LFM_PLAN_* bits.  Same scope code as the forward.
+extern "C" int lfm_dit_plan(const lfm_dit_shape* s, const lfm_dit_call* c, int* plan_out) {
+  int rc = check_shape(s);
+  if (rc) return rc;
+  if (!c || !plan_out) return LFM_ERR_ARG;
+  const int B = c->batch;
+  if (B <= 0 || (c->t_len != 1 && c->t_len != B)) return LFM_ERR_SHAPE;
+  CallScope scope;
+  if ((rc = call_scope_enter(c)) != LFM_OK) return rc;
+  const DitPlan p = dit_plan(s, B, (c->t_len == 1 && !c->y) ? 1 : B);
+  *plan_out = (p.fold ? LFM_PLAN_FOLDED_LN : 0) | (p.fused ? LFM_PLAN_FUSED_QKV_ATTENTION : 0);
+  return LFM_OK;
+}
+
 extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w, void* workspace, size_t workspace_bytes,
                                const lfm_dit_call* c, lfm_stream_t stream) {
   int rc = check_shape(s);
@@ -1368,9 +1401,8 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
   const int KK = s->in_ch * s->patch * s->patch;
   // folded LayerNorm-modulate: decided here because the */2 patch embedding can already play the first producer (see below)
   const int tiles_p = D / 256;
-  const bool fold = g_opt_fold_ln && (D % 256 == 0) && (M % 256 == 0) && (rows == 1 || T % 256 == 0) && (long)(M / 256) * tiles_p >= 192 &&
-                    (g_gemm_sel == 0 || g_gemm_sel == 6) && (H % 64 == 0) && s->depth >= 1;
-  const bool w6 = g_gemm_sel == 6 || (g_gemm_sel == 0 && g_opt_v6);  // the block GEMMs of the folded path on the one-wave-per-SIMD kernel
+  const DitPlan plan = dit_plan(s, B, rows);
+  const bool fold = plan.fold, w6 = plan.w6;
   const bool pe_mfma = s->patch == 2 && s->in_ch == 4 && (D % 256 == 0) && D <= 1280 && (s->res % 2 == 0) && !(g_gemm_dbg & 2097152);  // flag: round-1 kernel
   if (tab) {
     rc = dit_cond_select(s, ws, (const float*)c->cond_table, c->cond_step, c->cond_offset, c->cond_rows, st);
@@ -1430,8 +1462,7 @@ extern "C" int lfm_dit_forward(const lfm_dit_shape* s, const lfm_dit_weights* w,
 #endif
   const bool prof_blk = prof_ok && g_prof_blk_count < LFM_PROF_BLK_MAX;
   if (prof_blk) (void)hipEventRecord(g_prof_blk_ev[2 * g_prof_blk_count], st);
-  // QKV projection + attention in one kernel (qkv_attention_kernel.h): one (image, head) per workgroup -- images of exactly one 256-token tile, head_dim 64
-  const bool fused = fold && g_opt_fused_qkv && !w6 && T == 256 && D == s->heads * 64 && (long)M * D < (1L << 31) && (long)3 * D * D < (1L << 31);  // 32-bit LDS-DMA byte offsets / 2
+  const bool fused = plan.fused;  // QKV projection + attention in one kernel (qkv_attention_kernel.h)
   if (fold) {
     for (int i = 0; i < s->depth; ++i) {
       const float* mod = ws.mod + (long)i * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp

@@ -109,6 +109,8 @@ def lib():
     L.lfm_set_option.argtypes = [C.c_int, C.c_int]
     L.lfm_dit_call_settings.restype = C.c_int
     L.lfm_dit_call_settings.argtypes = [C.POINTER(DitCall), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.lfm_dit_plan.restype = C.c_int
+    L.lfm_dit_plan.argtypes = [C.POINTER(DitShape), C.POINTER(DitCall), C.POINTER(C.c_int)]
     L.lfm_dit_attention_hd.restype = C.c_int
     L.lfm_dit_attention_hd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.lfm_grid_advance.restype = C.c_int
@@ -270,6 +272,19 @@ def effective_clock_mhz(device=None, iters=20000):
     # 2 560 000 MFMAs per SIMD in a 21.6 ms and in a 23.7 ms run) -- 8.13 ticks per 16-pass MFMA, i.e. one s_memtime tick = TWO shader cycles here; the
     # issue-bound estimate 16 cycles x MFMAs / wall time agrees within 2 %.
     return 2.0 * float(ticks.max()) / (ms * 1e3)
+
+
+PLAN_FOLDED_LN, PLAN_FUSED_QKV_ATTENTION = 1, 2  # lfm_dit_plan bits
+
+
+def dit_plan(shape, batch, t_len=1, labels=False, fold_ln=0, gemm_select=0):
+    """LFM_PLAN_* bits of the block loop lfm_dit_forward would run for this shape / batch under the current library options (no launch, no GPU needed)."""
+    call = DitCall()
+    call.batch, call.t_len, call.y = int(batch), int(t_len), (1 if labels else None)  # y: only NULL-ness is read
+    call.fold_ln, call.gemm_select = fold_ln, gemm_select
+    plan = C.c_int(-1)
+    check(lib().lfm_dit_plan(C.byref(shape), C.byref(call), C.byref(plan)), "lfm_dit_plan")
+    return plan.value
 
 
 def set_option(key, value):

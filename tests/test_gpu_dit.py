@@ -646,6 +646,8 @@ def test_fused_qkv_attention_matches_two_kernels(dev, name, batch, labels):
     y = torch.randint(0, 1001, (batch,), generator=g) if labels else None
     t = torch.linspace(0.05, 0.95, batch) if labels else torch.tensor(0.4)
     xd, td, yd = x.to(dev), t.to(dev), (y.to(dev) if labels else None)
+    plan = hip.dit_plan(m.shape_struct(), batch, t_len=batch if labels else 1, labels=labels)
+    assert plan == hip.PLAN_FOLDED_LN | hip.PLAN_FUSED_QKV_ATTENTION, "the fused kernel would not run for this case: the comparison below would be vacuous"
     try:
         hip.set_option(hip.OPT_FUSED_QKV_ATTENTION, 0)
         two = m(td, xd, yd).clone()

@@ -344,6 +344,33 @@ def test_unbuilt_dit_shapes_are_refused_at_construction():
     DiT_models["DiT-S/8"](img_resolution=64, in_channels=4, num_classes=1, label_dropout=0.0)        # 64 tokens, K = 256: built
 
 
+def test_dit_plan_says_which_block_loop_runs():
+    """lfm_dit_plan (no launch): the folded LayerNorm path and the fused QKV + attention kernel are taken exactly where their preconditions hold -- residual width a
+    multiple of 256, whole 256-row tiles, a chip-filling batch; 256 tokens per image and head_dim 64 for the fused kernel -- and follow the library options and
+    the per-call fold switch."""
+    from lfm_amd import hip
+
+    def shape(depth, hidden, heads, patch=2, res=32):
+        return hip.DitShape(depth, hidden, heads, patch, 4, res, 4 * hidden, 1)
+
+    L2, B2, XL2, S2, L4 = shape(24, 1024, 16), shape(12, 768, 12), shape(28, 1152, 16), shape(12, 384, 6), shape(24, 1024, 16, patch=4)
+    both = hip.PLAN_FOLDED_LN | hip.PLAN_FUSED_QKV_ATTENTION
+    assert hip.dit_plan(L2, 64) == both and hip.dit_plan(L2, 48) == both
+    assert hip.dit_plan(L2, 47) == 0  # 188 tiles: not chip-filling
+    assert hip.dit_plan(B2, 64, t_len=64, labels=True) == both and hip.dit_plan(B2, 512) == both
+    assert hip.dit_plan(XL2, 64) == 0 and hip.dit_plan(S2, 256) == 0  # 1152 / 384 are not multiples of 256
+    assert hip.dit_plan(L4, 256) == hip.PLAN_FOLDED_LN  # 64 tokens per image, one shared conditioning row: folded, but an image is not one 256-row tile
+    assert hip.dit_plan(L4, 256, t_len=256, labels=True) == 0  # per-image rows need whole tiles of ONE image
+    assert hip.dit_plan(L2, 64, fold_ln=hip.CALL_OFF) == 0
+    hip.set_option(hip.OPT_FUSED_QKV_ATTENTION, 0)
+    try:
+        assert hip.dit_plan(L2, 64) == hip.PLAN_FOLDED_LN
+    finally:
+        hip.set_option(hip.OPT_FUSED_QKV_ATTENTION, 1)
+    assert hip.dit_plan(L2, 64, gemm_select=hip.call_gemm_select(6)) == hip.PLAN_FOLDED_LN  # the one-wave-per-SIMD kernels keep the two-kernel form
+    assert hip.dit_plan(L2, 64, gemm_select=hip.call_gemm_select(1)) == 0  # a forced 128x128 kernel: separate LayerNorm launches
+
+
 def test_library_options_are_host_state_only():
     """lfm_set_option touches no device: unknown keys are refused, the folded-LayerNorm switch toggles (default on)."""
     from lfm_amd import hip
