@@ -14,10 +14,11 @@
 // launch_gemm256h_tn<EpiQKVMod> + attention_launch (tests/test_gpu_dit.py::test_fused_qkv_attention_matches_two_kernels).
 //
 // K loop = gemm256h_kernel.h's (quadrant phases, piece-granular LDS-DMA ring, ping-pong wave groups, one barrier per phase, counted waits) with a 192-column
-// tile: wave (g, wn) owns rows g*128.. x the 48 columns {Q dims 16 wn.., K dims 16 wn.., V dims 16 wn..} of the head (the W rows are gathered by the DMA source
-// addresses), i.e. accumulator tiles j = 0 (Q), 1 (K), 2 (V).  Piece B0 = the Q and K rows (128 rows, 16 KiB, as before), piece B1 = the V rows (64 rows,
-// 8 KiB: ONE LDS-DMA per thread), so the phases are A0xB0 (16 MFMAs) | A0xB1 (8) | A1xB1 (8) | A1xB0 (16) and the counted vmcnt waits 5 5 5 6 instead of
-// 6 6 6 6.  The V tile is issued with the operands swapped (a lane then owns FOUR CONSECUTIVE TOKENS of one head dim = one 8-byte write into a V^T row).
+// tile: wave (g, wn) owns rows g*128.. x 48 columns of the head, gathered by the DMA source addresses of the W rows -- accumulator tiles j = 0, 1: 32 dims of
+// Q (waves wn = 0, 1) or of K (wn = 2, 3), interleaved in fours so that a lane's two tiles are EIGHT CONSECUTIVE dims of a row (one 16-byte write in the
+// hand-over); tile j = 2: V dims 16 wn .. + 15.  Piece B0 = the Q and K rows (128 rows, 16 KiB, as before), piece B1 = the V rows (64 rows, 8 KiB: ONE LDS-DMA
+// per thread), so the phases are A0xB0 (16 MFMAs) | A0xB1 (8) | A1xB1 (8) | A1xB0 (16) and the counted vmcnt waits 5 5 5 6 instead of 6 6 6 6.  The V tile is
+// issued with the operands swapped (a lane then owns FOUR CONSECUTIVE TOKENS of one head dim: half a 16-byte chunk of a V^T row, the other half in lane +- 32).
 //
 // PERSISTENT workgroups (one per CU, items strided over the grid).  Measured with one workgroup per item (profiles/r06_fused_qkv_attention.txt): of 122 us the
 // K loop beyond its first tile takes 74, the key loop 32 and everything else 28 = 7 us per item -- workgroup dispatch, the row statistics, the first LDS-DMA round
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(const half_t* __rest
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
     a_addr[ks] = (g * 64 + l15) * 128 + (((ks * 4 + l4) ^ rkey) << 4);   // + i4 * 2048
-    w_addr[ks] = (wn * 32 + l15) * 128 + (((ks * 4 + l4) ^ rkey) << 4);  // + j * 2048 (j = 0: Q, 1: K)
+    w_addr[ks] = (wn * 32 + l15) * 128 + (((ks * 4 + l4) ^ rkey) << 4);  // + j * 2048 (tiles j = 0, 1)
     w1_addr[ks] = (wn * 16 + l15) * 128 + (((ks * 4 + l4) ^ rkey) << 4);
   }
   half8_t af[4][2], wf[3][2];
@@ -201,9 +202,9 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(const half_t* __rest
           }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (VT) {  // operands swapped: acc[i][2][r] = C[m = 16 i + 4 l4 + r][V dim l15]
+        if constexpr (VT) {  // operands swapped: acc[i][2][r] = C[m = 16 i + 4 l4 + r][V dim 16 wn + l15]
           acc[I0 + i4][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i4][ks], wf[2][ks], acc[I0 + i4][2], 0, 0, 0);
-        } else {  // acc[i][j][r] = C[m = 16 i + l15][dim 4 l4 + r]
+        } else {  // acc[i][j][r] = C[m = 16 i + l15][dim 32 (wn & 1) + 8 l4 + 4 j + r of Q / K]
 #pragma unroll
           for (int j2 = 0; j2 < 2; ++j2) acc[I0 + i4][j2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j2][ks], af[i4][ks], acc[I0 + i4][j2], 0, 0, 0);
         }
@@ -263,8 +264,8 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(const half_t* __rest
     }
     if (t < nk) tile(g256q_ic<0>{}, t);
   };
-  // LDS in the attention phase: Q [256][64] in the first ring half (its A0 / B0 slots), K [256][64] and V^T [64][256] in the second half; above the ring the
-  // (a, b) rows and 1 KiB of output staging per wave.  Q, K: 128-byte rows, chunk c of row r at c ^ ((r >> 1) & 7); V^T: 512-byte rows, tokens of a 16-group in
+  // LDS in the attention phase: Q [256][64] in the first ring half (its A0 / B0 slots), K [256][64] and V^T [64][256] in the second half; above the ring 4 KiB
+  // of output staging per wave, whose first 2 KiB hold the (a, b) rows of the current item until its hand-over.  Q, K: 128-byte rows, chunk c of row r at c ^ ((r >> 1) & 7); V^T: 512-byte rows, tokens of a 16-group in
   // the vt_pos order, chunk c of row d at c ^ (d & 15) -- the images dit_attention_kernel<256, 1, 64> stages from HBM.
   char* const Qs = smem;
   char* const Ks = smem + G256Q_BUF_BYTES;
