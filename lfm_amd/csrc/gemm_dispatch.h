@@ -22,7 +22,8 @@ static inline int gemm_auto_choice(int M, int N, int K, int batch = 1) {
   if ((K % G256N_BK) == 0) {
     const long tiles128 = (long)cdiv(M, 256) * cdiv(N, G256N_BN) * batch;
     const bool narrow = N > 64 && N < 256 && tiles128 >= 256;
-    if (sel == 4 || (sel == 0 && (narrow || (big && lfm_gemm_prefers_v4(M, N, K))))) return 4;
+    const bool mid = !big && N >= 256 && tiles128 >= 192;  // see launch_gemm_auto
+    if (sel == 4 || (sel == 0 && (narrow || mid || (big && lfm_gemm_prefers_v4(M, N, K))))) return 4;
   }
   if (sel == 6 && (K % G256Q_BK) == 0) return 6;
   if ((sel == 5 || (sel == 0 && big)) && (K % G256Q_BK) == 0) return 5;
@@ -38,7 +39,11 @@ static inline int launch_gemm_auto(const ASrc& asrc, const half_t* W, long ldw, 
   if ((K % G256N_BK) == 0) {
     const long tiles128 = (long)cdiv(M, 256) * cdiv(N, G256N_BN) * batch;
     const bool narrow = N > 64 && N < 256 && tiles128 >= 256;  // e.g. the 128-channel convolutions at 256^2 / 512^2
-    if (sel == 4 || (sel == 0 && (narrow || (big && lfm_gemm_prefers_v4(M, N, K)))))
+    // Round 6: problems too small for the 256x256 tiling (< 192 such tiles) but with >= 192 tiles of 256x128 -- the UNets' 1x1 convolutions / attention
+    // projections at 16 384 x 384 .. 512, 4096 x 1536, 32 768 x 256 -- ran on the 128x128 kernel: 14.4 vs 17.2, 18.0 vs 20.2, 16.8 vs 19.3, 18.6 vs 20.4 us here
+    // (tools/linear_shapes_probe.py, profiles/r06_linear_shapes_probe.txt; below 192 tiles the 128x128 kernel wins: 4096 x 512 11.0 vs 13.8 us).  Bit-identical.
+    const bool mid = !big && N >= 256 && tiles128 >= 192;
+    if (sel == 4 || (sel == 0 && (narrow || mid || (big && lfm_gemm_prefers_v4(M, N, K)))))
       return launch_gemm256n_tn(asrc, W, ldw, M, N, K, epi, stream, batch, bsA, bsW, bsC);
   }
   // the 256x256 kernels address row-major operands through buffer resources (unsigned 32-bit byte offsets: operands below 2^31 elements, like the 32-bit row offsets of every kernel)
