@@ -22,9 +22,9 @@
 //
 // PERSISTENT workgroups (one per CU, items strided over the grid).  Measured with one workgroup per item (profiles/r06_fused_qkv_attention.txt): of 122 us the
 // K loop beyond its first tile takes 74, the key loop 32 and everything else 28 = 7 us per item -- workgroup dispatch, the row statistics, the first LDS-DMA round
-// trip, one K-tile, the hand-over, the stores.  Here the NEXT item's first four operand pieces, its row statistics and column constants are requested as soon as
-// every wave holds its Q fragments (the hand-over puts Q into the ring's first half and K / V^T into the second, so the first half is free during the key loop),
-// and the two pieces that land in the second half right behind the key loop: an item starts its K loop on operands that are already there.
+// trip, one K-tile, the hand-over, the stores.  Here the NEXT item's first four operand pieces, its row statistics and column constants are requested inside
+// the key loop (the hand-over puts K / V^T into the ring's second half and Q above the ring, so the first half is free from the K loop's last barrier on), and
+// the two pieces that land in the second half right behind the key loop: an item starts its K loop on operands that are already there.
 // VMEM bookkeeping (vmcnt counts loads, LDS-DMAs and stores alike and retires in issue order, as in attention_stream_kernel.h): per wave and item, in issue
 // order, inside the key loop {column-constant and (waves 0-3) row-statistic loads interleaved with A0(0) A0(0) B0(0) B0(0) B1(0)} A1(0) A1(0), then 4 output stores,
 // A0(1) A0(1) B0(1) B0(1): the K loop may start once B1(0) has landed = all but the newest 10 (the first item of a workgroup: 6, there are no stores in between).
@@ -44,7 +44,7 @@ struct QkvAttnArgs {
   int m0;
 };
 
-#define QKVA_LDS_BYTES (G256Q_LDS_BYTES + 8 * 4096)  // operand ring | output staging (4 KiB per wave), whose first 2 KiB hold the (a, b) of the 256 rows until the hand-over
+#define QKVA_LDS_BYTES (G256Q_LDS_BYTES + 8 * 4096)  // operand ring | Q rows = output staging (4 KiB per wave)
 
 __global__ __launch_bounds__(512) void qkv_attention_kernel(const half_t* __restrict__ A, long lda, const half_t* __restrict__ W, long ldw, int M, int K,
                                                             QkvAttnArgs ep, int items, int dbg) {
@@ -232,7 +232,25 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(const half_t* __rest
   issue_a(1, 0, smem + G256Q_SLOT_A1);
   issue_a(0, 1, smem + G256Q_BUF_BYTES + G256Q_SLOT_A0);
   issue_b0(1, smem + G256Q_BUF_BYTES + G256Q_SLOT_B0);
-  g256h_rowstat_finish(ep, rsr, smem, m0, M, head);
+  // (a, b) = (rstd, -rstd (mu - c)) of an item's 256 rows (g256h_rowstat_finish with its own destination): the upper 8 KiB of the first ring half's B1 slot, which
+  // no LDS-DMA ever touches (piece B1 is 8 KiB of a 16-KiB slot) -- written for item k + 1 at the end of item k, read at item k + 1's hand-over
+  float* const rs = (float*)(smem + G256Q_SLOT_B1 + 8192);
+  auto rowstat_finish = [&](const G256hRowStatRegs& r, int m0_, int head_) {
+    if (threadIdx.x < 256) {
+      float sx = 0.f, sq = 0.f;
+#pragma unroll
+      for (int t = 0; t < G256H_MAX_PARTS; ++t) {  // fixed order
+        sx += r.p[t].x;
+        sq += r.p[t].y;
+      }
+      const float mu = sx * ep.st.inv_n, dl = mu - r.c;
+      const float var = fmaxf(sq * ep.st.inv_n - dl * dl, 0.f);
+      const float rstd = rsqrtf(var + ep.st.eps);
+      *(f32x2*)(rs + 2 * threadIdx.x) = (f32x2){rstd, -rstd * dl};
+      if (head_ == 0 && m0_ + (int)threadIdx.x < M) ep.st.cen_out[m0_ + threadIdx.x] = mu;  // head 0 publishes the row means: the next producer's centring constants
+    }
+  };
+  rowstat_finish(rsr, m0, head);
   auto run = [&](auto GC) {
     constexpr int G = decltype(GC)::value;
     if constexpr (G == 0) load_part(g256q_ic<0>{}, g256q_ic<0>{}, 0, 1 < nk, 2 < nk);
@@ -264,14 +282,15 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(const half_t* __rest
     }
     if (t < nk) tile(g256q_ic<0>{}, t);
   };
-  // LDS in the attention phase: Q [256][64] in the first ring half (its A0 / B0 slots), K [256][64] and V^T [64][256] in the second half; above the ring 4 KiB
-  // of output staging per wave, whose first 2 KiB hold the (a, b) rows of the current item until its hand-over.  Q, K: 128-byte rows, chunk c of row r at c ^ ((r >> 1) & 7); V^T: 512-byte rows, tokens of a 16-group in
-  // the vt_pos order, chunk c of row d at c ^ (d & 15) -- the images dit_attention_kernel<256, 1, 64> stages from HBM.
-  char* const Qs = smem;
+  // LDS in the attention phase: K [256][64] and V^T [64][256] in the SECOND ring half, Q [256][64] above the ring -- the first ring half stays free, so the next
+  // item's first four operand pieces can be requested from the moment the K loop ends.  A wave's own 32 Q rows (4 KiB) are its output staging once it holds its Q
+  // fragments.  Q, K: 128-byte rows, chunk c of row r at c ^ ((r >> 1) & 7); V^T: 512-byte rows, tokens of a 16-group in the vt_pos order, chunk c of row d at
+  // c ^ (d & 15) -- the images dit_attention_kernel<256, 1, 64> stages from HBM.
+  char* const Qs = smem + G256Q_LDS_BYTES;
   char* const Ks = smem + G256Q_BUF_BYTES;
   char* const Vs = smem + G256Q_BUF_BYTES + 32768;
-  const float* const rs = (const float*)(smem + G256Q_LDS_BYTES);
-  char* const ob = smem + G256Q_LDS_BYTES + wave * 4096;
+  char* const ob = Qs + wave * 4096;
+
   const float scale_log2e = ep.scale_log2e;
   bool first = true;
   // (measurement builds, flag 2: s_memtime stamps of waves 0 and 4 of workgroup 0 -> att_trace[0..31] / [32..63], read with lfm_attention_trace_read; per item k, slot
@@ -379,7 +398,7 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(const half_t* __rest
     half8_t qf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const half8_t*)(Qs + (wave * 32 + l31) * 128 + (((ks * 2 + hsel) ^ akey) << 4));
-    // the workgroup's next item: once every wave holds its Q fragments the first ring half is free -- its first four operand pieces (seven LDS-DMAs), its row
+    // the workgroup's next item: the first ring half has been free since the K loop's last barrier -- its first four operand pieces (seven LDS-DMAs), its row
     // statistics and column constants are requested under the key loop, one group per half key block: a VMEM issue stalls the wave ~110 cycles
     // (tools/ubench/ldsdma_rate.hip), which the SIMD's other wave can use inside the key loop and nobody can in front of it.  Order (the counted wait at the loop
     // top relies on it): every plain load goes out BEFORE the fifth DMA (piece B1(0)).
@@ -391,8 +410,6 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(const half_t* __rest
     int nrow_m = 0;
     if (has_next) {
       g256_tile_order(nitem, items, ep.heads, dbg, ntile_m, nhead);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      G256_BARRIER();
       set_item(ntile_m * G256_BM, nhead);
       nuvh = (long)ntile_m * ep.uv_stride + nhead * 64;
       nrow_m = ntile_m * G256_BM + (int)threadIdx.x;
@@ -518,7 +535,7 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(const half_t* __rest
     // every wave is done with K / V^T and with its output staging: the next item's (a, b) rows (its statistics have long landed), and the second ring half
     // takes its A0(1) B0(1)
     G256_BARRIER();
-    g256h_rowstat_finish(ep, rsr, smem, ntile_m * G256_BM, M, nhead);
+    rowstat_finish(rsr, ntile_m * G256_BM, nhead);
     issue_a(0, 1, smem + G256Q_BUF_BYTES + G256Q_SLOT_A0);
     issue_b0(1, smem + G256Q_BUF_BYTES + G256Q_SLOT_B0);
     item = nitem;
