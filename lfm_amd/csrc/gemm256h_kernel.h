@@ -447,6 +447,8 @@ __device__ __forceinline__ void g256h_epilogue(f32x4_t (&acc)[8][4], char* smem,
 // waits for the first; the reads in between cover that wait).
 // Measured (tools/dma_opt_probe.py, profiles/r04_dma_opt_probe.txt; bit-identical results): bit 0 -0.6 .. -2.1 us on the main loops of both 256x256 kernels
 // (252 -> 218 VGPRs in this one) = the default; bit 1 +1.5 .. +3 us = rejected.
+// OPT bit 2 (round 6): the pieces' LDS-DMAs placed against the LOAD parts' fragment reads (none | B1 | A1 | A0 B0 instead of B1 | A1 | A0 | B0; counted vmcnt 4 4 4 6):
+// -0.2 % per DiT-L/2 forward, bit-identical (profiles/r06_dma_phase_balance.txt) -- not the default.
 #ifndef G256H_DEFAULT_OPT
 #define G256H_DEFAULT_OPT 1
 #endif
@@ -548,6 +550,20 @@ __global__ __launch_bounds__(512) void gemm256h_tn_kernel(ASrc asrc, const half_
     char* cur = smem + BUF * G256Q_BUF_BYTES;
     char* oth = smem + (BUF ^ 1) * G256Q_BUF_BYTES;
     auto stage = [&](int P) {  // this phase's piece (P: which of its two LDS-DMAs)
+      if constexpr ((OPT & 4) != 0) {  // (round 6 experiment) pieces placed against the parts' fragment reads (12 | 4 | 8 | 0): none | B1(t+1) | A1(t+1) | A0(t+2) B0(t+2)
+        if constexpr (PH == 1) {
+          if (s1) issue_b(1, t + 1, oth + G256Q_SLOT_B1);
+        } else if constexpr (PH == 2) {
+          if (s1) issue_a(1, oth + G256Q_SLOT_A1);
+        } else if constexpr (PH == 3) {
+          if (s2) {
+            asrc.begin_tile(t + 2, G256Q_BK);
+            issue_a(0, cur + G256Q_SLOT_A0);
+            issue_b(0, t + 2, cur + G256Q_SLOT_B0);
+          }
+        }
+        return;
+      }
       if constexpr (PH == 0) {
         if (s1) issue_b(1, t + 1, oth + G256Q_SLOT_B1, P);
       } else if constexpr (PH == 1) {
@@ -594,6 +610,12 @@ __global__ __launch_bounds__(512) void gemm256h_tn_kernel(ASrc asrc, const half_
     stage((OPT & 2) != 0 ? 2 : 0);
     if constexpr (ABL == 1 || ABL == 3 || (ABL >= 5 && ABL <= 7)) {
       G256H_VMCNT(0);
+    } else if constexpr ((OPT & 4) != 0) {  // issue order per K-tile: B1 B1 | A1 A1 | A0 A0 B0 B0; the LOAD part after next reads what has landed here
+      if (s1) {
+        if constexpr (PH < 3) G256H_VMCNT(4);
+        else if (s2) G256H_VMCNT(6);
+        else G256H_VMCNT(2);
+      } else G256H_VMCNT(0);
     } else if (s2) G256H_VMCNT(6);  // pieces allowed in flight: 3 3 3 3 | 3 3 2 1 | 0 0 0 0
     else if (s1) {
       if constexpr (PH < 2) G256H_VMCNT(6);

@@ -17,7 +17,8 @@
 // tile: wave (g, wn) owns rows g*128.. x 48 columns of the head, gathered by the DMA source addresses of the W rows -- accumulator tiles j = 0, 1: 32 dims of
 // Q (waves wn = 0, 1) or of K (wn = 2, 3), interleaved in fours so that a lane's two tiles are EIGHT CONSECUTIVE dims of a row (one 16-byte write in the
 // hand-over); tile j = 2: V dims 16 wn .. + 15.  Piece B0 = the Q and K rows (128 rows, 16 KiB, as before), piece B1 = the V rows (64 rows, 8 KiB: ONE LDS-DMA
-// per thread), so the phases are A0xB0 (16 MFMAs) | A0xB1 (8) | A1xB1 (8) | A1xB0 (16) and the counted vmcnt waits 5 5 5 6 instead of 6 6 6 6.  The V tile is
+// per thread), so the phases are A0xB0 (16 MFMAs) | A0xB1 (8) | A1xB1 (8) | A1xB0 (16); the seven LDS-DMAs of a K-tile are spread over the LOAD parts as 0 | 3 | 1 | 3
+// (against the parts' 12 | 2 | 8 | 0 fragment reads), counted vmcnt waits 4 5 4 6.  The V tile is
 // issued with the operands swapped (a lane then owns FOUR CONSECUTIVE TOKENS of one head dim: half a 16-byte chunk of a V^T row, the other half in lane +- 32).
 //
 // PERSISTENT workgroups (one per CU, items strided over the grid).  Measured with one workgroup per item (profiles/r06_fused_qkv_attention.txt): of 122 us the
@@ -142,23 +143,35 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(const half_t* __rest
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (PH == 0) {
-      if (s1) issue_b1(t + 1, oth + G256Q_SLOT_B1);
-    } else if constexpr (PH == 1) {
-      if (s1) issue_a(1, t + 1, oth + G256Q_SLOT_A1);
+    // Which LDS-DMAs go out in which LOAD part is balanced against the part's fragment reads (12 | 2 | 8 | 0): none | B1(t+1) A1(t+1) A1(t+1) | A0(t+2) | A0(t+2)
+    // B0(t+2) B0(t+2).  A barrier interval lasts as long as the slower wave group's (LOAD + MFMA) pair -- with a DMA at ~110 cycles of the issuing wave and a read
+    // at ~30, the gemm256h placement (1 | 2 | 2 | 2 here) makes the 12-read part the longest of all; see profiles/r06_dma_phase_balance.txt.  Legal: a slot is
+    // refilled after both groups' reads of it (A0 / B0 of this tile: read in LOAD 0, one interval apart), and every piece still has >= 3 intervals to land.
+    if constexpr (PH == 1) {
+      if (s1) {
+        issue_b1(t + 1, oth + G256Q_SLOT_B1);
+        issue_a(1, t + 1, oth + G256Q_SLOT_A1);
+      }
     } else if constexpr (PH == 2) {
-      if (s2) issue_a(0, t + 2, cur + G256Q_SLOT_A0);
-    } else {
-      if (s2) issue_b0(t + 2, cur + G256Q_SLOT_B0);
+      if (s2) glds16_buf(rsa, avoff[0][0], (unsigned)(t + 2) * (G256Q_BK * 2), cur + G256Q_SLOT_A0 + dma_off);
+    } else if constexpr (PH == 3) {
+      if (s2) {
+        glds16_buf(rsa, avoff[0][1], (unsigned)(t + 2) * (G256Q_BK * 2), cur + G256Q_SLOT_A0 + 8192 + dma_off);
+        issue_b0(t + 2, cur + G256Q_SLOT_B0);
+      }
     }
-    // DMAs of the three newest pieces may still fly (A0 / B0 / A1: two per wave, B1: one)
+    // counted waits: what the LOAD part after next reads has landed (a barrier lies in between); newer DMAs may still fly.  Issue order per K-tile:
+    // B1 A1 A1 | A0 | A0 B0 B0
     if (s2) {
-      if constexpr (PH < 3) QKVA_VMCNT(5);
-      else QKVA_VMCNT(6);
+      if constexpr (PH == 0) QKVA_VMCNT(4);       // A1(t) landed; A0(t+1) x2, B0(t+1) x2 may fly
+      else if constexpr (PH == 1) QKVA_VMCNT(5);  // A0(t+1) landed; B0(t+1) x2, B1(t+1), A1(t+1) x2
+      else if constexpr (PH == 2) QKVA_VMCNT(4);  // B0(t+1) landed; B1(t+1), A1(t+1) x2, A0(t+2)
+      else QKVA_VMCNT(6);                         // B1(t+1) landed; A1(t+1) x2, A0(t+2) x2, B0(t+2) x2
     } else if (s1) {
-      if constexpr (PH < 2) QKVA_VMCNT(5);
-      else if constexpr (PH == 2) QKVA_VMCNT(3);
-      else QKVA_VMCNT(2);
+      if constexpr (PH == 0) QKVA_VMCNT(4);
+      else if constexpr (PH == 1) QKVA_VMCNT(5);
+      else if constexpr (PH == 2) QKVA_VMCNT(3);  // B0(t+1) landed; B1(t+1), A1(t+1) x2
+      else QKVA_VMCNT(2);                         // B1(t+1) landed; A1(t+1) x2
     } else QKVA_VMCNT(0);
   };
   // MFMA part of phase PH: A sub (64 rows) x {Q, K tiles | V tile} x K = 64
