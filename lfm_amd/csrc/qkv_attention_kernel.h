@@ -145,7 +145,9 @@ __global__ __launch_bounds__(512) void qkv_attention_kernel(const half_t* __rest
     __builtin_amdgcn_sched_barrier(0);
     // Which LDS-DMAs go out in which LOAD part is balanced against the part's fragment reads (12 | 2 | 8 | 0): none | B1(t+1) A1(t+1) A1(t+1) | A0(t+2) | A0(t+2)
     // B0(t+2) B0(t+2).  A barrier interval lasts as long as the slower wave group's (LOAD + MFMA) pair -- with a DMA at ~110 cycles of the issuing wave and a read
-    // at ~30, the gemm256h placement (1 | 2 | 2 | 2 here) makes the 12-read part the longest of all; see profiles/r06_dma_phase_balance.txt.  Legal: a slot is
+    // at ~30, the gemm256h placement (1 | 2 | 2 | 2 here) makes the 12-read part the longest of all; see profiles/r06_dma_phase_balance.txt (-0.25 % per forward:
+    // far less than that model says; splitting the twelve READS of phase 0 over two parts as well -- B0 fragments of the next K-tile prefetched in part 3 -- was
+    // slower by 0.8 %).  Legal: a slot is
     // refilled after both groups' reads of it (A0 / B0 of this tile: read in LOAD 0, one interval apart), and every piece still has >= 3 intervals to land.
     if constexpr (PH == 1) {
       if (s1) {
